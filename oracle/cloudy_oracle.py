@@ -1,0 +1,371 @@
+"""ctypes binding of the CPU oracle (oracle/cloudy_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; the product package (cloudy.jl_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libcloudy_oracle.so")
+
+MAX_MODES, MAX_P, MAX_VEL = 8, 8, 8
+EXPONENTIAL, GAMMA, MONODISPERSE, LOGNORMAL = 0, 1, 2, 3
+FIXED_THRESHOLD, MOVING_THRESHOLD = 0, 1
+
+
+def build(force=False):
+    """Compile the oracle with gcc (recipe: oracle/Makefile)."""
+    src = [os.path.join(_HERE, f) for f in ("cloudy_oracle.c", "cloudy_oracle.h")]
+    if (not force and os.path.exists(_LIB_PATH)
+            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src)):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "libcloudy_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+class Dist(C.Structure):
+    _fields_ = [("type", C.c_int), ("n", C.c_double), ("theta", C.c_double), ("k", C.c_double)]
+
+    def __repr__(self):
+        return f"Dist(type={self.type}, n={self.n!r}, theta={self.theta!r}, k={self.k!r})"
+
+
+class CoalData(C.Structure):
+    _fields_ = [
+        ("N", C.c_int), ("P", C.c_int), ("N_mom_max", C.c_int),
+        ("N_2d_ints", C.c_int * MAX_MODES),
+        ("dist_thresholds", C.c_double * MAX_MODES),
+        ("c", C.c_double * (MAX_MODES * MAX_MODES * MAX_P * MAX_P)),
+    ]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("N", C.c_int),
+        ("dist_type", C.c_int * MAX_MODES),
+        ("NProgMoms", C.c_int * MAX_MODES),
+        ("norms", C.c_double * 2),
+        ("k_range", C.c_double * 2),
+        ("threshold_style", C.c_int),
+        ("coal_data", CoalData),
+        ("n_vel", C.c_int),
+        ("vel", C.c_double * (MAX_VEL * 2)),
+    ]
+
+
+_lib = None
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.co_gamma.restype = C.c_double
+        L.co_gamma.argtypes = [C.c_double]
+        L.co_gamma_inc_p.restype = C.c_double
+        L.co_gamma_inc_p.argtypes = [C.c_double, C.c_double]
+        L.co_gamma_inc_inv.restype = C.c_double
+        L.co_gamma_inc_inv.argtypes = [C.c_double] * 3
+        L.co_get_dist_moment_ind.argtypes = [_ip, C.c_int, C.c_int, C.c_int]
+        L.co_get_dist_moments_ind_range.argtypes = [_ip, C.c_int, C.c_int, _ip, _ip]
+        L.co_get_moments_normalizing_factors.argtypes = [_ip, C.c_int, _dp, _dp]
+        L.co_check_symmetry.argtypes = [_dp, C.c_int]
+        L.co_get_normalized_kernel_tensor.argtypes = [_dp, C.c_int, _dp, _dp]
+        for f in ("co_constant_kernel", "co_linear_kernel", "co_hydrodynamic_kernel"):
+            getattr(L, f).restype = C.c_double
+            getattr(L, f).argtypes = [C.c_double] * 3
+        L.co_long_kernel.restype = C.c_double
+        L.co_long_kernel.argtypes = [C.c_double] * 5
+        L.co_nparams.argtypes = [C.c_int]
+        L.co_dist_valid.argtypes = [C.POINTER(Dist)]
+        L.co_moment.restype = C.c_double
+        L.co_moment.argtypes = [C.POINTER(Dist), C.c_double]
+        L.co_get_moments.argtypes = [C.POINTER(Dist), _dp]
+        L.co_density.restype = C.c_double
+        L.co_density.argtypes = [C.POINTER(Dist), C.c_double]
+        L.co_normed_density.restype = C.c_double
+        L.co_normed_density.argtypes = [C.POINTER(Dist), C.c_double]
+        L.co_update_dist_from_moments.argtypes = [C.c_int, _dp, C.c_int, _dp, C.POINTER(Dist)]
+        L.co_moment_source_helper.restype = C.c_double
+        L.co_moment_source_helper.argtypes = [C.POINTER(Dist), C.c_double, C.c_double, C.c_double, C.c_int]
+        L.co_compute_threshold.restype = C.c_double
+        L.co_compute_threshold.argtypes = [C.POINTER(Dist), C.c_double, C.c_double]
+        L.co_compute_thresholds.argtypes = [C.POINTER(Dist), C.c_int, _dp, _dp]
+        L.co_coalescence_data_init.argtypes = [C.POINTER(CoalData), C.c_int, C.c_int, _dp, _ip, _dp, _dp, C.c_int]
+        L.co_get_coal_ints.argtypes = [C.POINTER(Dist), C.POINTER(CoalData), C.c_int, _dp, _dp]
+        L.co_get_moments_matrix.argtypes = [C.POINTER(Dist), C.c_int, C.c_int, C.c_int, _dp]
+        L.co_get_finite_2d_integrals.argtypes = [C.POINTER(Dist), C.c_int, C.c_int, _dp, _dp, _ip, _dp]
+        L.co_weighting_fn.restype = C.c_double
+        L.co_weighting_fn.argtypes = [C.c_double, C.c_int, C.POINTER(Dist), C.c_int]
+        L.co_get_sedimentation_flux.argtypes = [C.POINTER(Dist), C.c_int, _dp, C.c_int, _dp]
+        L.co_rhs_coal.argtypes = [C.POINTER(Params), _dp, _dp, _dp]
+        L.co_rhs_coal_batch.argtypes = [C.POINTER(Params), C.c_long, C.c_long, _dp, _dp, _dp, C.c_int]
+        L.co_rainshaft_cell_batch.argtypes = [C.POINTER(Params), C.c_long, C.c_long, _dp, _dp, _dp, C.c_int]
+        L.co_update_dist_batch.argtypes = [C.POINTER(Params), C.c_long, C.c_long, _dp, _dp]
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _darr(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float64))
+
+
+def _iarr(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.int32))
+
+
+# ---- special functions ------------------------------------------------------------------
+def gamma(x):
+    return lib().co_gamma(float(x))
+
+
+def gamma_inc_p(a, x):
+    return lib().co_gamma_inc_p(float(a), float(x))
+
+
+def gamma_inc_inv(a, p, q=None):
+    return lib().co_gamma_inc_inv(float(a), float(p), float(1.0 - p if q is None else q))
+
+
+# ---- helper_functions.jl ----------------------------------------------------------------
+def get_dist_moment_ind(NProgMoms, i, m):
+    a = _iarr(NProgMoms)
+    r = lib().co_get_dist_moment_ind(a.ctypes.data_as(_ip), len(a), int(i), int(m))
+    if r < 0:
+        raise ValueError("moment index must be positive integer and equal or smaller than the dist number "
+                         "of prognostic moments!!!")
+    return r
+
+
+def get_dist_moments_ind_range(NProgMoms, i):
+    a = _iarr(NProgMoms)
+    f, l = C.c_int(), C.c_int()
+    if lib().co_get_dist_moments_ind_range(a.ctypes.data_as(_ip), len(a), int(i), C.byref(f), C.byref(l)) < 0:
+        raise IndexError("distribution index out of range")
+    return range(f.value, l.value + 1)
+
+
+def get_moments_normalizing_factors(NProgMoms, norms):
+    a = _iarr(NProgMoms)
+    nn = _darr(norms)
+    out = np.zeros(int(a.sum()))
+    r = lib().co_get_moments_normalizing_factors(a.ctypes.data_as(_ip), len(a), _d(nn), _d(out))
+    if r < 0:
+        raise ValueError("norms must be positive!")
+    return out
+
+
+# ---- KernelTensors.jl ---------------------------------------------------------------------
+def check_symmetry(c):
+    c = _darr(c)
+    if c.ndim != 2 or c.shape[0] != c.shape[1]:
+        raise ValueError("array needs to be quadratic in order to be symmetric.")
+    if lib().co_check_symmetry(_d(c), c.shape[0]) != 0:
+        raise ValueError("array not symmetric.")
+
+
+def get_normalized_kernel_tensor(c, norms):
+    c = _darr(c)
+    out = np.zeros_like(c)
+    lib().co_get_normalized_kernel_tensor(_d(c), c.shape[0], _d(_darr(norms)), _d(out))
+    return out
+
+
+# ---- ParticleDistributions.jl -------------------------------------------------------------
+def make_dist(dist_type, n, theta, k=1.0):
+    d = Dist(int(dist_type), float(n), float(theta), float(k))
+    if not lib().co_dist_valid(C.byref(d)):
+        raise ValueError("invalid distribution parameters")
+    return d
+
+
+def nparams(dist_type):
+    return lib().co_nparams(int(dist_type))
+
+
+def moment(d, q):
+    return lib().co_moment(C.byref(d), float(q))
+
+
+def get_moments(d):
+    out = np.zeros(nparams(d.type))
+    lib().co_get_moments(C.byref(d), _d(out))
+    return out
+
+
+def density(d, x):
+    if x < 0:
+        raise ValueError("Density can only be evaluated at nonnegative values.")
+    return lib().co_density(C.byref(d), float(x))
+
+
+def normed_density(d, x):
+    if x < 0:
+        raise ValueError("Density can only be evaluated at nonnegative values.")
+    return lib().co_normed_density(C.byref(d), float(x))
+
+
+def update_dist_from_moments(dist_type, moments, k_range=None):
+    m = _darr(moments)
+    out = Dist()
+    kr = _darr(k_range) if k_range is not None else None
+    r = lib().co_update_dist_from_moments(int(dist_type), _d(m), len(m), _d(kr) if kr is not None else None,
+                                          C.byref(out))
+    if r != 0:
+        raise TypeError("no method matching update_dist_from_moments for this number of moments")
+    return out
+
+
+def moment_source_helper(d, p1, p2, x_threshold, n_bins_per_log_unit=15):
+    return lib().co_moment_source_helper(C.byref(d), float(p1), float(p2), float(x_threshold),
+                                         int(n_bins_per_log_unit))
+
+
+def compute_threshold(d, percentile=0.97, minx=1e-18):
+    return lib().co_compute_threshold(C.byref(d), float(percentile), float(minx))
+
+
+def compute_thresholds(pdists, percentiles=None):
+    arr = (Dist * len(pdists))(*pdists)
+    out = np.zeros(len(pdists))
+    pc = _darr(percentiles) if percentiles is not None else None
+    lib().co_compute_thresholds(arr, len(pdists), _d(pc) if pc is not None else None, _d(out))
+    return out
+
+
+# ---- Coalescence.jl -------------------------------------------------------------------------
+def coalescence_data(kernel_c, NProgMoms, dist_thresholds, norms=(1.0, 1.0), threshold_style=FIXED_THRESHOLD):
+    """kernel_c: [P,P] (one tensor for all pairs, Coalescence.jl:89-104) or [N,N,P,P]."""
+    npm = _iarr(NProgMoms)
+    N = len(npm)
+    kc = _darr(kernel_c)
+    if kc.ndim == 2:
+        kc = np.ascontiguousarray(np.broadcast_to(kc, (N, N) + kc.shape))
+    P = kc.shape[-1]
+    cd = CoalData()
+    r = lib().co_coalescence_data_init(C.byref(cd), N, P, _d(kc), npm.ctypes.data_as(_ip),
+                                       _d(_darr(dist_thresholds)), _d(_darr(norms)), int(threshold_style))
+    if r == -2:
+        raise ValueError("array not symmetric.")
+    if r != 0:
+        raise ValueError("invalid CoalescenceData arguments")
+    return cd
+
+
+def get_coal_ints(pdists, coal_data, threshold_style=FIXED_THRESHOLD, with_scale=False):
+    arr = (Dist * len(pdists))(*pdists)
+    nm = sum(nparams(d.type) for d in pdists)
+    out, sc = np.zeros(nm), np.zeros(nm)
+    lib().co_get_coal_ints(arr, C.byref(coal_data), int(threshold_style), _d(out), _d(sc))
+    return (out, sc) if with_scale else out
+
+
+def get_moments_matrix(pdists, M, N_mom_max):
+    arr = (Dist * len(pdists))(*pdists)
+    out = np.zeros((len(pdists), M))
+    lib().co_get_moments_matrix(arr, len(pdists), M, N_mom_max, _d(out))
+    return out
+
+
+def get_finite_2d_integrals(pdists, thresholds, moments, N_2d_ints):
+    arr = (Dist * len(pdists))(*pdists)
+    N, M = moments.shape
+    F = np.zeros((N, M, M))
+    n2 = _iarr(N_2d_ints)
+    lib().co_get_finite_2d_integrals(arr, N, M, _d(_darr(thresholds)), _d(_darr(moments)),
+                                     n2.ctypes.data_as(_ip), _d(F))
+    return F
+
+
+def weighting_fn(x, k, pdists):
+    arr = (Dist * len(pdists))(*pdists)
+    r = lib().co_weighting_fn(float(x), int(k), arr, len(pdists))
+    if r != r:
+        raise AssertionError("k out of range")
+    return r
+
+
+def get_sedimentation_flux(pdists, vel):
+    arr = (Dist * len(pdists))(*pdists)
+    v = _darr(vel).reshape(-1, 2)
+    nm = sum(nparams(d.type) for d in pdists)
+    out = np.zeros(nm)
+    lib().co_get_sedimentation_flux(arr, len(pdists), _d(v), v.shape[0], _d(out))
+    return out
+
+
+# ---- box_model_helpers.jl / rainshaft_helpers.jl --------------------------------------------
+def make_params(dist_types, kernel_c, dist_thresholds, norms=(1.0, 1.0), threshold_style=FIXED_THRESHOLD,
+                k_range=(np.finfo(np.float64).eps, 10.0), vel=()):
+    p = Params()
+    N = len(dist_types)
+    p.N = N
+    npm = [nparams(t) for t in dist_types]
+    for i in range(N):
+        p.dist_type[i] = int(dist_types[i])
+        p.NProgMoms[i] = npm[i]
+    p.norms[0], p.norms[1] = float(norms[0]), float(norms[1])
+    p.k_range[0], p.k_range[1] = float(k_range[0]), float(k_range[1])
+    p.threshold_style = int(threshold_style)
+    p.coal_data = coalescence_data(kernel_c, npm, dist_thresholds, norms, threshold_style)
+    v = _darr(vel).reshape(-1, 2)
+    p.n_vel = v.shape[0]
+    for i in range(v.shape[0]):
+        p.vel[2 * i], p.vel[2 * i + 1] = v[i, 0], v[i, 1]
+    return p
+
+
+def nmom_of(p):
+    return sum(p.NProgMoms[i] for i in range(p.N))
+
+
+def rhs_coal(p, mom, with_scale=False):
+    m = _darr(mom)
+    d, s = np.zeros_like(m), np.zeros_like(m)
+    if lib().co_rhs_coal(C.byref(p), _d(m), _d(d), _d(s)) < 0:
+        raise ValueError("rhs_coal failed")
+    return (d, s) if with_scale else d
+
+
+def rhs_coal_batch(p, mom, with_scale=False, n_threads=0):
+    """mom: [nmom, n_parcels] moment-major (C-contiguous) -> dmom of the same shape."""
+    m = _darr(mom)
+    nm, n = m.shape
+    assert nm == nmom_of(p)
+    d = np.empty_like(m)
+    s = np.empty_like(m) if with_scale else None
+    if lib().co_rhs_coal_batch(C.byref(p), n, n, _d(m), _d(d), _d(s) if s is not None else None, int(n_threads)) < 0:
+        raise ValueError("rhs_coal_batch failed")
+    return (d, s) if with_scale else d
+
+
+def rainshaft_cell_batch(p, mom, n_threads=0):
+    m = _darr(mom)
+    nm, n = m.shape
+    cs, sf = np.empty_like(m), np.empty_like(m)
+    lib().co_rainshaft_cell_batch(C.byref(p), n, n, _d(m), _d(cs), _d(sf), int(n_threads))
+    return cs, sf
+
+
+def update_dist_batch(p, mom):
+    m = _darr(mom)
+    nm, n = m.shape
+    out = np.empty((3 * p.N, n))
+    if lib().co_update_dist_batch(C.byref(p), n, n, _d(m), _d(out)) < 0:
+        raise ValueError("update_dist_batch failed")
+    return out
+
+
+def max_threads():
+    return lib().co_max_threads()
