@@ -1,0 +1,300 @@
+#!/usr/bin/env python3
+"""bench.py -- parcel moment-RHS evaluations per second of the MI355X coalescence kernel.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--parcels P] [--workload cfg3a|cfg3b|cfg2]
+
+One "step" = one pass of the hot path (cloudy_coal_rhs: normalise -> closure inversion -> moments ->
+finite 2-D integrals -> Q/R/S -> de-normalise) over one device-resident batch of synthetic parcels.
+Headline workload (BASELINE.json configs[2], SURVEY.md 8(d) "cfg3a"): 1e7 parcels per GPU, two Gamma modes,
+order-2 polynomial CoalescenceTensors (the exact pieces of Long's kernel), 6 prognostic moments, fp64,
+thresholds (Inf, Inf).  The same batch with the reference example's finite threshold (5e-10 kg, Inf)
+("cfg3b", the Simpson / incomplete-gamma path) is measured in the same run and reported under "variants".
+
+Multi-GPU: one process per GPU (torch.distributed, backend nccl = RCCL); parcels shard with no data-path
+collective (weak scaling: every rank owns --parcels parcels).  The only collective is the all-reduce of the
+nmom tendency sums for the mass-conservation diagnostic, outside the per-step path.
+
+Rank 0 prints ONE JSON line (see the keys at the bottom).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SEED = 20260723
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+NORMS = (1e6, 1e-9)    # every reference example, e.g. box_single_gamma.jl:25
+INF = float("inf")
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic Gamma-mixture batches; the generator is shared by tests and smoke()
+# ------------------------------------------------------------------------------------------------
+def _gamma_mode(rng, n, n_lo, n_hi, k_lo, k_hi, x_lo, x_hi):
+    nn = 10.0 ** rng.uniform(np.log10(n_lo), np.log10(n_hi), n)
+    k = rng.uniform(k_lo, k_hi, n)
+    xbar = 10.0 ** rng.uniform(np.log10(x_lo), np.log10(x_hi), n)
+    th = xbar / k
+    # get_moments, ParticleDistributions.jl:293-299
+    return np.stack([nn, nn * k * th, nn * k * (k + 1.0) * th * th])
+
+
+def synth_moments(n_modes, n, seed=SEED, degenerate_frac=0.01):
+    """(3*n_modes, n) physical moments: cloud, rain, (drizzle-size third) Gamma modes, ~1 % degenerate parcels."""
+    rng = np.random.Generator(np.random.Philox(key=seed))
+    specs = [(1e6, 1e9, 0.5, 8.0, 1e-11, 1e-9), (1.0, 1e5, 1.0, 6.0, 1e-9, 1e-7), (1e-3, 1e2, 1.0, 6.0, 1e-7, 1e-5),
+             (1e-6, 1e-1, 1.0, 6.0, 1e-5, 1e-3)]
+    mom = np.concatenate([_gamma_mode(rng, n, *specs[i]) for i in range(n_modes)], axis=0)
+    nd = int(n * degenerate_frac)
+    if nd > 0:
+        idx = rng.choice(n, nd, replace=False)
+        kind = rng.integers(0, 4, nd)
+        for mode in range(n_modes):
+            r = 3 * mode
+            z = idx[kind == 0]          # empty mode: M0 <= eps -> fallback (0, 1, 1)
+            mom[r:r + 3, z] = 0.0
+            s = idx[kind == 1]          # zero variance: M2/M1 == M1/M0 -> k = +Inf -> clamp 10
+            mom[r + 2, s] = mom[r + 1, s] ** 2 / mom[r, s]
+            g = idx[kind == 2]          # negative variance -> k < 0 -> clamp eps
+            mom[r + 2, g] = 0.5 * mom[r + 1, g] ** 2 / mom[r, g]
+            h = idx[kind == 3]          # very narrow: k just above the upper clamp
+            mom[r + 2, h] = mom[r + 1, h] ** 2 / mom[r, h] * (1.0 + 1.0 / 25.0)
+    return np.ascontiguousarray(mom)
+
+
+def workload_spec(name):
+    """-> (n_modes, kernel pieces, thresholds) of a named workload, physical units."""
+    long_k = dict(x_threshold=5.236e-10, below=9.44e9, above=5.78)  # box_gamma_mixture_long.jl:20
+    if name == "cfg2":   # 1 Gamma mode, Golovin b = 5 (box_single_gamma.jl:19), thr (Inf,)
+        return dict(n_modes=1, kernel="golovin", thresholds=(INF,), default_parcels=1_000_000)
+    if name == "cfg3a":  # 2 Gamma modes, Long pieces order 2, thr (Inf, Inf)
+        return dict(n_modes=2, kernel="long", long=long_k, thresholds=(INF, INF), default_parcels=10_000_000)
+    if name == "cfg3b":  # same, reference thresholds (box_gamma_mixture_long.jl:36)
+        return dict(n_modes=2, kernel="long", long=long_k, thresholds=(5e-10, INF), default_parcels=10_000_000)
+    raise ValueError(f"unknown workload {name}")
+
+
+def kernel_matrix(spec):
+    """[N, N, P, P] un-normalised coefficient tensors (physical units)."""
+    N = spec["n_modes"]
+    eps = float(np.finfo(np.float64).eps)
+    if spec["kernel"] == "golovin":
+        c = np.array([[eps, 5.0], [5.0, 0.0]])  # CoalescenceTensor(LinearKernelFunction(5.0), 1, 1e-6): C_1_1 = eps
+        return np.broadcast_to(c, (N, N, 2, 2)).copy()
+    lk = spec["long"]
+    kc = np.zeros((N, N, 3, 3))
+    for j in range(N):
+        for k in range(N):
+            kc[j, k, 0, 0] = eps
+            if j == 0 and k == 0:   # CoalescenceTensor(kernel_func, 2, 5e-10): below-threshold piece b (x^2 + y^2)
+                kc[j, k, 0, 2] = kc[j, k, 2, 0] = lk["below"]
+            else:                   # CoalescenceTensor(kernel_func, 2, 1e-6, 5e-10): a (x + y)
+                kc[j, k, 0, 1] = kc[j, k, 1, 0] = lk["above"]
+    return kc
+
+
+def make_workload(name, n_parcels, seed=SEED):
+    """Product-side objects of a workload: moments, CoalescenceData, ODE parameters (no oracle involved)."""
+    import __graft_entry__ as ge
+
+    pkg = ge.load_package()
+    spec = workload_spec(name)
+    N = spec["n_modes"]
+    kc = kernel_matrix(spec)
+    kernels = tuple(tuple(pkg.CoalescenceTensor(kc[j, k]) for k in range(N)) for j in range(N))
+    NProgMoms = (3,) * N
+    coal_data = pkg.CoalescenceData(kernels, NProgMoms, spec["thresholds"], NORMS)
+    pdists = tuple(pkg.GammaPrimitiveParticleDistribution(1.0, 1.0, 1.0) for _ in range(N))
+    par = pkg.ODEParameters(pdists, coal_data, NProgMoms, NORMS)
+    return dict(name=name, spec=spec, mom=synth_moments(N, n_parcels, seed), coal_data=coal_data,
+                dist_types=[1] * N, par=par, kernel_c=kc, NProgMoms=NProgMoms)
+
+
+def oracle_params(name):
+    """co_params of the CPU oracle for a workload (checker / cpu_baseline only)."""
+    from oracle import cloudy_oracle as O
+
+    spec = workload_spec(name)
+    return O.make_params([O.GAMMA] * spec["n_modes"], kernel_matrix(spec), spec["thresholds"], norms=NORMS)
+
+
+# ------------------------------------------------------------------------------------------------
+def _dist_setup(n_gpus):
+    """torch.distributed over RCCL when launched by torch.distributed.run; -> (rank, world, dist or None)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1:
+        return 0, 1, 0, None, None
+    import torch  # imported BEFORE libcloudy_hip.so so that both share one HIP runtime (same SONAME)
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                            device_id=torch.device("cuda", local_rank))
+    return rank, world, local_rank, dist, torch
+
+
+def _time_steps(pkg, plan, m, dm, steps, dist, torch):
+    """EXACTLY `steps` launches between barrier+sync brackets; returns wall seconds (max over ranks)."""
+    L = pkg.lib()
+    n, ld = m.shape[1], m.shape[1]
+    if dist is not None:
+        torch.cuda.synchronize()
+        dist.barrier()
+    pkg._lib.check(L.cloudy_stream_synchronize(None))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pkg._lib.check(L.cloudy_coal_rhs(plan.handle, n, ld, m.ptr, dm.ptr, None))
+    pkg._lib.check(L.cloudy_stream_synchronize(None))
+    if dist is not None:
+        torch.cuda.synchronize()
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def _event_ms(pkg, plan, m, dm, iters):
+    """Average launch duration from HIP events recorded on the launch stream (cloudy_time_coal_rhs)."""
+    import ctypes as C
+
+    ms = C.c_float()
+    pkg._lib.check(pkg.lib().cloudy_time_coal_rhs(plan.handle, m.shape[1], m.shape[1], m.ptr, dm.ptr, None, iters,
+                                                  C.byref(ms)))
+    return float(ms.value)
+
+
+def _run_workload(pkg, name, n_parcels, steps, warmup, rank, dist, torch):
+    wl = make_workload(name, n_parcels, seed=SEED + 1000 * rank)
+    plan = wl["coal_data"].plan(wl["dist_types"])
+    m = pkg.DeviceArray.from_numpy(wl["mom"])
+    dm = pkg.DeviceArray.zeros(*wl["mom"].shape)
+    rhs = pkg.make_box_model_rhs(pkg.AnalyticalCoalStyle())
+    for _ in range(max(warmup, 1)):
+        rhs(dm, m, wl["par"], 0.0)
+    wall = _time_steps(pkg, plan, m, dm, steps, dist, torch)
+    ev_ms = _event_ms(pkg, plan, m, dm, steps)
+    # conservation diagnostic: sum over parcels and modes of dM1 must vanish (mass is conserved)
+    sums = pkg.moment_sums(plan, dm)
+    gsums = pkg.allreduce_sums(sums) if dist is not None else sums
+    tot = pkg.mode_sums(gsums, wl["NProgMoms"])
+    # mode 0 only loses mass (it collects nothing), so |sum_p dM1_mode0| is the gross mass-transfer rate
+    gross = abs(float(gsums[1]))
+    return dict(wl=wl, plan=plan, wall=wall, event_ms=ev_ms, mass_rate_sum=float(tot[1]), mass_rate_gross=gross,
+                nmom=plan.nmom)
+
+
+def _cpu_baseline(name, target_seconds=12.0):
+    """The C oracle (kind 'port' of the reference algorithm) on the host cores, bounded sample of the same batch."""
+    from oracle import cloudy_oracle as O
+
+    p = oracle_params(name)
+    nthreads = O.max_threads()
+    n_modes = workload_spec(name)["n_modes"]
+    probe = synth_moments(n_modes, 2000, SEED)
+    t0 = time.perf_counter()
+    O.rhs_coal_batch(p, probe, n_threads=nthreads)
+    per = max((time.perf_counter() - t0) / probe.shape[1], 1e-9)
+    n = int(min(max(target_seconds / per, 2000), 4_000_000))
+    mom = synth_moments(n_modes, n, SEED)
+    t0 = time.perf_counter()
+    O.rhs_coal_batch(p, mom, n_threads=nthreads)
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="parcel-RHS/s", cores=nthreads, kind="port",
+                sample=f"{n} parcels of the {name} batch, oracle/cloudy_oracle.c (C restatement of the Julia "
+                       f"reference; julia is not installed), OpenMP x{nthreads}, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--parcels", type=int, default=0, help="parcels per GPU (default: the workload's size)")
+    ap.add_argument("--workload", default="cfg3a")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local_rank, dist, torch = _dist_setup(args.gpus)
+    import __graft_entry__ as ge
+
+    pkg = ge.load_package()
+    if pkg.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the coalescence RHS has no CPU fallback")
+    pkg._lib.check(pkg.lib().cloudy_set_device(local_rank))
+
+    spec = workload_spec(args.workload)
+    n_local = args.parcels or spec["default_parcels"]
+    res = _run_workload(pkg, args.workload, n_local, args.steps, args.warmup, rank, dist, torch)
+    nmom = res["nmom"]
+    bytes_per_eval = 2 * nmom * 8  # read nmom moments + write nmom tendencies, fp64
+    total = n_local * world
+    value = total * args.steps / res["wall"]
+    achieved = bytes_per_eval * n_local / (res["event_ms"] * 1e-3) / 1e9
+
+    variants = {}
+    if not args.no_variants and args.workload == "cfg3a":
+        v = _run_workload(pkg, "cfg3b", n_local, max(3, args.steps // 10), 1, rank, dist, torch)
+        v_steps = max(3, args.steps // 10)
+        variants["cfg3b"] = {
+            "workload": "same batch, thresholds (5e-10 kg, Inf): Simpson / incomplete-gamma path "
+                        "(box_gamma_mixture_long.jl:36); fp64-VALU bound, not HBM bound",
+            "value": n_local * world * v_steps / v["wall"], "unit": "parcel-RHS/s",
+            "ms_per_step": 1e3 * v["wall"] / v_steps, "kernel_ms": v["event_ms"],
+            "hbm_GBs": bytes_per_eval * n_local / (v["event_ms"] * 1e-3) / 1e9,
+            "mass_rate_residual": abs(v["mass_rate_sum"]) / max(v["mass_rate_gross"], 1e-300) if rank == 0 else None,
+        }
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = _cpu_baseline(args.workload)
+        if variants:
+            variants["cfg3b"]["cpu_baseline"] = _cpu_baseline("cfg3b", target_seconds=10.0)
+
+    if rank == 0:
+        out = {
+            "metric": "parcel moment-RHS evals/sec at 1e7 parcels; achieved HBM GB/s vs 8 TB/s peak",
+            "value": value,
+            "unit": "parcel-RHS/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * res["wall"] / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {n_local} parcels/GPU, {spec['n_modes']}-mode Gamma mixture, "
+                                   f"order-{2 if spec['kernel'] == 'long' else 1} polynomial CoalescenceTensor, "
+                                   f"{nmom} moments, thresholds {spec['thresholds']}, norms {NORMS}",
+                       "parcels_per_gpu": n_local, "global_parcels": total, "sharding": f"parcel ranges x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "coal_rhs_kernel", "kernel_ms": res["event_ms"],
+                         "algorithmic_bytes_per_launch": bytes_per_eval * n_local},
+            "cpu_baseline": cpu,
+            "mass_rate_residual": abs(res["mass_rate_sum"]) / max(res["mass_rate_gross"], 1e-300),
+            "variants": variants,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

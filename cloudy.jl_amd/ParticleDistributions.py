@@ -1,0 +1,92 @@
+"""Closure families and their batched inversion (src/ParticleDistributions/ParticleDistributions.jl).
+
+A distribution object is the host-side descriptor the reference passes as `p.pdists[i]`: in rhs_coal! only its
+TYPE matters (its parameters are overwritten by update_dist_from_moments, box_model_helpers.jl:32-38).  Batched
+parameter arrays live on the GPU as 3N planes (n, theta, k) per mode.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from .device import DeviceArray, as_device
+
+EXPONENTIAL, GAMMA = 0, 1
+
+
+class AbstractParticleDistribution:
+    pass
+
+
+class PrimitiveParticleDistribution(AbstractParticleDistribution):
+    pass
+
+
+@dataclass(frozen=True)
+class ExponentialPrimitiveParticleDistribution(PrimitiveParticleDistribution):
+    n: float
+    θ: float
+    type_id = EXPONENTIAL
+
+    def __post_init__(self):  # ParticleDistributions.jl:72-75
+        if self.n < 0 or self.θ <= 0:
+            raise ValueError("n needs to be nonnegative. θ needs to be positive.")
+
+
+@dataclass(frozen=True)
+class GammaPrimitiveParticleDistribution(PrimitiveParticleDistribution):
+    n: float
+    θ: float
+    k: float
+    type_id = GAMMA
+
+    def __post_init__(self):  # ParticleDistributions.jl:101-104
+        if self.n < 0 or self.θ <= 0 or self.k <= 0:
+            raise ValueError("n needs to be nonnegative. θ and k need to be positive.")
+
+
+def nparams(dist):
+    """ParticleDistributions.jl:425-427."""
+    return 3 if isinstance(dist, GammaPrimitiveParticleDistribution) else 2
+
+
+def get_moments(pdist):
+    """First nparams moments, closed form (ParticleDistributions.jl:293-315); used to build initial conditions."""
+    if isinstance(pdist, GammaPrimitiveParticleDistribution):
+        return [pdist.n, pdist.n * pdist.k * pdist.θ, pdist.n * pdist.k * (pdist.k + 1) * pdist.θ**2]
+    return [pdist.n, pdist.n * pdist.θ]
+
+
+def pack_params(pdists_batch):
+    """[(n, theta, k) arrays per mode] -> (3N, n_parcels) host array in the device plane order."""
+    rows = []
+    for d in pdists_batch:
+        n = np.asarray(d[0], dtype=np.float64)
+        th = np.asarray(d[1], dtype=np.float64)
+        k = np.asarray(d[2], dtype=np.float64) if len(d) > 2 else np.ones_like(n)
+        rows += [n, th, np.broadcast_to(k, n.shape)]
+    return np.ascontiguousarray(np.stack([np.atleast_1d(r) for r in rows]))
+
+
+def update_dist_from_moments(plan, mom, params_out=None, stream=None):
+    """Batched update_dist_from_moments (ParticleDistributions.jl:456-476, 512-523) on the GPU.
+
+    mom: (nmom, n) device array, physical units -> (3N, n) device array of (n, theta, k), normalised units."""
+    ptr, planes, n, ld = as_device(mom)
+    if planes != plan.nmom:
+        raise TypeError(f"no method matching update_dist_from_moments: expected {plan.nmom} moments, got {planes}")
+    out = params_out if params_out is not None else DeviceArray(3 * plan.N, n)
+    optr, oplanes, on, old = as_device(out)
+    if old != ld or oplanes != 3 * plan.N:
+        raise ValueError("params_out must be (3N, n) with the same leading dimension as mom")
+    _lib.check(_lib.lib().cloudy_update_dist_from_moments(plan.handle, n, ld, ptr, optr, stream))
+    return out
+
+
+def compute_thresholds(plan, params, out=None, stream=None):
+    """Per-parcel thresholds used by the S terms (ParticleDistributions.jl:734-761); (N, n) device array."""
+    ptr, planes, n, ld = as_device(params)
+    o = out if out is not None else DeviceArray(plan.N, n)
+    optr = as_device(o)[0]
+    _lib.check(_lib.lib().cloudy_compute_thresholds(plan.handle, n, ld, ptr, optr, stream))
+    return o

@@ -1,0 +1,20 @@
+"""Batched sedimentation flux (src/Sources/Sedimentation.jl:22-37) and the rainshaft per-cell sources
+(test/examples/utils/rainshaft_helpers.jl:52-78, without the inter-cell flux divergence)."""
+from . import _lib
+from .device import DeviceArray, as_device
+
+
+def get_sedimentation_flux(plan, mom, out=None, stream=None):
+    """mom (nmom, n) device, physical units -> flux (nmom, n) device, physical units."""
+    ptr, planes, n, ld = as_device(mom)
+    o = out if out is not None else DeviceArray(plan.nmom, n)
+    _lib.check(_lib.lib().cloudy_sedimentation_flux(plan.handle, n, ld, ptr, as_device(o)[0], stream))
+    return o
+
+
+def rainshaft_sources(plan, mom, coal_source=None, sedi_flux=None, stream=None):
+    ptr, planes, n, ld = as_device(mom)
+    cs = coal_source if coal_source is not None else DeviceArray(plan.nmom, n)
+    sf = sedi_flux if sedi_flux is not None else DeviceArray(plan.nmom, n)
+    _lib.check(_lib.lib().cloudy_rainshaft_sources(plan.handle, n, ld, ptr, as_device(cs)[0], as_device(sf)[0], stream))
+    return cs, sf

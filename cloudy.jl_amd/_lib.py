@@ -1,0 +1,102 @@
+"""ctypes binding of libcloudy_hip.so (include/cloudy_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing, or a batched call is made
+without a GPU, this module raises -- it never routes through oracle/ or numpy.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcloudy_hip.so")
+
+MAX_MODES, MAX_P, MAX_VEL = 4, 5, 4
+OK, EINVAL, ENOTSYMMETRIC, EHIP, ENOMEM, EUNSUPPORTED, ENODEVICE = 0, -1, -2, -3, -4, -5, -6
+
+
+class CloudyError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libcloudy_hip error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+class PlanDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("n_modes", C.c_int32),
+        ("dist_type", C.c_int32 * MAX_MODES),
+        ("tensor_p", C.c_int32),
+        ("kernel_layout", C.c_int32),
+        ("kernel_is_normalized", C.c_int32),
+        ("kernel_c", C.POINTER(C.c_double)),
+        ("dist_thresholds", C.c_double * MAX_MODES),
+        ("threshold_style", C.c_int32),
+        ("norms", C.c_double * 2),
+        ("k_range", C.c_double * 2),
+        ("n_bins_per_log_unit", C.c_int32),
+        ("dtype", C.c_int32),
+        ("n_vel", C.c_int32),
+        ("vel", C.c_double * (MAX_VEL * 2)),
+        ("device", C.c_int32),
+    ]
+
+
+# every symbol include/cloudy_hip.h declares: (restype, argtypes)
+_vp, _sz, _i, _dp = C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)
+SYMBOLS = {
+    "cloudy_plan_desc_init": (None, [C.POINTER(PlanDesc)]),
+    "cloudy_plan_create": (_i, [C.POINTER(PlanDesc), C.POINTER(_vp)]),
+    "cloudy_plan_destroy": (None, [_vp]),
+    "cloudy_plan_nmom": (_i, [_vp]),
+    "cloudy_plan_nparams": (_i, [_vp]),
+    "cloudy_plan_get": (_i, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _dp, _dp, _dp]),
+    "cloudy_coal_rhs": (_i, [_vp, _sz, _sz, _vp, _vp, _vp]),
+    "cloudy_coal_rhs_host": (_i, [_vp, _sz, _sz, _vp, _vp]),
+    "cloudy_get_coal_ints": (_i, [_vp, _sz, _sz, _vp, _vp, _vp]),
+    "cloudy_update_dist_from_moments": (_i, [_vp, _sz, _sz, _vp, _vp, _vp]),
+    "cloudy_finite_2d_integrals": (_i, [_vp, _sz, _sz, _vp, _vp, _vp]),
+    "cloudy_compute_thresholds": (_i, [_vp, _sz, _sz, _vp, _vp, _vp]),
+    "cloudy_sedimentation_flux": (_i, [_vp, _sz, _sz, _vp, _vp, _vp]),
+    "cloudy_rainshaft_sources": (_i, [_vp, _sz, _sz, _vp, _vp, _vp, _vp]),
+    "cloudy_moment_sums": (_i, [_vp, _sz, _sz, _i, _vp, _vp, _vp]),
+    "cloudy_device_count": (_i, []),
+    "cloudy_set_device": (_i, [_i]),
+    "cloudy_malloc": (_i, [C.POINTER(_vp), _sz]),
+    "cloudy_free": (_i, [_vp]),
+    "cloudy_memcpy_h2d": (_i, [_vp, _vp, _sz, _vp]),
+    "cloudy_memcpy_d2h": (_i, [_vp, _vp, _sz, _vp]),
+    "cloudy_memset": (_i, [_vp, _i, _sz, _vp]),
+    "cloudy_stream_synchronize": (_i, [_vp]),
+    "cloudy_time_coal_rhs": (_i, [_vp, _sz, _sz, _vp, _vp, _vp, _i, C.POINTER(C.c_float)]),
+    "cloudy_last_error": (C.c_char_p, []),
+    "cloudy_version": (_i, []),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if the HIP extension has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the coalescence RHS.")
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)  # AttributeError if the ABI lost a symbol
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != OK:
+        raise CloudyError(rc, lib().cloudy_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def device_count():
+    return lib().cloudy_device_count()

@@ -1,0 +1,63 @@
+"""The operator boundary: make_box_model_rhs (test/examples/utils/box_model_helpers.jl:22-53), batched.
+
+    rhs = make_box_model_rhs(AnalyticalCoalStyle())          # same factory signature
+    rhs(dm, m, par, t)                                        # same 4-argument in-place ODE function
+
+`m`, `dm` are (nmom, n_parcels) device arrays (DeviceArray or CUDA torch tensors), i.e. Julia's m[parcel, moment].
+`par` carries the fields rhs_coal! reads: pdists (types only), coal_data, NProgMoms, norms.
+"""
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import _lib
+from .device import as_device
+from .EquationTypes import AnalyticalCoalStyle, CoalescenceStyle, FixedThreshold, MovingThreshold, NumericalCoalStyle
+from .ParticleDistributions import nparams
+
+EPS = float(np.finfo(np.float64).eps)
+
+
+def ODEParameters(pdists, coal_data, NProgMoms, norms, **extra):
+    """The ODE_parameters NamedTuple of the examples (e.g. box_gamma_mixture.jl:29-35)."""
+    return SimpleNamespace(pdists=tuple(pdists), coal_data=coal_data, NProgMoms=tuple(NProgMoms), norms=tuple(norms),
+                           **extra)
+
+
+def _plan_for(par):
+    if tuple(nparams(d) for d in par.pdists) != tuple(par.NProgMoms):
+        raise ValueError("NProgMoms must equal nparams of p.pdists")
+    if tuple(par.norms) != tuple(par.coal_data.norms):
+        raise ValueError("p.norms differs from the norms the CoalescenceData was built with")
+    return par.coal_data.plan([d.type_id for d in par.pdists], k_range=getattr(par, "k_range", (EPS, 10.0)),
+                              vel=getattr(par, "vel", ()))
+
+
+def rhs_coal(coal_type, dmom, mom, p, threshold_style, stream=None):
+    """rhs_coal! (box_model_helpers.jl:29-53): normalise, invert closures, get_coal_ints, de-normalise --
+    one fused HIP kernel per call."""
+    if isinstance(coal_type, NumericalCoalStyle):
+        raise NotImplementedError("NumericalCoalStyle is not built for the GPU; see DESIGN.md")
+    if not isinstance(coal_type, AnalyticalCoalStyle):
+        raise ValueError("Invalid coal style!")
+    if isinstance(threshold_style, MovingThreshold) != isinstance(p.coal_data.ts, MovingThreshold):
+        raise ValueError("threshold style of the RHS does not match the CoalescenceData")
+    plan = _plan_for(p)
+    mptr, planes, n, ld = as_device(mom)
+    dptr, dplanes, dn, dld = as_device(dmom)
+    if planes != plan.nmom or dplanes != plan.nmom or dn != n or dld != ld:
+        raise ValueError(f"mom and dmom must both be ({plan.nmom}, n) with equal leading dimension")
+    _lib.check(_lib.lib().cloudy_coal_rhs(plan.handle, n, ld, mptr, dptr, stream))
+    return dmom
+
+
+def make_box_model_rhs(coal_type, threshold_style=None):
+    """make_box_model_rhs(coal_type::CoalescenceStyle, threshold_style::ThresholdStyle = FixedThreshold())."""
+    if not isinstance(coal_type, CoalescenceStyle):
+        raise TypeError("coal_type must be a CoalescenceStyle")
+    ts = threshold_style if threshold_style is not None else FixedThreshold()
+
+    def rhs(dm, m, par, t):
+        return rhs_coal(coal_type, dm, m, par, ts)
+
+    return rhs

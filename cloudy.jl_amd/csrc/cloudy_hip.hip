@@ -1,0 +1,463 @@
+// cloudy_hip.hip -- the C ABI of libcloudy_hip.so (include/cloudy_hip.h): plan construction on the host,
+// argument checking, and dispatch to the gfx950 kernels.  No CPU compute path exists here: every batched
+// entry point launches HIP kernels or fails with CLOUDY_ENODEVICE / CLOUDY_EHIP.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "host_plan.hpp"
+#include "kernels.hpp"
+#include "reduce_kernels.hpp"
+
+using namespace cloudy;
+
+struct cloudy_plan {
+    HostPlan h;
+};
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int fail_hip(hipError_t e, const char *what) {
+    return fail(e == hipErrorNoDevice || e == hipErrorInvalidDevice ? CLOUDY_ENODEVICE : CLOUDY_EHIP, "%s: %s", what,
+                hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) return fail_hip(_e, #expr); \
+    } while (0)
+
+constexpr int kSumBlocks = 1024;
+
+hipError_t dispatch(const HostPlan &h, const LaunchReq &r) {
+    switch (h.N) {
+    case 1: return launch_n1(h, r);
+    case 2: return launch_n2(h, r);
+    case 3: return launch_n3(h, r);
+    case 4: return launch_n4(h, r);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+int check_batch(const cloudy_plan *plan, size_t n, size_t ld, const void *a, const void *b) {
+    if (!plan) return fail(CLOUDY_EINVAL, "plan is NULL");
+    if (ld < n) return fail(CLOUDY_EINVAL, "ld (%zu) must be >= n_parcels (%zu)", ld, n);
+    if (n > 0 && (!a || !b)) return fail(CLOUDY_EINVAL, "device buffer is NULL");
+    return CLOUDY_OK;
+}
+
+int run(const cloudy_plan *plan, const LaunchReq &r) {
+    if (r.n == 0) return CLOUDY_OK;
+    hipError_t e = dispatch(plan->h, r);
+    if (e != hipSuccess) return fail_hip(e, "kernel launch");
+    return CLOUDY_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *cloudy_last_error(void) { return g_err; }
+int cloudy_version(void) { return CLOUDY_HIP_VERSION; }
+
+void cloudy_plan_desc_init(cloudy_plan_desc *d) {
+    if (!d) return;
+    std::memset(d, 0, sizeof(*d));
+    d->struct_size = (uint32_t)sizeof(*d);
+    d->norms[0] = d->norms[1] = 1.0;
+    d->k_range[0] = DBL_EPSILON;
+    d->k_range[1] = 10.0;  // ParticleDistributions.jl:459
+    d->n_bins_per_log_unit = 15;  // ParticleDistributions.jl:594
+    for (int i = 0; i < CLOUDY_MAX_MODES; ++i) d->dist_thresholds[i] = INFINITY;
+    d->dtype = CLOUDY_F64;
+    d->device = -1;
+}
+
+int cloudy_plan_create(const cloudy_plan_desc *d, cloudy_plan **out) {
+    if (!d || !out) return fail(CLOUDY_EINVAL, "desc/out is NULL");
+    *out = nullptr;
+    if (d->struct_size != sizeof(cloudy_plan_desc))
+        return fail(CLOUDY_EINVAL, "struct_size %u != %zu (call cloudy_plan_desc_init)", d->struct_size,
+                    sizeof(cloudy_plan_desc));
+    const int N = d->n_modes, P = d->tensor_p;
+    if (N < 1 || N > CLOUDY_MAX_MODES) return fail(CLOUDY_EUNSUPPORTED, "n_modes %d outside 1..%d", N, CLOUDY_MAX_MODES);
+    if (P < 1 || P > CLOUDY_MAX_P) return fail(CLOUDY_EUNSUPPORTED, "tensor_p %d outside 1..%d", P, CLOUDY_MAX_P);
+    if (!d->kernel_c) return fail(CLOUDY_EINVAL, "kernel_c is NULL");
+    if (d->dtype != CLOUDY_F64) return fail(CLOUDY_EUNSUPPORTED, "only CLOUDY_F64 plans are built in this revision");
+    if (!(d->norms[0] > 0) || !(d->norms[1] > 0))
+        return fail(CLOUDY_EINVAL, "norms must be positive!");  // helper_functions.jl:44-46
+    if (d->threshold_style != CLOUDY_FIXED_THRESHOLD && d->threshold_style != CLOUDY_MOVING_THRESHOLD)
+        return fail(CLOUDY_EINVAL, "bad threshold_style");
+    if (d->n_bins_per_log_unit < 1) return fail(CLOUDY_EINVAL, "n_bins_per_log_unit must be >= 1");
+    if (!(d->k_range[0] > 0) || !(d->k_range[1] >= d->k_range[0])) return fail(CLOUDY_EINVAL, "bad k_range");
+    if (d->n_vel < 0 || d->n_vel > CLOUDY_MAX_VEL) return fail(CLOUDY_EUNSUPPORTED, "n_vel outside 0..%d", CLOUDY_MAX_VEL);
+
+    cloudy_plan *p = new (std::nothrow) cloudy_plan();
+    if (!p) return fail(CLOUDY_ENOMEM, "out of host memory");
+    HostPlan &h = p->h;
+    h.N = N;
+    h.P = P;
+    h.dtype = d->dtype;
+    h.threshold_style = d->threshold_style;
+    h.nbpl = d->n_bins_per_log_unit;
+    h.kmin = d->k_range[0];
+    h.kmax = d->k_range[1];
+    h.norms[0] = d->norms[0];
+    h.norms[1] = d->norms[1];
+    int off = 0, np_max = 0;
+    for (int i = 0; i < N; ++i) {
+        if (d->dist_type[i] == CLOUDY_DIST_EXPONENTIAL)
+            h.np[i] = 2;
+        else if (d->dist_type[i] == CLOUDY_DIST_GAMMA)
+            h.np[i] = 3;
+        else {
+            delete p;
+            return fail(CLOUDY_EUNSUPPORTED, "dist_type[%d] = %d: only Exponential and Gamma closures are built", i,
+                        d->dist_type[i]);
+        }
+        h.dist_type[i] = d->dist_type[i];
+        h.off[i] = off;
+        off += h.np[i];
+        if (h.np[i] > np_max) np_max = h.np[i];
+        // get_moments_normalizing_factors, helper_functions.jl:40-53: norms[1] * norms[2]^(j-1)
+        h.mom_norm[i][0] = d->norms[0];
+        h.mom_norm[i][1] = d->norms[0] * d->norms[1];
+        h.mom_norm[i][2] = d->norms[0] * (d->norms[1] * d->norms[1]);
+    }
+    h.nmom = off;
+
+    // kernels: check_symmetry (KernelTensors.jl:157-171) + get_normalized_kernel_tensor (:189-199)
+    for (int j = 0; j < N; ++j)
+        for (int k = 0; k < N; ++k) {
+            const double *c =
+                d->kernel_layout == CLOUDY_KERNEL_MATRIX ? d->kernel_c + (size_t)(j * N + k) * P * P : d->kernel_c;
+            for (int a = 0; a < P; ++a)
+                for (int b = a + 1; b < P; ++b)
+                    if (c[a * P + b] != c[b * P + a]) {
+                        delete p;
+                        return fail(CLOUDY_ENOTSYMMETRIC, "array not symmetric.");
+                    }
+            for (int a = 0; a < P; ++a)
+                for (int b = 0; b < P; ++b)
+                    h.c[j][k][a][b] = d->kernel_is_normalized
+                                          ? c[a * P + b]
+                                          : c[a * P + b] * (d->norms[0] * std::pow(d->norms[1], (double)(a + b)));
+        }
+
+    // CoalescenceData fields, Coalescence.jl:69-84
+    h.n_mom_max = np_max + (P - 1);
+    for (int i = 0; i < N; ++i) {
+        const int nxt = (i < N - 1) ? (h.np[i] > h.np[i + 1] ? h.np[i] : h.np[i + 1]) : h.np[i];
+        h.n_2d[i] = (P - 1) + nxt;
+        h.thr[i] = d->threshold_style == CLOUDY_FIXED_THRESHOLD ? d->dist_thresholds[i] / d->norms[1]
+                                                                 : d->dist_thresholds[i];
+        if (std::isnan(h.thr[i])) {
+            delete p;
+            return fail(CLOUDY_EINVAL, "dist_thresholds[%d] is NaN", i);
+        }
+    }
+
+    // Simpson node tables for FixedThreshold (ParticleDistributions.jl:604-610): the grid depends only on
+    // the (normalised) threshold, so it is built once here, in fp64, exactly as the reference builds it.
+    std::vector<double> nodes;
+    bool any_finite = false;
+    if (d->threshold_style == CLOUDY_FIXED_THRESHOLD) {
+        for (int i = 0; i < N - 1; ++i) {
+            const double xt = h.thr[i];
+            if (std::isinf(xt) && xt > 0) continue;
+            if (!(xt > 0)) {
+                delete p;
+                return fail(CLOUDY_EINVAL, "dist_thresholds[%d] must be positive or +Inf", i);
+            }
+            const double x_lb = std::fmin(1e-5, 1e-5 * xt);
+            const int n_bins = (int)std::floor(h.nbpl * std::log10(xt / x_lb));
+            if (n_bins < 3) {
+                delete p;
+                return fail(CLOUDY_EINVAL, "n_bins must be at least 3");  // ParticleDistributions.jl:699
+            }
+            const double x_min = std::log(x_lb);
+            const double dx = (std::log(xt) - std::log(x_lb)) / n_bins;
+            h.finite[i] = 1;
+            h.node_off[i] = (int)(nodes.size() / kNodeStride);
+            h.n_bins[i] = n_bins;
+            any_finite = true;
+            for (int j = 1; j <= n_bins; ++j) {
+                const double lx = x_min + (j - 1) * dx;  // logx, :566
+                const double x = std::exp(lx);
+                nodes.push_back(x);
+                nodes.push_back(lx);
+                nodes.push_back(xt - x);
+                nodes.push_back(std::log(xt - x));
+                nodes.push_back(simpson_weight(j, n_bins) * dx);
+            }
+        }
+        h.mode = any_finite ? MODE_FIXED : MODE_ALLINF;
+    } else {
+        h.mode = (N > 1) ? MODE_MOVING : MODE_ALLINF;
+        for (int i = 0; i < N - 1; ++i)
+            if (!(h.thr[i] >= 0.0 && h.thr[i] <= 1.0)) {
+                delete p;
+                return fail(CLOUDY_EINVAL, "MovingThreshold percentile %d outside [0, 1]", i);
+            }
+    }
+
+    // sedimentation velocity, rescaled as the rainshaft caller does (rainshaft_helpers.jl:74-76)
+    h.n_vel = d->n_vel;
+    for (int v = 0; v < d->n_vel; ++v) {
+        h.vel[v][0] = d->vel[v][0];
+        h.vel[v][1] = d->vel[v][1];
+        h.vel_n[v][0] = d->vel[v][0] * std::pow(d->norms[1], d->vel[v][1]);
+        h.vel_n[v][1] = d->vel[v][1];
+    }
+
+    // device-side constants
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1) {
+        delete p;
+        return fail(CLOUDY_ENODEVICE, "no HIP device: %s", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    }
+    if (d->device >= 0) {
+        if (d->device >= ndev) {
+            delete p;
+            return fail(CLOUDY_EINVAL, "device %d out of range (%d devices)", d->device, ndev);
+        }
+        e = hipSetDevice(d->device);
+        if (e != hipSuccess) {
+            delete p;
+            return fail_hip(e, "hipSetDevice");
+        }
+        h.device = d->device;
+    } else {
+        (void)hipGetDevice(&h.device);
+    }
+    h.n_nodes = (int)(nodes.size() / kNodeStride);
+    if (h.n_nodes > 0) {
+        e = hipMalloc((void **)&h.nodes_dev, nodes.size() * sizeof(double));
+        if (e == hipSuccess)
+            e = hipMemcpy(h.nodes_dev, nodes.data(), nodes.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            cloudy_plan_destroy(p);
+            return fail_hip(e, "node table upload");
+        }
+    }
+    e = hipMalloc((void **)&h.partial_dev, sizeof(double) * kSumBlocks * (CLOUDY_MAX_MOMENTS + 64));
+    if (e != hipSuccess) {
+        cloudy_plan_destroy(p);
+        return fail_hip(e, "workspace allocation");
+    }
+    *out = p;
+    return CLOUDY_OK;
+}
+
+void cloudy_plan_destroy(cloudy_plan *plan) {
+    if (!plan) return;
+    if (plan->h.nodes_dev) (void)hipFree(plan->h.nodes_dev);
+    if (plan->h.partial_dev) (void)hipFree(plan->h.partial_dev);
+    delete plan;
+}
+
+int cloudy_plan_nmom(const cloudy_plan *plan) { return plan ? plan->h.nmom : fail(CLOUDY_EINVAL, "plan is NULL"); }
+int cloudy_plan_nparams(const cloudy_plan *plan) { return plan ? 3 * plan->h.N : fail(CLOUDY_EINVAL, "plan is NULL"); }
+
+int cloudy_plan_get(const cloudy_plan *plan, int32_t *N_mom_max, int32_t *N_2d_ints, double *thresholds,
+                    double *kernel_c_normalized, double *mom_norms) {
+    if (!plan) return fail(CLOUDY_EINVAL, "plan is NULL");
+    const HostPlan &h = plan->h;
+    if (N_mom_max) *N_mom_max = h.n_mom_max;
+    for (int i = 0; i < h.N; ++i) {
+        if (N_2d_ints) N_2d_ints[i] = h.n_2d[i];
+        if (thresholds) thresholds[i] = h.thr[i];
+    }
+    if (kernel_c_normalized)
+        for (int j = 0; j < h.N; ++j)
+            for (int k = 0; k < h.N; ++k)
+                for (int a = 0; a < h.P; ++a)
+                    for (int b = 0; b < h.P; ++b)
+                        kernel_c_normalized[((size_t)(j * h.N + k) * h.P + a) * h.P + b] = h.c[j][k][a][b];
+    if (mom_norms)
+        for (int i = 0; i < h.N; ++i)
+            for (int m = 0; m < h.np[i]; ++m) mom_norms[h.off[i] + m] = h.mom_norm[i][m];
+    return CLOUDY_OK;
+}
+
+int cloudy_coal_rhs(const cloudy_plan *plan, size_t n, size_t ld, const void *mom_dev, void *dmom_dev, void *stream) {
+    int rc = check_batch(plan, n, ld, mom_dev, dmom_dev);
+    if (rc) return rc;
+    LaunchReq r{OP_COAL, IN_MOMENTS, 1, 0, n, ld, (const double *)mom_dev, (double *)dmom_dev, nullptr,
+                (hipStream_t)stream};
+    return run(plan, r);
+}
+
+int cloudy_get_coal_ints(const cloudy_plan *plan, size_t n, size_t ld, const void *params_dev, void *out_dev,
+                         void *stream) {
+    int rc = check_batch(plan, n, ld, params_dev, out_dev);
+    if (rc) return rc;
+    LaunchReq r{OP_COAL, IN_PARAMS, 0, 0, n, ld, (const double *)params_dev, (double *)out_dev, nullptr,
+                (hipStream_t)stream};
+    return run(plan, r);
+}
+
+int cloudy_update_dist_from_moments(const cloudy_plan *plan, size_t n, size_t ld, const void *mom_dev,
+                                    void *params_dev, void *stream) {
+    int rc = check_batch(plan, n, ld, mom_dev, params_dev);
+    if (rc) return rc;
+    LaunchReq r{OP_UPDATE_DIST, IN_MOMENTS, 0, 0, n, ld, (const double *)mom_dev, (double *)params_dev, nullptr,
+                (hipStream_t)stream};
+    return run(plan, r);
+}
+
+int cloudy_finite_2d_integrals(const cloudy_plan *plan, size_t n, size_t ld, const void *params_dev, void *F_dev,
+                               void *stream) {
+    int rc = check_batch(plan, n, ld, params_dev, F_dev);
+    if (rc) return rc;
+    LaunchReq r{OP_FINITE_2D, IN_PARAMS, 0, 0, n, ld, (const double *)params_dev, (double *)F_dev, nullptr,
+                (hipStream_t)stream};
+    return run(plan, r);
+}
+
+int cloudy_compute_thresholds(const cloudy_plan *plan, size_t n, size_t ld, const void *params_dev,
+                              void *thresholds_dev, void *stream) {
+    int rc = check_batch(plan, n, ld, params_dev, thresholds_dev);
+    if (rc) return rc;
+    LaunchReq r{OP_FINITE_2D, IN_PARAMS, 0, 0, n, ld, (const double *)params_dev, nullptr, (double *)thresholds_dev,
+                (hipStream_t)stream};
+    return run(plan, r);
+}
+
+int cloudy_sedimentation_flux(const cloudy_plan *plan, size_t n, size_t ld, const void *mom_dev, void *flux_dev,
+                              void *stream) {
+    int rc = check_batch(plan, n, ld, mom_dev, flux_dev);
+    if (rc) return rc;
+    if (plan->h.n_vel < 1) return fail(CLOUDY_EINVAL, "plan has no terminal-velocity coefficients (n_vel = 0)");
+    LaunchReq r{OP_SEDI, IN_MOMENTS, 1, 0, n, ld, (const double *)mom_dev, (double *)flux_dev, nullptr,
+                (hipStream_t)stream};
+    return run(plan, r);
+}
+
+int cloudy_rainshaft_sources(const cloudy_plan *plan, size_t n, size_t ld, const void *mom_dev, void *coal_source_dev,
+                             void *sedi_flux_dev, void *stream) {
+    int rc = check_batch(plan, n, ld, mom_dev, coal_source_dev);
+    if (rc) return rc;
+    if (n > 0 && !sedi_flux_dev) return fail(CLOUDY_EINVAL, "device buffer is NULL");
+    if (plan->h.n_vel < 1) return fail(CLOUDY_EINVAL, "plan has no terminal-velocity coefficients (n_vel = 0)");
+    if (plan->h.threshold_style != CLOUDY_FIXED_THRESHOLD)
+        return fail(CLOUDY_EINVAL, "make_rainshaft_rhs uses FixedThreshold (rainshaft_helpers.jl:70)");
+    LaunchReq r1{OP_COAL, IN_MOMENTS, 1, 1, n, ld, (const double *)mom_dev, (double *)coal_source_dev, nullptr,
+                 (hipStream_t)stream};
+    rc = run(plan, r1);
+    if (rc) return rc;
+    LaunchReq r2{OP_SEDI, IN_MOMENTS, 1, 1, n, ld, (const double *)mom_dev, (double *)sedi_flux_dev, nullptr,
+                 (hipStream_t)stream};
+    return run(plan, r2);
+}
+
+int cloudy_moment_sums(const cloudy_plan *plan, size_t n, size_t ld, int planes, const void *arr_dev, double *sums_dev,
+                       void *stream) {
+    if (!plan) return fail(CLOUDY_EINVAL, "plan is NULL");
+    if (planes < 1 || planes > CLOUDY_MAX_MOMENTS + 64) return fail(CLOUDY_EINVAL, "planes out of range");
+    if (ld < n) return fail(CLOUDY_EINVAL, "ld must be >= n_parcels");
+    if (!sums_dev || (n > 0 && !arr_dev)) return fail(CLOUDY_EINVAL, "device buffer is NULL");
+    size_t blocks = (n + kBlock - 1) / kBlock;
+    if (blocks > (size_t)kSumBlocks) blocks = kSumBlocks;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(plane_partial_sums_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, n, ld,
+                       planes, (const double *)arr_dev, plan->h.partial_dev);
+    hipLaunchKernelGGL(plane_final_sums_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, (int)blocks, planes,
+                       (const double *)plan->h.partial_dev, sums_dev);
+    HIP_TRY(hipGetLastError());
+    return CLOUDY_OK;
+}
+
+int cloudy_coal_rhs_host(const cloudy_plan *plan, size_t n, size_t ld, const void *mom_host, void *dmom_host) {
+    int rc = check_batch(plan, n, ld, mom_host, dmom_host);
+    if (rc) return rc;
+    if (n == 0) return CLOUDY_OK;
+    const size_t bytes = (size_t)plan->h.nmom * ld * sizeof(double);
+    double *buf = nullptr;
+    HIP_TRY(hipMalloc((void **)&buf, 2 * bytes));
+    hipError_t e = hipMemcpy(buf, mom_host, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        rc = cloudy_coal_rhs(plan, n, ld, buf, (char *)buf + bytes, nullptr);
+        if (rc == CLOUDY_OK) e = hipMemcpy(dmom_host, (char *)buf + bytes, bytes, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(buf);
+    if (e != hipSuccess) return fail_hip(e, "host staging copy");
+    return rc;
+}
+
+int cloudy_time_coal_rhs(const cloudy_plan *plan, size_t n, size_t ld, const void *mom_dev, void *dmom_dev,
+                         void *stream, int iters, float *ms_per_launch) {
+    if (iters < 1 || !ms_per_launch) return fail(CLOUDY_EINVAL, "iters must be >= 1 and ms_per_launch non-NULL");
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    int rc = CLOUDY_OK;
+    hipError_t he = hipEventRecord(e0, (hipStream_t)stream);
+    for (int i = 0; i < iters && rc == CLOUDY_OK && he == hipSuccess; ++i)
+        rc = cloudy_coal_rhs(plan, n, ld, mom_dev, dmom_dev, stream);
+    if (he == hipSuccess) he = hipEventRecord(e1, (hipStream_t)stream);
+    if (he == hipSuccess) he = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != CLOUDY_OK) return rc;
+    if (he != hipSuccess) return fail_hip(he, "event timing");
+    *ms_per_launch = ms / (float)iters;
+    return CLOUDY_OK;
+}
+
+int cloudy_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int cloudy_set_device(int device) {
+    HIP_TRY(hipSetDevice(device));
+    return CLOUDY_OK;
+}
+int cloudy_malloc(void **dev_ptr, size_t bytes) {
+    if (!dev_ptr) return fail(CLOUDY_EINVAL, "dev_ptr is NULL");
+    HIP_TRY(hipMalloc(dev_ptr, bytes));
+    return CLOUDY_OK;
+}
+int cloudy_free(void *dev_ptr) {
+    HIP_TRY(hipFree(dev_ptr));
+    return CLOUDY_OK;
+}
+int cloudy_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return CLOUDY_OK;
+}
+int cloudy_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return CLOUDY_OK;
+}
+int cloudy_memset(void *dst, int value, size_t bytes, void *stream) {
+    HIP_TRY(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
+    return CLOUDY_OK;
+}
+int cloudy_stream_synchronize(void *stream) {
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return CLOUDY_OK;
+}
+
+}  // extern "C"

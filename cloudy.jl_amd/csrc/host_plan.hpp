@@ -1,0 +1,52 @@
+// host_plan.hpp -- host-side plan (the CoalescenceData + ODE_parameters of the reference, flattened)
+// and the launch request passed to the per-N instantiation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/cloudy_hip.h"
+
+namespace cloudy {
+
+struct HostPlan {
+    int N = 0, P = 0, nmom = 0;
+    int dist_type[CLOUDY_MAX_MODES] = {0}, np[CLOUDY_MAX_MODES] = {0}, off[CLOUDY_MAX_MODES] = {0};
+    int finite[CLOUDY_MAX_MODES] = {0}, node_off[CLOUDY_MAX_MODES] = {0}, n_bins[CLOUDY_MAX_MODES] = {0};
+    int n_2d[CLOUDY_MAX_MODES] = {0};
+    int n_mom_max = 0, threshold_style = 0, nbpl = 15, mode = 0, dtype = 0;
+    double thr[CLOUDY_MAX_MODES] = {0};                 // Coalescence.jl:78-84
+    double mom_norm[CLOUDY_MAX_MODES][3] = {{0}};       // helper_functions.jl:40-53, per (mode, order)
+    double norms[2] = {1, 1};
+    double kmin = 0, kmax = 10;
+    double c[CLOUDY_MAX_MODES][CLOUDY_MAX_MODES][CLOUDY_MAX_P][CLOUDY_MAX_P] = {{{{0}}}};
+    int n_vel = 0;
+    double vel[CLOUDY_MAX_VEL][2] = {{0}};              // physical
+    double vel_n[CLOUDY_MAX_VEL][2] = {{0}};            // rainshaft_helpers.jl:74-76
+    int device = 0;
+    double *nodes_dev = nullptr;                        // [n_nodes][kNodeStride]
+    int n_nodes = 0;
+    double *partial_dev = nullptr;                      // moment_sums workspace
+};
+
+enum Op { OP_COAL = 0, OP_UPDATE_DIST = 1, OP_FINITE_2D = 2, OP_SEDI = 3 };
+
+struct LaunchReq {
+    int op;
+    int input_kind;   // IN_MOMENTS / IN_PARAMS
+    int physical_out; // 1: multiply by mom_norms (rhs_coal!), 0: normalised units (get_coal_ints)
+    int rainshaft;    // clamp negatives + skip empty cells
+    size_t n, ld;
+    const double *in;
+    double *out;      // OP_COAL: dmom; OP_UPDATE_DIST: params; OP_FINITE_2D: F (may be null); OP_SEDI: flux
+    double *out2;     // OP_FINITE_2D: thresholds (may be null)
+    hipStream_t stream;
+};
+
+// one per instantiation unit (inst_n1.hip ... inst_n4.hip)
+hipError_t launch_n1(const HostPlan &h, const LaunchReq &r);
+hipError_t launch_n2(const HostPlan &h, const LaunchReq &r);
+hipError_t launch_n3(const HostPlan &h, const LaunchReq &r);
+hipError_t launch_n4(const HostPlan &h, const LaunchReq &r);
+
+}  // namespace cloudy

@@ -1,0 +1,5 @@
+// instantiation unit: every kernel of the N = 3 mode family (P = 1..5, all threshold modes)
+#include "launch_impl.hpp"
+namespace cloudy {
+hipError_t launch_n3(const HostPlan &h, const LaunchReq &r) { return launch_n<3>(h, r); }
+}  // namespace cloudy

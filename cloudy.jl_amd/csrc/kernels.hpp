@@ -1,0 +1,542 @@
+// kernels.hpp -- gfx950 kernels for the batched collision-coalescence moment tendency.
+//
+// One wavefront lane owns one parcel.  State is moment-major SoA (plane q at base + q*ld), so a
+// wave's load of one moment is one contiguous 512-byte request.  All parcel-independent constants
+// (normalised kernel tensors, norms, thresholds, Simpson nodes) are wave-uniform: they arrive as
+// kernel arguments / uniform-address loads and live in SGPRs, the CDNA home for broadcast data
+// (no LDS traffic, no per-lane registers).
+//
+// The per-parcel chain fused here (reference file:line, CliMA/Cloudy.jl v0.6.0):
+//   normalise            test/examples/utils/box_model_helpers.jl:30-31
+//   closure inversion    src/ParticleDistributions/ParticleDistributions.jl:456-476 (Gamma), :512-523 (Exp)
+//   moments matrix       src/Sources/Coalescence.jl:187-198   (integer orders via M_q = M_{q-1} theta (k+q-1))
+//   finite 2-D integrals src/Sources/Coalescence.jl:200-244, ParticleDistributions.jl:567-612, :698-710
+//   Q, R, S and assembly src/Sources/Coalescence.jl:115-185, :260-455
+//   de-normalise         test/examples/utils/box_model_helpers.jl:52
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_math.hpp"
+
+namespace cloudy {
+
+enum { IN_MOMENTS = 0, IN_PARAMS = 1 };
+enum { MODE_ALLINF = 0, MODE_FIXED = 1, MODE_MOVING = 2 };
+enum { DIST_EXP = 0, DIST_GAMMA = 1 };
+constexpr int kNodeStride = 5;  // x, ln x, x_t - x, ln(x_t - x), w * dx
+constexpr int kBlock = 256;
+
+template <int N, int P>
+struct KArgs {
+    int32_t dist_type[N], np[N], off[N];
+    int32_t finite[N];                 // FIXED: 1 if mode i < N-1 has a finite threshold
+    int32_t node_off[N], n_bins[N];    // FIXED: slice of the node table of mode i
+    int32_t n_2d[N];
+    int32_t n_mom_max, input_kind, rainshaft, nbpl;
+    double thr[N];                     // FIXED: threshold / m0; MOVING: percentile
+    double inv_norm[3 * N], out_scale[3 * N];
+    double kmin, kmax;
+    double c[N][N][P][P];              // normalised tensors, c[j][k][a][b]
+};
+
+template <int M>
+__host__ __device__ constexpr int tri(int p, int q) {  // packed upper triangle, p <= q < M
+    return p * M - (p * (p - 1)) / 2 + (q - p);
+}
+template <int M>
+__host__ __device__ constexpr int trisym(int p, int q) {
+    return p <= q ? tri<M>(p, q) : tri<M>(q, p);
+}
+
+// update_dist_from_moments, ParticleDistributions.jl:456-476 / :512-523 (normalised moments in)
+__device__ __forceinline__ void invert_closure(int dist_type, double m0, double m1, double m2, double kmin,
+                                               double kmax, double &n, double &th, double &k) {
+    if (m0 > kEps && m1 > kEps) {
+        n = m0;
+        const double mean = m1 / m0;
+        if (dist_type == DIST_GAMMA) {
+            double kk = mean / (m2 / m1 - mean);
+            // max(kmin, min(kmax, kk)) with Julia's NaN-propagating min/max
+            double inner = (kk < kmax || kk != kk) ? kk : kmax;
+            k = (inner > kmin || inner != inner) ? inner : kmin;
+            th = mean / k;
+        } else {
+            k = 1.0;
+            th = mean;
+        }
+    } else {
+        n = 0.0;
+        th = 1.0;
+        k = 1.0;
+    }
+}
+
+// get_moments_matrix row, Coalescence.jl:187-198: M_q = n theta^q Gamma(q+k)/Gamma(k), q = 0..M-1,
+// columns >= N_mom_max zero.
+template <int M>
+__device__ __forceinline__ void moment_row(double n, double th, double k, int n_mom_max, double (&Mk)[M]) {
+    Mk[0] = n;
+#pragma unroll
+    for (int q = 1; q < M; ++q) Mk[q] = Mk[q - 1] * (th * (k + double(q - 1)));
+#pragma unroll
+    for (int q = 0; q < M; ++q)
+        if (q >= n_mom_max) Mk[q] = 0.0;
+}
+
+// moment_source_helper on the plan's fixed log-uniform Simpson grid for all (p1 <= p2) at once.
+//   msh[p1][p2] = n M_p2 / Gamma(k) * sum_j (w_j dx) x_j^p1 t_j^k e^{-t_j} P(k + p2, z_j),
+//   t_j = x_j / theta, z_j = (x_t - x_j) / theta
+// which is ParticleDistributions.jl:589-612 (Gamma) / :567-587 (Exponential, k = 1) regrouped so that
+// one incomplete-gamma evaluation per node (at the top order) serves every p2 through the stable
+// downward recurrence P(a-1, z) = P(a, z) + z^(a-1) e^-z / Gamma(a).
+template <int P>
+__device__ __forceinline__ void msh_fixed_grid(const double *__restrict__ nd, int nb, double n, double th, double k,
+                                               bool is_gamma, const double (&Mk)[P + 2],
+                                               double (&msh)[(P + 2) * (P + 3) / 2]) {
+    constexpr int M = P + 2;
+    constexpr int T = M * (M + 1) / 2;
+    double acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = 0.0;
+    const double inv_th = 1.0 / th, lnth = log(th);
+    const double a_top = k + double(M - 1);
+    const double lg_top = lgamma(a_top + 1.0);
+#pragma unroll 1
+    for (int j = 0; j < nb; ++j) {
+        const double x = nd[kNodeStride * j + 0];
+        const double lx = nd[kNodeStride * j + 1];
+        const double xmx = nd[kNodeStride * j + 2];
+        const double lxmx = nd[kNodeStride * j + 3];
+        const double wdx = nd[kNodeStride * j + 4];
+        const double t = x * inv_th, z = xmx * inv_th;
+        const double h0 = wdx * exp(fma(k, lx - lnth, -t));
+        const double E0 = exp(fma(a_top, lxmx - lnth, -z) - lg_top);
+        double Pz[M];
+        Pz[M - 1] = inc_gamma_p_from_E(a_top, z, E0, nullptr);
+        const double invz = 1.0 / z;
+        double E = E0, a = a_top;
+#pragma unroll
+        for (int p2 = M - 2; p2 >= 0; --p2) {
+            E *= a * invz;
+            a -= 1.0;
+            Pz[p2] = Pz[p2 + 1] + E;
+        }
+        double h = h0;
+#pragma unroll
+        for (int p1 = 0; p1 < M; ++p1) {
+#pragma unroll
+            for (int p2 = p1; p2 < M; ++p2) acc[tri<M>(p1, p2)] = fma(h, Pz[p2], acc[tri<M>(p1, p2)]);
+            h *= x;
+        }
+    }
+    const double pref = is_gamma ? n / tgamma(k) : n;
+#pragma unroll
+    for (int p1 = 0; p1 < M; ++p1)
+#pragma unroll
+        for (int p2 = p1; p2 < M; ++p2) msh[tri<M>(p1, p2)] = pref * Mk[p2] * acc[tri<M>(p1, p2)];
+}
+
+// Simpson end weights of integrate_SimpsonEvenFast (ParticleDistributions.jl:698-710) as a weight per node
+__host__ __device__ inline double simpson_weight(int j /*1-based*/, int n_bins) {
+    const int e = n_bins + 1;
+    double w = (j >= 5 && j <= n_bins - 3) ? 1.0 : 0.0;
+    if (j == 1 || j == e) w += 17.0 / 48.0;
+    if (j == 2 || j == e - 1) w += 59.0 / 48.0;
+    if (j == 3 || j == e - 2) w += 43.0 / 48.0;
+    if (j == 4 || j == e - 3) w += 49.0 / 48.0;
+    return w;
+}
+
+// Same integral on a per-parcel grid (MovingThreshold: the threshold, hence the grid, depends on the parcel).
+template <int P>
+__device__ __forceinline__ void msh_moving_grid(double xt, int nbpl, double n, double th, double k, bool is_gamma,
+                                                const double (&Mk)[P + 2], double (&msh)[(P + 2) * (P + 3) / 2]) {
+    constexpr int M = P + 2;
+    constexpr int T = M * (M + 1) / 2;
+    double acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = 0.0;
+    // ParticleDistributions.jl:604-607
+    const double x_lb = fmin(1e-5, 1e-5 * xt);
+    const int nb = (int)floor(double(nbpl) * log10(xt / x_lb));
+    const double x_min = log(x_lb);
+    const double dx = (log(xt) - x_min) / double(nb);
+    const double inv_th = 1.0 / th, lnth = log(th);
+    const double a_top = k + double(M - 1);
+    const double lg_top = lgamma(a_top + 1.0);
+#pragma unroll 1
+    for (int j = 1; j <= nb; ++j) {
+        const double lx = x_min + double(j - 1) * dx;
+        const double x = exp(lx);
+        const double xmx = xt - x;
+        const double wdx = simpson_weight(j, nb) * dx;
+        const double t = x * inv_th, z = xmx * inv_th;
+        if (!(z > 0.0)) continue;  // P(a, z <= 0) = 0
+        const double h0 = wdx * exp(fma(k, lx - lnth, -t));
+        const double E0 = exp(fma(a_top, log(xmx) - lnth, -z) - lg_top);
+        double Pz[M];
+        Pz[M - 1] = inc_gamma_p_from_E(a_top, z, E0, nullptr);
+        const double invz = 1.0 / z;
+        double E = E0, a = a_top;
+#pragma unroll
+        for (int p2 = M - 2; p2 >= 0; --p2) {
+            E *= a * invz;
+            a -= 1.0;
+            Pz[p2] = Pz[p2 + 1] + E;
+        }
+        double h = h0;
+#pragma unroll
+        for (int p1 = 0; p1 < M; ++p1) {
+#pragma unroll
+            for (int p2 = p1; p2 < M; ++p2) acc[tri<M>(p1, p2)] = fma(h, Pz[p2], acc[tri<M>(p1, p2)]);
+            h *= x;
+        }
+    }
+    const double pref = is_gamma ? n / tgamma(k) : n;
+#pragma unroll
+    for (int p1 = 0; p1 < M; ++p1)
+#pragma unroll
+        for (int p2 = p1; p2 < M; ++p2) msh[tri<M>(p1, p2)] = pref * Mk[p2] * acc[tri<M>(p1, p2)];
+}
+
+// compute_threshold, ParticleDistributions.jl:747-761
+__device__ __forceinline__ double moving_threshold(bool is_gamma, double th, double k, double percentile) {
+    const double minx = 1e-18;
+    double v = is_gamma ? th * inc_gamma_inv(k, percentile, 1.0 - percentile) : -th * log(1.0 - percentile);
+    return fmax(v, minx);
+}
+
+// get_finite_2d_integrals entries of one mode (Coalescence.jl:213-227, upper triangle) and the
+// "promoted part" D[p][q] = M_p M_q - F[p][q], so that S_1k = 1/2 sum c C (MM - D), S_2k = 1/2 sum c C D.
+template <int P>
+__device__ __forceinline__ void finite_2d_and_promoted(const double (&Mk)[P + 2], bool thresholded,
+                                                       const double (&msh)[(P + 2) * (P + 3) / 2],
+                                                       double (&F)[(P + 2) * (P + 3) / 2],
+                                                       double (&D)[(P + 2) * (P + 3) / 2]) {
+    constexpr int M = P + 2;
+#pragma unroll
+    for (int p = 0; p < M; ++p)
+#pragma unroll
+        for (int q = p; q < M; ++q) {
+            const double mm = Mk[p] * Mk[q];
+            double f;
+            if (mm < kEps) {
+                f = 0.0;
+            } else if (!thresholded) {
+                f = mm;
+            } else {
+                const double h = msh[tri<M>(p, q)];
+                f = (h < mm || h != h) ? h : mm;  // Julia min(mm, h)
+            }
+            F[tri<M>(p, q)] = f;
+            D[tri<M>(p, q)] = mm - f;
+        }
+}
+
+// T_m = 1/2 sum_{a,b} c_ab sum_{c<=m} C(m,c) D[a+c][b+m-c]  (c, D symmetric)
+template <int P>
+__device__ __forceinline__ void contract_promoted(const double (&ckk)[P][P], const double (&D)[(P + 2) * (P + 3) / 2],
+                                                  double &T0, double &T1, double &T2) {
+    constexpr int M = P + 2;
+    T0 = 0.0;
+    T1 = 0.0;
+    T2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < P; ++a)
+#pragma unroll
+        for (int b = 0; b < P; ++b) {
+            const double c = ckk[a][b];
+            T0 = fma(c, D[trisym<M>(a, b)], T0);
+            T1 = fma(c, D[trisym<M>(a, b + 1)], T1);
+            T2 = fma(c, D[trisym<M>(a, b + 2)] + D[trisym<M>(a + 1, b + 1)], T2);
+        }
+    T0 *= 0.5;
+}
+
+// get_coal_ints for one parcel: acc[k][m], normalised units.
+template <int N, int P, int MODE>
+__device__ __forceinline__ void coal_ints_parcel(const KArgs<N, P> &A, const double *__restrict__ nodes,
+                                                 const double (&nn)[N], const double (&th)[N], const double (&kk)[N],
+                                                 double (&acc)[N][3]) {
+    constexpr int M = P + 2;
+    constexpr int T = M * (M + 1) / 2;
+    double Mm[N][M];
+#pragma unroll
+    for (int i = 0; i < N; ++i) moment_row<M>(nn[i], th[i], kk[i], A.n_mom_max, Mm[i]);
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.0;
+
+    // ---- promoted part of the self collisions: moves T_m from mode k to mode k+1 (lost for k = N-1)
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        bool thresholded = false;
+        double msh[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) msh[t] = 0.0;
+        if (MODE == MODE_FIXED) {
+            if (k < N - 1 && A.finite[k]) {  // wave-uniform
+                thresholded = true;
+                if (nn[k] > 0.0)
+                    msh_fixed_grid<P>(nodes + (size_t)A.node_off[k] * kNodeStride, A.n_bins[k], nn[k], th[k], kk[k],
+                                      A.dist_type[k] == DIST_GAMMA, Mm[k], msh);
+            }
+        } else if (MODE == MODE_MOVING) {
+            if (k < N - 1) {
+                const bool is_gamma = A.dist_type[k] == DIST_GAMMA;
+                const double xt = moving_threshold(is_gamma, th[k], kk[k], A.thr[k]);
+                thresholded = !(xt == INFINITY);
+                if (thresholded && nn[k] > 0.0) msh_moving_grid<P>(xt, A.nbpl, nn[k], th[k], kk[k], is_gamma, Mm[k], msh);
+            }
+        }
+        // without a threshold D is non-zero only where M_p M_q < eps: impossible when every moment >= 2^-26
+        double mn = Mm[k][0];
+#pragma unroll
+        for (int q = 1; q < M; ++q)
+            if (q < A.n_mom_max) mn = fmin(mn, Mm[k][q]);
+        const bool need = (nn[k] > 0.0) && (thresholded || mn < kSqrtEps);
+        if (need) {
+            double F[T], D[T];
+            finite_2d_and_promoted<P>(Mm[k], thresholded, msh, F, D);
+            double T0, T1, T2;
+            contract_promoted<P>(A.c[k][k], D, T0, T1, T2);
+            acc[k][0] -= T0;
+            acc[k][1] -= T1;
+            acc[k][2] -= T2;
+            if (k + 1 < N) {
+                acc[k + 1][0] += T0;
+                acc[k + 1][1] += T1;
+                acc[k + 1][2] += T2;
+            }
+        }
+    }
+    // ---- pair terms: Q - R for j < k, -R for j > k, S_1(full products) - R for j == k, with the
+    //      products common to Q and R (and to S_1 and R) cancelled analytically:
+    //      Q_0 = R_0;  Q_1 = R_1 + sum v1_b Mk_b;  Q_2 = R_2 + 2 sum v1_b Mk_{b+1} + sum v2_b Mk_b
+    //      with v_s[b] = sum_a c_ab Mj_{a+s}.
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if (j < k) {
+                double s1 = 0.0, s2a = 0.0, s2b = 0.0;
+#pragma unroll
+                for (int b = 0; b < P; ++b) {
+                    double v1 = 0.0, v2 = 0.0;
+#pragma unroll
+                    for (int a = 0; a < P; ++a) {
+                        v1 = fma(A.c[j][k][a][b], Mm[j][a + 1], v1);
+                        v2 = fma(A.c[j][k][a][b], Mm[j][a + 2], v2);
+                    }
+                    s1 = fma(v1, Mm[k][b], s1);
+                    s2a = fma(v1, Mm[k][b + 1], s2a);
+                    s2b = fma(v2, Mm[k][b], s2b);
+                }
+                acc[k][1] += s1;
+                acc[k][2] += fma(2.0, s2a, s2b);
+            } else if (j > k) {
+                double r0 = 0.0, r1 = 0.0, r2 = 0.0;
+#pragma unroll
+                for (int b = 0; b < P; ++b) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int a = 0; a < P; ++a) v = fma(A.c[j][k][a][b], Mm[j][a], v);
+                    r0 = fma(v, Mm[k][b], r0);
+                    r1 = fma(v, Mm[k][b + 1], r1);
+                    r2 = fma(v, Mm[k][b + 2], r2);
+                }
+                acc[k][0] -= r0;
+                acc[k][1] -= r1;
+                acc[k][2] -= r2;
+            } else {
+                double r0 = 0.0, s2 = 0.0;
+#pragma unroll
+                for (int b = 0; b < P; ++b) {
+                    double v = 0.0, v1 = 0.0;
+#pragma unroll
+                    for (int a = 0; a < P; ++a) {
+                        v = fma(A.c[k][k][a][b], Mm[k][a], v);
+                        v1 = fma(A.c[k][k][a][b], Mm[k][a + 1], v1);
+                    }
+                    r0 = fma(v, Mm[k][b], r0);
+                    s2 = fma(v1, Mm[k][b + 1], s2);
+                }
+                acc[k][0] -= 0.5 * r0;  // S_1 - R, order 0
+                acc[k][2] += s2;        // S_1 - R, order 2 (order 1 cancels: mass conservation)
+            }
+        }
+    }
+
+}
+
+// load one parcel (moments -> normalise -> invert, or parameters as given)
+template <int N, int P>
+__device__ __forceinline__ bool load_parcel(const KArgs<N, P> &A, size_t i, size_t ld, const double *__restrict__ in,
+                                            double (&nn)[N], double (&th)[N], double (&kk)[N]) {
+    bool all_small = true;
+    if (A.input_kind == IN_MOMENTS) {
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+            const int off = A.off[m];
+            double m0 = in[(size_t)(off + 0) * ld + i];
+            double m1 = in[(size_t)(off + 1) * ld + i];
+            double m2 = 0.0;
+            const bool three = A.np[m] == 3;
+            if (three) m2 = in[(size_t)(off + 2) * ld + i];
+            if (A.rainshaft) {  // rainshaft_helpers.jl:52
+                m0 = m0 < 0.0 ? 0.0 : m0;
+                m1 = m1 < 0.0 ? 0.0 : m1;
+                m2 = m2 < 0.0 ? 0.0 : m2;
+            }
+            m0 *= A.inv_norm[3 * m + 0];
+            m1 *= A.inv_norm[3 * m + 1];
+            m2 *= A.inv_norm[3 * m + 2];
+            all_small = all_small && (m0 < kEps) && (m1 < kEps) && (!three || m2 < kEps);
+            invert_closure(A.dist_type[m], m0, m1, m2, A.kmin, A.kmax, nn[m], th[m], kk[m]);
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+            nn[m] = in[(size_t)(3 * m + 0) * ld + i];
+            th[m] = in[(size_t)(3 * m + 1) * ld + i];
+            kk[m] = (A.dist_type[m] == DIST_GAMMA) ? in[(size_t)(3 * m + 2) * ld + i] : 1.0;
+        }
+        all_small = false;
+    }
+    return all_small;
+}
+
+template <int N, int P, int MODE>
+__global__ void __launch_bounds__(kBlock)
+    coal_rhs_kernel(const KArgs<N, P> A, const double *__restrict__ nodes, size_t n, size_t ld,
+                    const double *__restrict__ in, double *__restrict__ out) {
+    // one parcel per lane, no grid-stride loop: a parcel loop would let LICM hoist every libm polynomial
+    // constant of the body into registers for the whole kernel (measured: 256 VGPRs + spills vs ~100).
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) {
+        double nn[N], th[N], kk[N], acc[N][3];
+        const bool all_small = load_parcel<N, P>(A, i, ld, in, nn, th, kk);
+        coal_ints_parcel<N, P, MODE>(A, nodes, nn, th, kk, acc);
+        const bool skip = A.rainshaft && all_small;  // rainshaft_helpers.jl:67-68
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int off = A.off[k];
+            out[(size_t)(off + 0) * ld + i] = skip ? 0.0 : acc[k][0] * A.out_scale[3 * k + 0];
+            out[(size_t)(off + 1) * ld + i] = skip ? 0.0 : acc[k][1] * A.out_scale[3 * k + 1];
+            if (A.np[k] == 3) out[(size_t)(off + 2) * ld + i] = skip ? 0.0 : acc[k][2] * A.out_scale[3 * k + 2];
+        }
+    }
+}
+
+// ---- diagnostics / the callers either side of the operator ---------------------------------------
+
+template <int N, int P>
+__global__ void __launch_bounds__(kBlock)
+    update_dist_kernel(const KArgs<N, P> A, size_t n, size_t ld, const double *__restrict__ in,
+                       double *__restrict__ params) {
+    // one parcel per lane, no grid-stride loop: a parcel loop would let LICM hoist every libm polynomial
+    // constant of the body into registers for the whole kernel (measured: 256 VGPRs + spills vs ~100).
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) {
+        double nn[N], th[N], kk[N];
+        load_parcel<N, P>(A, i, ld, in, nn, th, kk);
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+            params[(size_t)(3 * m + 0) * ld + i] = nn[m];
+            params[(size_t)(3 * m + 1) * ld + i] = th[m];
+            params[(size_t)(3 * m + 2) * ld + i] = kk[m];
+        }
+    }
+}
+
+// get_finite_2d_integrals (Coalescence.jl:200-244) and the thresholds it used; F planes (i, p1, p2)
+template <int N, int P, int MODE>
+__global__ void __launch_bounds__(kBlock)
+    finite_2d_kernel(const KArgs<N, P> A, const double *__restrict__ nodes, size_t n, size_t ld,
+                     const double *__restrict__ in, double *__restrict__ F, double *__restrict__ thr_out) {
+    constexpr int M = P + 2;
+    constexpr int T = M * (M + 1) / 2;
+    // one parcel per lane, no grid-stride loop: a parcel loop would let LICM hoist every libm polynomial
+    // constant of the body into registers for the whole kernel (measured: 256 VGPRs + spills vs ~100).
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) {
+        double nn[N], th[N], kk[N];
+        load_parcel<N, P>(A, i, ld, in, nn, th, kk);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            double Mk[M];
+            moment_row<M>(nn[k], th[k], kk[k], A.n_mom_max, Mk);
+            bool thresholded = false;
+            double xt = INFINITY;
+            double msh[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) msh[t] = 0.0;
+            const bool is_gamma = A.dist_type[k] == DIST_GAMMA;
+            if (MODE == MODE_FIXED) {
+                if (k < N - 1 && A.finite[k]) {
+                    thresholded = true;
+                    xt = A.thr[k];
+                    if (nn[k] > 0.0)
+                        msh_fixed_grid<P>(nodes + (size_t)A.node_off[k] * kNodeStride, A.n_bins[k], nn[k], th[k],
+                                          kk[k], is_gamma, Mk, msh);
+                }
+            } else if (MODE == MODE_MOVING) {
+                if (k < N - 1) {
+                    xt = moving_threshold(is_gamma, th[k], kk[k], A.thr[k]);
+                    thresholded = !(xt == INFINITY);
+                    if (thresholded && nn[k] > 0.0) msh_moving_grid<P>(xt, A.nbpl, nn[k], th[k], kk[k], is_gamma, Mk, msh);
+                }
+            }
+            if (thr_out) thr_out[(size_t)k * ld + i] = xt;
+            if (F) {
+                double Fm[T], D[T];
+                finite_2d_and_promoted<P>(Mk, thresholded, msh, Fm, D);
+#pragma unroll
+                for (int p = 0; p < M; ++p)
+#pragma unroll
+                    for (int q = 0; q < M; ++q) {
+                        double v = Fm[trisym<M>(p, q)];
+                        if (p >= A.n_2d[k] || q >= A.n_2d[k]) v = 0.0;  // Coalescence.jl:213 N_2d_ints mask
+                        F[(size_t)((k * M + p) * M + q) * ld + i] = v;
+                    }
+            }
+        }
+    }
+}
+
+struct SediArgs {
+    int32_t n_vel, pad;
+    double vel[4][2];  // already rescaled by norms[1]^vel[k][1] (rainshaft_helpers.jl:74-76)
+};
+
+// get_sedimentation_flux, Sedimentation.jl:22-37: flux[i][j] = -sum_v vel_v0 * M^i_{j-1+vel_v1}
+// with the fractional-order moment n theta^q Gamma(q+k)/Gamma(k).
+template <int N, int P>
+__global__ void __launch_bounds__(kBlock)
+    sedi_flux_kernel(const KArgs<N, P> A, const SediArgs S, size_t n, size_t ld, const double *__restrict__ in,
+                     double *__restrict__ out) {
+    // one parcel per lane, no grid-stride loop: a parcel loop would let LICM hoist every libm polynomial
+    // constant of the body into registers for the whole kernel (measured: 256 VGPRs + spills vs ~100).
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) {
+        double nn[N], th[N], kk[N];
+        load_parcel<N, P>(A, i, ld, in, nn, th, kk);
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+            const int off = A.off[m];
+            const double lnth = log(th[m]);
+            const double lgk = lgamma(kk[m]);
+            for (int j = 0; j < A.np[m]; ++j) {
+                double s = 0.0;
+                for (int v = 0; v < S.n_vel; ++v) {
+                    const double q = double(j) + S.vel[v][1];
+                    const double mom = nn[m] * exp(fma(q, lnth, lgamma(q + kk[m]) - lgk));
+                    s -= S.vel[v][0] * mom;
+                }
+                out[(size_t)(off + j) * ld + i] = s * A.out_scale[3 * m + j];
+            }
+        }
+    }
+}
+
+}  // namespace cloudy

@@ -1,0 +1,108 @@
+// launch_impl.hpp -- fills KArgs<N,P> from the host plan and launches the kernel for one N (all P, all modes).
+// Included by inst_n{1,2,3,4}.hip so that the instantiations compile in parallel.
+#pragma once
+#include "host_plan.hpp"
+#include "kernels.hpp"
+
+namespace cloudy {
+
+inline unsigned grid_for(size_t n, bool /*heavy*/) {
+    size_t blocks = (n + kBlock - 1) / kBlock;  // one parcel per lane (see kernels.hpp)
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+template <int N, int P>
+void fill_args(const HostPlan &h, const LaunchReq &r, KArgs<N, P> &A) {
+    for (int i = 0; i < N; ++i) {
+        A.dist_type[i] = h.dist_type[i];
+        A.np[i] = h.np[i];
+        A.off[i] = h.off[i];
+        A.finite[i] = h.finite[i];
+        A.node_off[i] = h.node_off[i];
+        A.n_bins[i] = h.n_bins[i];
+        A.n_2d[i] = h.n_2d[i];
+        A.thr[i] = h.thr[i];
+        for (int m = 0; m < 3; ++m) {
+            A.inv_norm[3 * i + m] = 1.0 / h.mom_norm[i][m];
+            A.out_scale[3 * i + m] = r.physical_out ? h.mom_norm[i][m] : 1.0;
+        }
+    }
+    A.n_mom_max = h.n_mom_max;
+    A.input_kind = r.input_kind;
+    A.rainshaft = r.rainshaft;
+    A.nbpl = h.nbpl;
+    A.kmin = h.kmin;
+    A.kmax = h.kmax;
+    for (int j = 0; j < N; ++j)
+        for (int k = 0; k < N; ++k)
+            for (int a = 0; a < P; ++a)
+                for (int b = 0; b < P; ++b) A.c[j][k][a][b] = h.c[j][k][a][b];
+}
+
+template <int N, int P>
+hipError_t launch_np(const HostPlan &h, const LaunchReq &r) {
+    KArgs<N, P> A;
+    fill_args<N, P>(h, r, A);
+    const bool heavy = h.mode != MODE_ALLINF;
+    switch (r.op) {
+    case OP_COAL: {
+        const unsigned g = grid_for(r.n, heavy);
+        if (h.mode == MODE_ALLINF)
+            hipLaunchKernelGGL((coal_rhs_kernel<N, P, MODE_ALLINF>), dim3(g), dim3(kBlock), 0, r.stream, A, h.nodes_dev,
+                               r.n, r.ld, r.in, r.out);
+        else if (h.mode == MODE_FIXED)
+            hipLaunchKernelGGL((coal_rhs_kernel<N, P, MODE_FIXED>), dim3(g), dim3(kBlock), 0, r.stream, A, h.nodes_dev,
+                               r.n, r.ld, r.in, r.out);
+        else
+            hipLaunchKernelGGL((coal_rhs_kernel<N, P, MODE_MOVING>), dim3(g), dim3(kBlock), 0, r.stream, A, h.nodes_dev,
+                               r.n, r.ld, r.in, r.out);
+        break;
+    }
+    case OP_UPDATE_DIST:
+        hipLaunchKernelGGL((update_dist_kernel<N, P>), dim3(grid_for(r.n, false)), dim3(kBlock), 0, r.stream, A, r.n,
+                           r.ld, r.in, r.out);
+        break;
+    case OP_FINITE_2D: {
+        const unsigned g = grid_for(r.n, heavy);
+        if (h.mode == MODE_ALLINF)
+            hipLaunchKernelGGL((finite_2d_kernel<N, P, MODE_ALLINF>), dim3(g), dim3(kBlock), 0, r.stream, A,
+                               h.nodes_dev, r.n, r.ld, r.in, r.out, r.out2);
+        else if (h.mode == MODE_FIXED)
+            hipLaunchKernelGGL((finite_2d_kernel<N, P, MODE_FIXED>), dim3(g), dim3(kBlock), 0, r.stream, A,
+                               h.nodes_dev, r.n, r.ld, r.in, r.out, r.out2);
+        else
+            hipLaunchKernelGGL((finite_2d_kernel<N, P, MODE_MOVING>), dim3(g), dim3(kBlock), 0, r.stream, A,
+                               h.nodes_dev, r.n, r.ld, r.in, r.out, r.out2);
+        break;
+    }
+    case OP_SEDI: {
+        SediArgs S;
+        S.n_vel = h.n_vel;
+        S.pad = 0;
+        for (int v = 0; v < 4; ++v) {
+            S.vel[v][0] = v < h.n_vel ? h.vel_n[v][0] : 0.0;
+            S.vel[v][1] = v < h.n_vel ? h.vel_n[v][1] : 0.0;
+        }
+        hipLaunchKernelGGL((sedi_flux_kernel<N, P>), dim3(grid_for(r.n, false)), dim3(kBlock), 0, r.stream, A, S, r.n,
+                           r.ld, r.in, r.out);
+        break;
+    }
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+template <int N>
+hipError_t launch_n(const HostPlan &h, const LaunchReq &r) {
+    switch (h.P) {
+    case 1: return launch_np<N, 1>(h, r);
+    case 2: return launch_np<N, 2>(h, r);
+    case 3: return launch_np<N, 3>(h, r);
+    case 4: return launch_np<N, 4>(h, r);
+    case 5: return launch_np<N, 5>(h, r);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace cloudy

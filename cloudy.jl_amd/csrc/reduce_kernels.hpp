@@ -1,0 +1,51 @@
+// reduce_kernels.hpp -- plane sums for the moment / mass-conservation diagnostic
+// (test/examples/utils/plotting_helpers.jl:240-252).  Included by cloudy_hip.hip only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+
+namespace cloudy {
+
+// per-block partial sums of `planes` planes; second pass adds the partials (deterministic order)
+__global__ void __launch_bounds__(kBlock)
+    plane_partial_sums_kernel(size_t n, size_t ld, int planes, const double *__restrict__ arr,
+                              double *__restrict__ partial) {
+    __shared__ double red[kBlock / 64];
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (int q = 0; q < planes; ++q) {
+        double s = 0.0;
+        for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) s += arr[(size_t)q * ld + i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < kBlock / 64; ++w) t += red[w];
+            partial[(size_t)q * gridDim.x + blockIdx.x] = t;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+    plane_final_sums_kernel(int nblocks, int planes, const double *__restrict__ partial, double *__restrict__ sums) {
+    __shared__ double red[kBlock / 64];
+    for (int q = 0; q < planes; ++q) {
+        double s = 0.0;
+        for (int b = threadIdx.x; b < nblocks; b += kBlock) s += partial[(size_t)q * nblocks + b];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < kBlock / 64; ++w) t += red[w];
+            sums[q] = t;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace cloudy

@@ -1,0 +1,79 @@
+"""Device-resident moment arrays for hosts without a HIP array type (plain ctypes + numpy).
+
+Layout: shape (planes, n) row-major == moment-major SoA planes with ld = n, the layout of Julia's
+column-major m[parcel, moment] (reference test/examples/utils/rainshaft_helpers.jl:48-56).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class DeviceArray:
+    """A float64 (planes, n) buffer in HBM owned through cloudy_malloc/cloudy_free."""
+
+    def __init__(self, planes, n):
+        self.shape = (int(planes), int(n))
+        self.nbytes = 8 * self.shape[0] * self.shape[1]
+        p = C.c_void_p()
+        _lib.check(_lib.lib().cloudy_malloc(C.byref(p), max(self.nbytes, 8)))
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, a):
+        a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+        if a.ndim == 1:
+            a = a.reshape(-1, 1)
+        d = cls(*a.shape)
+        if d.nbytes:
+            _lib.check(_lib.lib().cloudy_memcpy_h2d(d.ptr, a.ctypes.data, d.nbytes, None))
+            _lib.check(_lib.lib().cloudy_stream_synchronize(None))
+        return d
+
+    @classmethod
+    def zeros(cls, planes, n):
+        d = cls(planes, n)
+        _lib.check(_lib.lib().cloudy_memset(d.ptr, 0, d.nbytes, None))
+        return d
+
+    def to_numpy(self):
+        out = np.empty(self.shape, dtype=np.float64)
+        if self.nbytes:
+            _lib.check(_lib.lib().cloudy_stream_synchronize(None))
+            _lib.check(_lib.lib().cloudy_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes, None))
+            _lib.check(_lib.lib().cloudy_stream_synchronize(None))
+        return out
+
+    def data_ptr(self):
+        return self.ptr
+
+    @property
+    def ld(self):
+        return self.shape[1]
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            _lib.lib().cloudy_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def as_device(x):
+    """(pointer, planes, n, ld) of a DeviceArray or of a CUDA/HIP torch tensor of shape (planes, n)."""
+    if isinstance(x, DeviceArray):
+        return x.ptr, x.shape[0], x.shape[1], x.shape[1]
+    if hasattr(x, "data_ptr") and hasattr(x, "is_cuda"):
+        if not x.is_cuda:
+            raise TypeError("torch tensor must live on the GPU (no CPU fallback)")
+        if x.dtype.itemsize != 8 or not x.dtype.is_floating_point:
+            raise TypeError("expected a float64 tensor")
+        if x.dim() != 2 or x.stride(1) != 1:
+            raise TypeError("expected a (planes, n) tensor with contiguous parcels")
+        return x.data_ptr(), x.shape[0], x.shape[1], x.stride(0) if x.shape[0] > 1 else x.shape[1]
+    raise TypeError(f"unsupported device array type {type(x)!r}")

@@ -1,0 +1,170 @@
+/*
+ * cloudy_hip.h -- C ABI of libcloudy_hip.so: the MI355X (gfx950) batched collision-coalescence
+ * moment-tendency operator for Cloudy.jl.
+ *
+ * Drop-in boundary.  Each entry point replaces one Julia-level interface of CliMA/Cloudy.jl v0.6.0
+ * (file:line relative to the reference checkout) for a batch of independent 0-D parcels; the
+ * Julia-side `ccall` binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ *   cloudy_plan_create            <- CoalescenceData(kernel, NProgMoms, dist_thresholds, norms, ts)
+ *                                    src/Sources/Coalescence.jl:55-104  (+ the ODE_parameters NamedTuple
+ *                                    test/examples/Analytical/box_gamma_mixture.jl:29-35)
+ *   cloudy_coal_rhs               <- rhs!(dm, m, par, t) = rhs_coal!(AnalyticalCoalStyle(), dm, m, par, ts)
+ *                                    test/examples/utils/box_model_helpers.jl:22-53
+ *   cloudy_get_coal_ints          <- get_coal_ints(::AnalyticalCoalStyle, pdists, coal_data[, ::MovingThreshold])
+ *                                    src/Sources/Coalescence.jl:115-185
+ *   cloudy_update_dist_from_moments <- update_dist_from_moments(pdist, moments)
+ *                                    src/ParticleDistributions/ParticleDistributions.jl:456-476, 512-523
+ *   cloudy_finite_2d_integrals    <- get_finite_2d_integrals / moment_source_helper
+ *                                    src/Sources/Coalescence.jl:200-244, ParticleDistributions.jl:567-612
+ *   cloudy_compute_thresholds     <- compute_thresholds(pdists, percentiles)
+ *                                    src/ParticleDistributions/ParticleDistributions.jl:734-761
+ *   cloudy_sedimentation_flux     <- get_sedimentation_flux(pdists, vel)   src/Sources/Sedimentation.jl:22-37
+ *   cloudy_rainshaft_sources      <- the per-cell body of make_rainshaft_rhs
+ *                                    test/examples/utils/rainshaft_helpers.jl:52-78
+ *   cloudy_moment_sums            <- moments_sum diagnostic, test/examples/utils/plotting_helpers.jl:240-252
+ *
+ * Data layout (all batched calls): moment-major structure-of-arrays, element (q, parcel) at
+ * base[q * ld + parcel], ld >= n_parcels -- exactly Julia's column-major m[parcel, moment]
+ * (test/examples/utils/rainshaft_helpers.jl:48-56).  Plane q is the flat moment index of
+ * get_dist_moment_ind (src/helper_functions.jl:13-20), 0-based.  Values are in physical units;
+ * normalisation by norms happens inside, as in rhs_coal!.
+ *
+ * Ownership: the caller owns every buffer; a plan owns only its constant block.  No call
+ * allocates.  All device entry points are asynchronous on `stream` (a hipStream_t passed as
+ * void*; NULL = the default stream).  Errors: int status, never a C++ exception; the message
+ * of the last failure on the calling thread is cloudy_last_error().
+ *
+ * Plain C: no HIP or torch types appear in any signature.
+ */
+#ifndef CLOUDY_HIP_H
+#define CLOUDY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLOUDY_HIP_VERSION 100 /* 0.1.0 */
+
+#define CLOUDY_MAX_MODES 4  /* N: number of sub-distributions */
+#define CLOUDY_MAX_P 5      /* P = tensor order + 1 (order <= 4, box_gamma_mixture_hydro.jl:23) */
+#define CLOUDY_MAX_VEL 4    /* terms of the terminal-velocity power series */
+#define CLOUDY_MAX_MOMENTS (3 * CLOUDY_MAX_MODES)
+
+/* distribution families, ParticleDistributions.jl:66-107 */
+enum { CLOUDY_DIST_EXPONENTIAL = 0, CLOUDY_DIST_GAMMA = 1 };
+/* EquationTypes.jl:20-22 */
+enum { CLOUDY_FIXED_THRESHOLD = 0, CLOUDY_MOVING_THRESHOLD = 1 };
+enum { CLOUDY_F64 = 0, CLOUDY_F32 = 1 };
+/* layout of cloudy_plan_desc.kernel_c */
+enum { CLOUDY_KERNEL_SINGLE = 0 /* [P][P] shared by all pairs, Coalescence.jl:89-104 */,
+       CLOUDY_KERNEL_MATRIX = 1 /* [N][N][P][P], Coalescence.jl:55-87 */ };
+
+enum {
+    CLOUDY_OK = 0,
+    CLOUDY_EINVAL = -1,       /* bad argument (the reference throws in a constructor) */
+    CLOUDY_ENOTSYMMETRIC = -2,/* check_symmetry failed, KernelTensors.jl:157-171 */
+    CLOUDY_EHIP = -3,         /* HIP runtime error (message has hipGetErrorString) */
+    CLOUDY_ENOMEM = -4,
+    CLOUDY_EUNSUPPORTED = -5, /* valid in the reference, outside this build */
+    CLOUDY_ENODEVICE = -6
+};
+
+typedef struct cloudy_plan cloudy_plan;
+
+typedef struct cloudy_plan_desc {
+    uint32_t struct_size;                    /* sizeof(cloudy_plan_desc); set by cloudy_plan_desc_init */
+    int32_t n_modes;                         /* N = length(pdists) */
+    int32_t dist_type[CLOUDY_MAX_MODES];     /* type of p.pdists[i]; NProgMoms[i] = nparams (2 / 3) */
+    int32_t tensor_p;                        /* P = order + 1 */
+    int32_t kernel_layout;                   /* CLOUDY_KERNEL_SINGLE / _MATRIX */
+    int32_t kernel_is_normalized;            /* 0: library applies get_normalized_kernel_tensor(c, norms) */
+    const double *kernel_c;                  /* c[a][b] multiplies x^a y^b (KernelTensors.jl:44-52); row-major */
+    double dist_thresholds[CLOUDY_MAX_MODES];/* FixedThreshold: mass in physical units (divided by norms[1] inside,
+                                                Coalescence.jl:78-84); MovingThreshold: percentiles. +INFINITY ok. */
+    int32_t threshold_style;
+    double norms[2];                         /* (n0, m0), helper_functions.jl:40-53 */
+    double k_range[2];                       /* param_range.k, ParticleDistributions.jl:459; default (eps, 10) */
+    int32_t n_bins_per_log_unit;             /* ParticleDistributions.jl:594; default 15 */
+    int32_t dtype;                           /* CLOUDY_F64 (CLOUDY_F32: see DESIGN.md) */
+    int32_t n_vel;                           /* 0 = no sedimentation term */
+    double vel[CLOUDY_MAX_VEL][2];           /* p.vel: terminal velocity sum_k vel[k][0] * x^vel[k][1], physical units */
+    int32_t device;                          /* HIP device ordinal, -1 = current */
+} cloudy_plan_desc;
+
+/* fills defaults: k_range = (eps, 10), n_bins_per_log_unit = 15, norms = (1, 1), thresholds = +Inf,
+ * dtype = F64, device = -1 */
+void cloudy_plan_desc_init(cloudy_plan_desc *desc);
+
+int cloudy_plan_create(const cloudy_plan_desc *desc, cloudy_plan **out);
+void cloudy_plan_destroy(cloudy_plan *plan);
+int cloudy_plan_nmom(const cloudy_plan *plan);      /* sum(NProgMoms) */
+int cloudy_plan_nparams(const cloudy_plan *plan);   /* 3 * N planes of (n, theta, k) */
+/* copies of the derived CoalescenceData fields (Coalescence.jl:69-84), for tests and hosts */
+int cloudy_plan_get(const cloudy_plan *plan, int32_t *N_mom_max, int32_t *N_2d_ints /*[N]*/,
+                    double *thresholds /*[N]*/, double *kernel_c_normalized /*[N][N][P][P]*/,
+                    double *mom_norms /*[nmom]*/);
+
+/* dmom = d(mom)/dt by collision-coalescence; mom, dmom: nmom planes, physical units. */
+int cloudy_coal_rhs(const cloudy_plan *plan, size_t n_parcels, size_t ld, const void *mom_dev, void *dmom_dev,
+                    void *stream);
+/* same through host buffers (allocates a staging buffer, copies, synchronises): convenience only */
+int cloudy_coal_rhs_host(const cloudy_plan *plan, size_t n_parcels, size_t ld, const void *mom_host,
+                         void *dmom_host);
+
+/* inner operator on given distributions: params = 3N planes (n, theta, k) per mode, normalised units
+ * (k plane ignored for exponential modes); out = nmom planes, normalised units. */
+int cloudy_get_coal_ints(const cloudy_plan *plan, size_t n_parcels, size_t ld, const void *params_dev,
+                         void *coal_ints_dev, void *stream);
+
+/* closure inversion: mom (physical) -> params planes (n, theta, k), normalised units */
+int cloudy_update_dist_from_moments(const cloudy_plan *plan, size_t n_parcels, size_t ld, const void *mom_dev,
+                                    void *params_dev, void *stream);
+
+/* F[i][p1][p2] of get_finite_2d_integrals: N*M*M planes (M = P+2), row-major (i, p1, p2) */
+int cloudy_finite_2d_integrals(const cloudy_plan *plan, size_t n_parcels, size_t ld, const void *params_dev,
+                               void *F_dev, void *stream);
+
+/* per-parcel thresholds actually used by the S terms: N planes (last = +Inf) */
+int cloudy_compute_thresholds(const cloudy_plan *plan, size_t n_parcels, size_t ld, const void *params_dev,
+                              void *thresholds_dev, void *stream);
+
+/* sedimentation flux of every prognostic moment, physical units (plan must have n_vel > 0) */
+int cloudy_sedimentation_flux(const cloudy_plan *plan, size_t n_parcels, size_t ld, const void *mom_dev,
+                              void *flux_dev, void *stream);
+
+/* coalescence source and sedimentation flux of each cell in one fused pass
+ * (negative moments clamped to zero, empty cells skipped) */
+int cloudy_rainshaft_sources(const cloudy_plan *plan, size_t n_cells, size_t ld, const void *mom_dev,
+                             void *coal_source_dev, void *sedi_flux_dev, void *stream);
+
+/* sums_dev[q] = sum over parcels of plane q (fp64 accumulate); `planes` planes are reduced.
+ * The multi-GPU conservation check all-reduces these nmom doubles (RCCL), see INTEGRATION.md. */
+int cloudy_moment_sums(const cloudy_plan *plan, size_t n_parcels, size_t ld, int planes, const void *arr_dev,
+                       double *sums_dev, void *stream);
+
+/* thin device-memory helpers so that a host without a HIP binding can keep state device-resident */
+int cloudy_device_count(void);
+int cloudy_set_device(int device);
+int cloudy_malloc(void **dev_ptr, size_t bytes);
+int cloudy_free(void *dev_ptr);
+int cloudy_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream);
+int cloudy_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, void *stream);
+int cloudy_memset(void *dst_dev, int value, size_t bytes, void *stream);
+int cloudy_stream_synchronize(void *stream);
+
+/* launch-timing helper used by bench.py: runs `iters` back-to-back cloudy_coal_rhs launches on `stream`
+ * bracketed by HIP events recorded on that stream; returns the average milliseconds per launch. */
+int cloudy_time_coal_rhs(const cloudy_plan *plan, size_t n_parcels, size_t ld, const void *mom_dev,
+                         void *dmom_dev, void *stream, int iters, float *ms_per_launch);
+
+const char *cloudy_last_error(void);
+int cloudy_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLOUDY_HIP_H */

@@ -1,0 +1,430 @@
+"""GPU parity tests: the HIP path (through the C ABI of libcloudy_hip.so) against the CPU oracle, the reference's
+known-answer values, and closed forms.  Tolerances (stated here, from BASELINE.json north_star):
+
+  * all-Inf polynomial path (constant / Golovin / Long pieces):  |hip - oracle| <= 1e-12 * scale, and rel 1e-12
+    against the closed forms;  rel 1e-10 vs the oracle on the Golovin analytic case
+  * Simpson / incomplete-gamma path (finite or moving thresholds): |hip - oracle| <= 1e-8 * scale
+
+`scale` is the sum of |Q|, |R|, |S| terms of an output as reported by the oracle: a tendency is a small difference
+of large terms (e.g. the net mass tendency of a mode), so rounding is measured against the terms."""
+import math
+
+import numpy as np
+import pytest
+
+import bench
+
+pytestmark = pytest.mark.gpu
+
+EPS = float(np.finfo(np.float64).eps)
+INF = float("inf")
+TOL_POLY = 1e-12
+TOL_QUAD = 1e-8
+TYPES = {"exponential": 0, "gamma": 1}
+
+
+def dev(cloudy, a):
+    return cloudy.DeviceArray.from_numpy(a)
+
+
+def run_rhs(cloudy, par, mom, ts=None):
+    rhs = cloudy.make_box_model_rhs(cloudy.AnalyticalCoalStyle(), ts)
+    m = dev(cloudy, mom)
+    dm = cloudy.DeviceArray.zeros(*mom.shape)
+    rhs(dm, m, par, 0.0)
+    return dm.to_numpy()
+
+
+def make_case(cloudy, oracle, dist_types, kc, thr, norms, moving=False, k_range=(EPS, 10.0), vel=()):
+    """product-side ODE parameters + oracle params for the same configuration"""
+    N = len(dist_types)
+    kc = np.asarray(kc, dtype=np.float64)
+    if kc.ndim == 2:
+        kc = np.broadcast_to(kc, (N, N) + kc.shape).copy()
+    kernels = tuple(tuple(cloudy.CoalescenceTensor(kc[j, k]) for k in range(N)) for j in range(N))
+    npm = tuple(3 if t == 1 else 2 for t in dist_types)
+    ts = cloudy.MovingThreshold() if moving else cloudy.FixedThreshold()
+    cd = cloudy.CoalescenceData(kernels, npm, thr, norms, ts)
+    pd = tuple(cloudy.GammaPrimitiveParticleDistribution(1.0, 1.0, 1.0) if t == 1 else
+               cloudy.ExponentialPrimitiveParticleDistribution(1.0, 1.0) for t in dist_types)
+    extra = {"vel": vel} if len(vel) else {}
+    par = cloudy.ODEParameters(pd, cd, npm, norms, k_range=k_range, **extra)
+    op = oracle.make_params(list(dist_types), kc, thr, norms=norms, threshold_style=1 if moving else 0,
+                            k_range=k_range, vel=vel)
+    return par, op, ts
+
+
+def assert_close_scaled(got, want, scale, tol, what=""):
+    assert got.shape == want.shape
+    nan_g, nan_w = np.isnan(got), np.isnan(want)
+    assert np.array_equal(nan_g, nan_w), f"{what}: NaN pattern differs"
+    ok = ~nan_w
+    err = np.abs(got[ok] - want[ok])
+    bound = tol * scale[ok]
+    bad = err > bound
+    worst = (err / np.maximum(scale[ok], 1e-300)).max() if err.size else 0.0
+    assert not bad.any(), f"{what}: max |diff|/scale = {worst:.3e} > {tol:g} ({bad.sum()} of {err.size})"
+    return worst
+
+
+def mixed_moments(dist_types, n, seed):
+    """physical moments for a mixed Exp/Gamma mode list, (nmom, n)"""
+    full = bench.synth_moments(len(dist_types), n, seed)
+    rows = []
+    for i, t in enumerate(dist_types):
+        rows += [full[3 * i], full[3 * i + 1]] + ([full[3 * i + 2]] if t == 1 else [])
+    return np.ascontiguousarray(np.stack(rows))
+
+
+# ----------------------------------------------------------------------------------------------------
+def test_closed_forms_constant_and_golovin(gpu_cloudy, oracle):
+    """SURVEY App. A.14, single Gamma mode, thresholds Inf, physical units with norms (1e6, 1e-9):
+    constant c=[[A]]: dM0 = -A/2 M0^2, dM1 = 0, dM2 = A M1^2;  Golovin: dM0 = -b M0 M1, dM1 = 0, dM2 = 2b M1 M2."""
+    cloudy = gpu_cloudy
+    n = 100_000
+    mom = bench.synth_moments(1, n, seed=5, degenerate_frac=0.0)
+    M0, M1, M2 = mom
+    A = 1e-9
+    par, op, _ = make_case(cloudy, oracle, [1], [[A]], (INF,), bench.NORMS)
+    d = run_rhs(cloudy, par, mom)
+    assert np.allclose(d[0], -A / 2 * M0 * M0, rtol=TOL_POLY, atol=0)
+    assert np.allclose(d[2], A * M1 * M1, rtol=TOL_POLY, atol=0)
+    assert np.all(np.abs(d[1]) <= 1e-15 * A * M0 * M1)
+    b = 5.0
+    par, op, _ = make_case(cloudy, oracle, [1], [[0.0, b], [b, 0.0]], (INF,), bench.NORMS)
+    d = run_rhs(cloudy, par, mom)
+    assert np.allclose(d[0], -b * M0 * M1, rtol=TOL_POLY, atol=0)
+    assert np.allclose(d[2], 2 * b * M1 * M2, rtol=TOL_POLY, atol=0)
+    assert np.all(np.abs(d[1]) <= 1e-15 * b * M1 * M1)
+    # the same Golovin case against the oracle: rel 1e-10 (north_star) -- and in fact 1e-12 of scale
+    want, scale = oracle.rhs_coal_batch(op, mom, with_scale=True)
+    assert np.allclose(d[[0, 2]], want[[0, 2]], rtol=1e-10, atol=0)
+    assert_close_scaled(d, want, scale, TOL_POLY, "golovin")
+
+
+@pytest.mark.parametrize("name,n,tol", [("cfg2", 200_000, TOL_POLY), ("cfg3a", 200_000, TOL_POLY),
+                                        ("cfg3b", 20_000, TOL_QUAD)])
+def test_bench_workloads_vs_oracle(gpu_cloudy, oracle, name, n, tol):
+    """The bench's synthetic Gamma-mixture batches (incl. ~1 % degenerate parcels) at oracle-sized n."""
+    cloudy = gpu_cloudy
+    wl = bench.make_workload(name, n, seed=99)
+    d = run_rhs(cloudy, wl["par"], wl["mom"])
+    want, scale = oracle.rhs_coal_batch(bench.oracle_params(name), wl["mom"], with_scale=True)
+    worst = assert_close_scaled(d, want, scale, tol, name)
+    print(f"{name}: max |hip-oracle|/scale = {worst:.2e}")
+    # mass conservation across modes, parcel by parcel
+    nm = wl["mom"].shape[0] // 3
+    net = sum(d[3 * i + 1] for i in range(nm))
+    gross = sum(scale[3 * i + 1] for i in range(nm))
+    assert np.all(np.abs(net) <= 1e-12 * gross)
+
+
+def test_gamma_exp_reference_kat(gpu_cloudy, oracle, kats):
+    """test_Sources_correctness.jl:87-169 through cloudy_get_coal_ints: Gamma(100, 0.1, 1) + Exp(1, 1), linear
+    kernel order 1, thresholds (0.5, Inf), NProgMoms (3, 2), norms (1, 1)."""
+    cloudy = gpu_cloudy
+    e = kats["gamma_exp_coal_ints"]
+    kc = np.array(e["kernel_c"])
+    cd = cloudy.CoalescenceData(cloudy.CoalescenceTensor(kc), (3, 2), (0.5, INF))
+    params = cloudy.pack_params([(np.full(64, 100.0), np.full(64, 0.1), np.full(64, 1.0)),
+                                 (np.full(64, 1.0), np.full(64, 1.0))])
+    out = cloudy.get_coal_ints(cloudy.AnalyticalCoalStyle(), ([1, 0], dev(cloudy, params)), cd).to_numpy()
+    assert np.all(out == out[:, :1])  # every lane identical
+    got = out[:, 0]
+    pd = [oracle.make_dist(1, 100.0, 0.1, 1.0), oracle.make_dist(0, 1.0, 1.0)]
+    want, scale = oracle.get_coal_ints(pd, oracle.coalescence_data(kc, (3, 2), (0.5, INF)), with_scale=True)
+    assert np.all(np.abs(got - want) <= TOL_QUAD * scale)
+    assert np.all(np.abs(got - np.array(e["restated"])) <= TOL_QUAD * scale)
+    assert abs(got[1] + got[4]) <= 1e-13 * scale[1]  # mass moves from mode 1 to mode 2, nothing is lost
+    print("gamma+exp KAT max |diff|/scale:", np.max(np.abs(got - want) / scale))
+
+
+def test_sm1916_constant_kernel_euler_steps(gpu_cloudy, kats):
+    """test_Sources_correctness.jl:41-85: 5 explicit Euler steps, constant kernel, one Exponential mode, against the
+    Smoluchowski (1916) solution 1/(1/a + b t/2); the RHS runs on the GPU, the Euler update on the host."""
+    cloudy = gpu_cloudy
+    e = kats["sm1916"]
+    cd = cloudy.CoalescenceData(cloudy.CoalescenceTensor(e["kernel_c"]), (2,), (INF,))
+    par = cloudy.ODEParameters((cloudy.ExponentialPrimitiveParticleDistribution(1.0, 1.0),), cd, (2,), (1.0, 1.0))
+    mom = np.tile(np.array(e["init_moments"])[:, None], (1, 3))
+    for _ in range(e["n_steps"]):
+        mom = mom + e["dt"] * run_rhs(cloudy, par, mom)
+    t = e["dt"] * e["n_steps"]
+    assert np.allclose(mom[0], 1.0 / (1.0 / e["a"] + e["b"] / 2 * t), rtol=1e-7)
+    assert np.all(mom[1] == 2.0)
+    for i in range(e["n_steps"] + 1):  # the reference's (loose) comparison loop
+        assert np.allclose(mom[0], 1.0 / (1.0 / e["a"] + e["b"] / 2 * e["dt"] * i), rtol=e["rtol"])
+
+
+def test_update_dist_from_moments_kats_and_fallbacks(gpu_cloudy, oracle, kats):
+    cloudy = gpu_cloudy
+    cd = cloudy.CoalescenceData(cloudy.CoalescenceTensor([[1.0]]), (3, 2), (INF, INF))
+    plan = cd.plan([1, 0])
+    cols = [
+        [10.0, 50.0, 300.0, 10.0, 50.0],      # :141-143 -> (10, 1, 5) ; :89-91 -> (10, 5)
+        [1.1, 2.423, 8.112, 1.1, 2.0],        # :137-140 ; :84-87
+        [1.1, 0.0, 8.112, 1.1, 0.0],          # degenerate -> (0, 1, 1) ; (0, 1)
+        [EPS, 1.0, 1.0, 1.0, EPS],            # M0 <= eps / M1 <= eps
+        [1.0, 1.0, 1.0, 2.0, 3.0],            # zero variance -> k = 10
+        [1.0, 1.0, 0.5, 2.0, 3.0],            # negative variance -> k = eps
+    ]
+    mom = np.ascontiguousarray(np.array(cols).T)
+    got = cloudy.update_dist_from_moments(plan, dev(cloudy, mom)).to_numpy()
+    assert tuple(got[:3, 0]) == (10.0, 1.0, 5.0) and tuple(got[3:5, 0]) == (10.0, 5.0)
+    assert tuple(got[:3, 2]) == (0.0, 1.0, 1.0) and tuple(got[3:5, 2]) == (0.0, 1.0)
+    assert tuple(got[:3, 3]) == (0.0, 1.0, 1.0) and tuple(got[3:5, 3]) == (0.0, 1.0)
+    assert got[2, 4] == 10.0 and got[1, 4] == 0.1
+    assert got[2, 5] == EPS
+    for j in range(mom.shape[1]):
+        g = oracle.update_dist_from_moments(1, mom[:3, j])
+        x = oracle.update_dist_from_moments(0, mom[3:, j])
+        assert np.allclose(got[:, j], [g.n, g.theta, g.k, x.n, x.theta, 1.0], rtol=4 * EPS, atol=0)
+    # k_range override of the reference test (:127-136): (1.1, 2.0, 4.1) with k <= 5 -> M2 ~ 4.364
+    plan5 = cd.plan([1, 0], k_range=(EPS, 5.0))
+    g = cloudy.update_dist_from_moments(plan5, dev(cloudy, np.array([[1.1], [2.0], [4.1], [1.0], [1.0]]))).to_numpy()[:3, 0]
+    assert g[2] == 5.0
+    assert g[0] * g[1] ** 2 * g[2] * (g[2] + 1) == pytest.approx(4.364, rel=1e-3)
+    # wrong arity throws (:92, :144)
+    with pytest.raises(TypeError):
+        cloudy.update_dist_from_moments(plan, dev(cloudy, np.ones((6, 4))))
+
+
+def test_finite_2d_integrals_and_moment_source_helper_kats(gpu_cloudy, oracle, kats):
+    """moment_source_helper KATs (test_ParticleDistributions_correctness.jl:207-213, 20 bins per log unit) read off
+    the F matrices of get_finite_2d_integrals, and F against the oracle for random parcels."""
+    cloudy = gpu_cloudy
+    for spec, t in ((["exponential", 1.0, 0.5], 0), (["gamma", 1.0, 0.5, 2.0], 1)):
+        cd = cloudy.CoalescenceData(cloudy.CoalescenceTensor([[0.0, 1.0], [1.0, 0.0]]), (3 if t else 2, 3), (0.5, INF))
+        plan = cloudy.Plan([t, 1], cd.kernel_c, (0.5, INF), (1.0, 1.0), 0, n_bins_per_log_unit=20)
+        k = spec[3] if t else 1.0
+        params = cloudy.pack_params([(np.full(8, spec[1]), np.full(8, spec[2]), np.full(8, k)),
+                                     (np.full(8, 1.0), np.full(8, 1.0), np.full(8, 1.0))])
+        F = cloudy.get_finite_2d_integrals(plan, dev(cloudy, params)).to_numpy()[:, 0].reshape(2, 4, 4)
+        for e in kats["moment_source_helper"]:
+            if e["dist"] == spec:
+                p1, p2 = int(e["p1"]), int(e["p2"])
+                lo, hi = min(p1, p2), max(p1, p2)
+                assert F[0, lo, hi] == pytest.approx(e["expected"], rel=e["rtol"]), e["cite"]
+                assert F[0, lo, hi] == pytest.approx(e["restated"], rel=1e-10), e["cite"]
+                assert F[0, hi, lo] == F[0, lo, hi]
+    # random parcels, default 15 bins, 3 modes with two finite thresholds, P = 3, vs the oracle
+    rng = np.random.default_rng(4)
+    n = 512
+    N, P, M = 3, 3, 5
+    kc = rng.uniform(0, 1, (P, P))
+    kc = kc + kc.T
+    dt = [1, 0, 1]
+    cd = cloudy.CoalescenceData(cloudy.CoalescenceTensor(kc), (3, 2, 3), (0.5, 7.0, INF))
+    plan = cd.plan(dt)
+    nn = 10 ** rng.uniform(-3, 3, (3, n))
+    th = 10 ** rng.uniform(-2, 1.5, (3, n))
+    kk = rng.uniform(0.3, 9, (3, n))
+    kk[1] = 1.0
+    params = cloudy.pack_params([(nn[i], th[i], kk[i]) for i in range(3)])
+    F = cloudy.get_finite_2d_integrals(plan, dev(cloudy, params)).to_numpy().reshape(N, M, M, n)
+    ocd = oracle.coalescence_data(kc, (3, 2, 3), (0.5, 7.0, INF))
+    worst = 0.0
+    for i in range(0, n, 7):
+        pd = [oracle.make_dist(dt[m], nn[m, i], th[m, i], kk[m, i]) for m in range(3)]
+        mo = oracle.get_moments_matrix(pd, M, ocd.N_mom_max)
+        Fo = oracle.get_finite_2d_integrals(pd, [ocd.dist_thresholds[j] for j in range(3)], mo,
+                                            [ocd.N_2d_ints[j] for j in range(3)])
+        mm = mo[:, :, None] * mo[:, None, :]
+        err = np.abs(F[..., i] - Fo)
+        assert np.all(err <= TOL_QUAD * np.maximum(mm, 1e-300)), i
+        worst = max(worst, float((err / np.maximum(mm, 1e-300)).max()))
+    print("F vs oracle, max |diff| / (M_p M_q):", worst)
+
+
+@pytest.mark.parametrize("dist_types,P,thr", [
+    ([1], 1, (INF,)), ([0], 2, (INF,)), ([1, 1], 2, (0.3e-9, INF)), ([0, 1], 3, (2e-10, INF)),
+    ([1, 0, 1], 2, (1e-10, 3e-8, INF)), ([1, 1, 1], 3, (1e-9, 1e-7, INF)), ([1, 1, 1], 5, (INF, 1e-7, INF)),
+    ([1, 0, 1, 1], 2, (1e-10, INF, 1e-6, INF)), ([1, 1, 1, 1], 3, (1e-9, 1e-7, 1e-5, INF)),
+    ([0, 0], 3, (1e-9, INF)), ([1, 1, 1, 1], 5, (INF, INF, INF, INF)),
+])
+def test_mode_and_order_families_vs_oracle(gpu_cloudy, oracle, dist_types, P, thr):
+    """Every (N, P) family with random symmetric tensors per pair, mixed Exponential / Gamma closures, fixed
+    thresholds (some Inf), against the oracle.  box_gamma_mixture_3modes.jl:29 uses (1e-9, 1e-7, Inf)."""
+    cloudy = gpu_cloudy
+    N = len(dist_types)
+    rng = np.random.default_rng(100 * N + P)
+    kc = np.zeros((N, N, P, P))
+    for j in range(N):
+        for k in range(j, N):
+            a = rng.uniform(0, 1, (P, P)) * (rng.uniform(0, 1, (P, P)) < 0.7)
+            a = (a + a.T) * np.array([[10.0 ** (3 * (x + y)) for y in range(P)] for x in range(P)])
+            kc[j, k] = kc[k, j] = a
+    par, op, _ = make_case(cloudy, oracle, dist_types, kc, thr, bench.NORMS)
+    n = 384 if any(np.isfinite(thr)) else 20_000
+    mom = mixed_moments(dist_types, n, seed=7 + N)
+    d = run_rhs(cloudy, par, mom)
+    want, scale = oracle.rhs_coal_batch(op, mom, with_scale=True)
+    tol = TOL_QUAD if any(np.isfinite(thr)) else TOL_POLY
+    worst = assert_close_scaled(d, want, scale, tol, f"N={N} P={P}")
+    print(f"N={N} P={P} thr={thr}: max |hip-oracle|/scale = {worst:.2e}")
+
+
+def test_moving_threshold_vs_oracle_and_threshold_kats(gpu_cloudy, oracle, kats):
+    """MovingThreshold (Coalescence.jl:152-185; box_gamma_mix_moving.jl:31: percentiles (0.99, 0.99, 0.99, 1.0))."""
+    cloudy = gpu_cloudy
+    b = 5.0
+    dist_types = [1, 1, 0, 1]
+    pct = (0.99, 0.97, 0.5, 1.0)
+    par, op, ts = make_case(cloudy, oracle, dist_types, [[EPS, b], [b, 0.0]], pct, bench.NORMS, moving=True)
+    n = 256
+    mom = mixed_moments(dist_types, n, seed=21)
+    d = run_rhs(cloudy, par, mom, ts)
+    want, scale = oracle.rhs_coal_batch(op, mom, with_scale=True)
+    worst = assert_close_scaled(d, want, scale, TOL_QUAD, "moving")
+    print("moving threshold: max |hip-oracle|/scale =", worst)
+    # compute_thresholds KATs (test_ParticleDistributions_correctness.jl:257-268): Exp(10,1), Gamma(5,10,2)
+    cd = cloudy.CoalescenceData(cloudy.CoalescenceTensor([[1.0]]), (2, 3, 3), (0.97, 0.97, 1.0), (1.0, 1.0),
+                                cloudy.MovingThreshold())
+    plan = cd.plan([0, 1, 1])
+    params = cloudy.pack_params([(np.full(4, 10.0), np.full(4, 1.0)), (np.full(4, 5.0), np.full(4, 10.0), np.full(4, 2.0)),
+                                 (np.ones(4), np.ones(4), np.ones(4))])
+    thr = cloudy.compute_thresholds(plan, dev(cloudy, params)).to_numpy()[:, 0]
+    assert thr[0] == pytest.approx(3.507, rel=1e-3) and thr[0] == pytest.approx(-math.log(1 - 0.97), rel=1e-14)
+    import scipy.special as sp
+
+    assert thr[1] == pytest.approx(10.0 * sp.gammaincinv(2.0, 0.97), rel=1e-12)
+    assert thr[1] == pytest.approx(oracle.compute_threshold(oracle.make_dist(1, 5.0, 10.0, 2.0), 0.97), rel=1e-12)
+    assert np.isinf(thr[2])
+    cd = cloudy.CoalescenceData(cloudy.CoalescenceTensor([[1.0]]), (2, 3), (0.5, 1.0), (1.0, 1.0), cloudy.MovingThreshold())
+    thr = cloudy.compute_thresholds(cd.plan([0, 1]), dev(cloudy, params[:6])).to_numpy()[:, 0]
+    assert thr[0] == pytest.approx(0.6931, rel=1e-3) and thr[0] == pytest.approx(math.log(2.0), rel=1e-14)
+    cd0 = cloudy.CoalescenceData(cloudy.CoalescenceTensor([[1.0]]), (2, 3, 3), (0.0, 0.0, 1.0), (1.0, 1.0),
+                                 cloudy.MovingThreshold())
+    thr0 = cloudy.compute_thresholds(cd0.plan([0, 1, 1]), dev(cloudy, params)).to_numpy()[:, 0]
+    assert abs(thr0[0]) < 1e-6 and abs(thr0[1]) < 1e-6  # percentile 0 -> max(0, 1e-18)
+
+
+def test_sedimentation_flux_kat_and_rainshaft_sources(gpu_cloudy, oracle, kats):
+    cloudy = gpu_cloudy
+    e = kats["sedimentation"]  # Exp(1,1), vel ((1, 0), (-1, 1/6)) -> (-1 + gamma(7/6), -1 + gamma(13/6))
+    cd = cloudy.CoalescenceData(cloudy.CoalescenceTensor([[1.0]]), (2,), (INF,))
+    plan = cd.plan([0], vel=e["vel"])
+    flux = cloudy.get_sedimentation_flux(plan, dev(cloudy, np.ones((2, 5)))).to_numpy()
+    ex = [-1.0 + math.gamma(1 + 1 / 6), -1.0 + math.gamma(2 + 1 / 6)]
+    assert np.allclose(flux[:, 0], ex, rtol=1e-13, atol=0)
+    # rainshaft per-cell sources (rainshaft_gamma_mixture.jl:39-47): Golovin b = 5, thr (2e-10, Inf), vel (50, 1/6)
+    vel = ((50.0, 1.0 / 6),)
+    par, op, _ = make_case(cloudy, oracle, [1, 1], [[EPS, 5.0], [5.0, 0.0]], (2e-10, INF), bench.NORMS, vel=vel)
+    n = 300
+    mom = bench.synth_moments(2, n, seed=13)
+    mom[:, :40] = 0.0               # empty cells (the initial rainshaft column is mostly empty)
+    mom[3:, 40:80] = 0.0            # no rain yet
+    mom[2, 80:90] *= -1.0           # negative moments are clamped to zero in place (:52)
+    mom[:, 90:95] = 1e-30           # all normalised moments < eps -> coalescence skipped (:67-68)
+    plan = par.coal_data.plan([1, 1], vel=vel)
+    cs, sf = cloudy.rainshaft_sources(plan, dev(cloudy, mom))
+    wcs, wsf = oracle.rainshaft_cell_batch(op, mom)
+    _, scale = oracle.rhs_coal_batch(op, np.maximum(mom, 0.0), with_scale=True)
+    assert np.all(np.abs(cs.to_numpy() - wcs) <= TOL_QUAD * np.maximum(scale, 1e-300))
+    assert np.allclose(sf.to_numpy(), wsf, rtol=1e-11, atol=0)
+    assert np.all(cs.to_numpy()[:, :40] == 0.0) and np.all(cs.to_numpy()[:, 90:95] == 0.0)
+
+
+def test_shapes_ragged_sizes_and_padding(gpu_cloudy, oracle):
+    """empty batch, one parcel, sizes that are not multiples of the 64-lane wave / 256-thread block, ld > n."""
+    cloudy = gpu_cloudy
+    import ctypes as C
+
+    wl = bench.make_workload("cfg3a", 1)
+    plan = wl["coal_data"].plan(wl["dist_types"])
+    L = cloudy.lib()
+    assert L.cloudy_coal_rhs(plan.handle, 0, 0, None, None, None) == 0          # n = 0 is a no-op
+    op = bench.oracle_params("cfg3a")
+    for n in (1, 63, 64, 65, 255, 257, 1000, 100_003):
+        mom = bench.synth_moments(2, n, seed=n)
+        d = run_rhs(cloudy, wl["par"], mom)
+        want, scale = oracle.rhs_coal_batch(op, mom, with_scale=True)
+        assert_close_scaled(d, want, scale, TOL_POLY, f"n={n}")
+    # ld > n: planes padded to a multiple of 256; the padding must not be touched
+    n, ld = 1000, 1024
+    mom = bench.synth_moments(2, n, seed=2)
+    buf = np.full((6, ld), 7.0)
+    buf[:, :n] = mom
+    m, dm = dev(cloudy, buf), dev(cloudy, np.full((6, ld), -3.0))
+    assert L.cloudy_coal_rhs(plan.handle, n, ld, m.ptr, dm.ptr, None) == 0
+    out = dm.to_numpy()
+    want, scale = oracle.rhs_coal_batch(op, mom, with_scale=True)
+    assert_close_scaled(out[:, :n], want, scale, TOL_POLY, "ld>n")
+    assert np.all(out[:, n:] == -3.0)
+    assert L.cloudy_coal_rhs(plan.handle, n, n - 1, m.ptr, dm.ptr, None) == cloudy._lib.EINVAL
+    # host-pointer convenience entry point gives the same numbers
+    host_out = np.zeros_like(mom)
+    assert L.cloudy_coal_rhs_host(plan.handle, n, n, mom.ctypes.data, host_out.ctypes.data) == 0
+    assert np.array_equal(host_out, out[:, :n])
+
+
+def test_error_behaviour_on_device(gpu_cloudy):
+    cloudy = gpu_cloudy
+    wl = bench.make_workload("cfg3a", 8)
+    m = dev(cloudy, wl["mom"])
+    with pytest.raises(ValueError):   # dm with the wrong number of planes
+        cloudy.make_box_model_rhs(cloudy.AnalyticalCoalStyle())(cloudy.DeviceArray.zeros(5, 8), m, wl["par"], 0.0)
+    with pytest.raises(NotImplementedError):
+        cloudy.make_box_model_rhs(cloudy.NumericalCoalStyle())(cloudy.DeviceArray.zeros(6, 8), m, wl["par"], 0.0)
+    with pytest.raises(ValueError):   # MovingThreshold RHS on FixedThreshold data
+        cloudy.make_box_model_rhs(cloudy.AnalyticalCoalStyle(), cloudy.MovingThreshold())(
+            cloudy.DeviceArray.zeros(6, 8), m, wl["par"], 0.0)
+    with pytest.raises(cloudy.CloudyError) as e:
+        cloudy.Plan([1], np.array([[1.0, 2.0], [3.0, 4.0]]), (INF,), (1.0, 1.0), 0)
+    assert e.value.code == cloudy._lib.ENOTSYMMETRIC
+    # NaN moments propagate like IEEE Julia: NaN in, NaN out, other parcels untouched
+    mom = wl["mom"].copy()
+    mom[1, 3] = np.nan
+    d = run_rhs(cloudy, wl["par"], mom)
+    assert np.isnan(d[:, 3]).any() and not np.isnan(np.delete(d, 3, axis=1)).any()
+
+
+def test_full_size_properties_1e7(gpu_cloudy):
+    """BASELINE size (1e7 parcels, cfg3a and cfg3b) through size-independent properties: mass conservation,
+    linearity in the kernel tensor, the n -> lambda n scaling (tendencies are bilinear in number), and agreement
+    of the two entry points (moments in / parameters in)."""
+    cloudy = gpu_cloudy
+    n = 10_000_000
+    for name in ("cfg3a", "cfg3b"):
+        wl = bench.make_workload(name, n, seed=1)
+        plan = wl["coal_data"].plan(wl["dist_types"])
+        m = dev(cloudy, wl["mom"])
+        dm = cloudy.DeviceArray.zeros(6, n)
+        rhs = cloudy.make_box_model_rhs(cloudy.AnalyticalCoalStyle())
+        rhs(dm, m, wl["par"], 0.0)
+        s = cloudy.moment_sums(plan, dm)
+        d = dm.to_numpy()
+        assert np.allclose(s, d.sum(axis=1), rtol=1e-9)
+        # (1) mass: per parcel the two mass tendencies cancel
+        gross = np.abs(d[1]) + np.abs(d[4])
+        assert np.all(np.abs(d[1] + d[4]) <= 1e-9 * np.maximum(gross, 1e-300))
+        assert abs(s[1] + s[4]) <= 1e-9 * abs(s[1])
+        # (2) number can only decrease, the second moment can only grow (coalescence)
+        assert np.all(d[0] + d[3] <= 0) and np.all(d[2] + d[5] >= -1e-12 * (np.abs(d[2]) + np.abs(d[5])))
+        # (3) n -> 2n doubles every moment: tendencies x4
+        m2 = dev(cloudy, 2.0 * wl["mom"][:, :1_000_000])
+        dm2 = cloudy.DeviceArray.zeros(6, 1_000_000)
+        rhs(dm2, m2, wl["par"], 0.0)
+        d2 = dm2.to_numpy()
+        ref = 4.0 * d[:, :1_000_000]
+        # (exact for thr = Inf up to the eps guards; for finite thr the guard M_p M_q < eps is scale dependent)
+        close = np.isclose(d2, ref, rtol=1e-9, atol=0) | (np.abs(d2 - ref) <= 1e-9 * (np.abs(d2) + np.abs(ref)))
+        assert close.mean() > 0.999
+        # (4) linearity in the tensor: rhs(c) = rhs(c_a) + rhs(c_b) with c = c_a + c_b
+        if name == "cfg3a":
+            kc = wl["kernel_c"]
+            ka, kb = kc.copy(), kc.copy()
+            ka[:, :, 0, 1] = ka[:, :, 1, 0] = 0.0
+            kb[:, :, 0, 2] = kb[:, :, 2, 0] = 0.0
+            kb[:, :, 0, 0] = 0.0
+            outs = []
+            for kk in (ka, kb):
+                kern = tuple(tuple(cloudy.CoalescenceTensor(kk[j, k]) for k in range(2)) for j in range(2))
+                cd = cloudy.CoalescenceData(kern, (3, 3), wl["spec"]["thresholds"], bench.NORMS)
+                par = cloudy.ODEParameters(wl["par"].pdists, cd, (3, 3), bench.NORMS)
+                o = cloudy.DeviceArray.zeros(6, n)
+                rhs(o, m, par, 0.0)
+                outs.append(o.to_numpy())
+            lin = outs[0] + outs[1]
+            assert np.all(np.abs(lin - d) <= 1e-11 * (np.abs(outs[0]) + np.abs(outs[1]) + 1e-300))
+        del m, dm, d

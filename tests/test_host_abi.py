@@ -1,0 +1,197 @@
+"""CPU-only checks of the boundary: the C-ABI library loads and exports every symbol include/cloudy_hip.h
+declares; host-side logic (index maps, CoalescenceData derived fields, tensor checks, error behaviour)
+matches the reference KATs and the oracle; no compute call is made (there is no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INF = float("inf")
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "cloudy_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(cloudy_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(cloudy):
+    L = cloudy.lib()
+    names = _header_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/cloudy_hip.h but not exported"
+    assert sorted(cloudy._lib.SYMBOLS) == names, "ctypes table and header disagree"
+    assert L.cloudy_version() == 100
+
+
+def test_plan_desc_layout_and_defaults(cloudy):
+    d = cloudy._lib.PlanDesc()
+    cloudy.lib().cloudy_plan_desc_init(C.byref(d))
+    assert d.struct_size == C.sizeof(cloudy._lib.PlanDesc)
+    assert (d.k_range[0], d.k_range[1]) == (np.finfo(np.float64).eps, 10.0)
+    assert d.n_bins_per_log_unit == 15 and d.device == -1
+    assert all(np.isinf(d.dist_thresholds[i]) for i in range(4))
+
+
+def test_plan_validation_errors_precede_device_lookup(cloudy):
+    L = cloudy.lib()
+
+    def create(mut):
+        d = cloudy._lib.PlanDesc()
+        L.cloudy_plan_desc_init(C.byref(d))
+        c = np.array([[0.0, 5.0], [5.0, 0.0]])
+        d.n_modes, d.tensor_p = 1, 2
+        d.dist_type[0] = 1
+        d.kernel_c = c.ctypes.data_as(C.POINTER(C.c_double))
+        mut(d, c)
+        h = C.c_void_p()
+        rc = L.cloudy_plan_create(C.byref(d), C.byref(h))
+        msg = L.cloudy_last_error().decode()
+        if rc == 0:
+            L.cloudy_plan_destroy(h)
+        return rc, msg
+
+    E = cloudy._lib
+    rc, msg = create(lambda d, c: c.__setitem__((0, 1), 4.0))
+    assert rc == E.ENOTSYMMETRIC and "not symmetric" in msg          # KernelTensors.jl:157-171
+    rc, msg = create(lambda d, c: d.norms.__setitem__(0, 0.0))
+    assert rc == E.EINVAL and "norms must be positive" in msg         # helper_functions.jl:44-46
+    rc, _ = create(lambda d, c: setattr(d, "n_modes", 9))
+    assert rc == E.EUNSUPPORTED
+    rc, _ = create(lambda d, c: setattr(d, "tensor_p", 6))
+    assert rc == E.EUNSUPPORTED
+    rc, _ = create(lambda d, c: d.dist_type.__setitem__(0, 3))
+    assert rc == E.EUNSUPPORTED
+    rc, _ = create(lambda d, c: setattr(d, "struct_size", 8))
+    assert rc == E.EINVAL
+    rc, _ = create(lambda d, c: setattr(d, "dtype", 1))
+    assert rc == E.EUNSUPPORTED
+    if cloudy.device_count() == 0:
+        rc, msg = create(lambda d, c: None)
+        assert rc == E.ENODEVICE and "no HIP device" in msg           # fails loudly, no CPU fallback
+
+
+def test_no_cpu_fallback_and_no_oracle_in_product(cloudy):
+    """The product package never imports the oracle, and batched calls without a GPU raise."""
+    pkg_dir = os.path.join(ROOT, "cloudy.jl_amd")
+    pat = re.compile(r"^\s*(import|from)\s+\S*oracle|cloudy_oracle|libcloudy_oracle|co_rhs_coal", re.M)
+    for fn in os.listdir(pkg_dir):
+        if fn.endswith(".py"):
+            assert not pat.search(open(os.path.join(pkg_dir, fn)).read()), fn
+    for fn in os.listdir(os.path.join(pkg_dir, "csrc")):
+        if fn.endswith((".hip", ".hpp", ".h", "Makefile")):
+            assert not pat.search(open(os.path.join(pkg_dir, "csrc", fn)).read()), fn
+    if cloudy.device_count() == 0:
+        cd = cloudy.CoalescenceData(cloudy.CoalescenceTensor([[1.0]]), (3,), (INF,))
+        with pytest.raises(cloudy.CloudyError) as e:
+            cd.plan([1])
+        assert e.value.code == cloudy._lib.ENODEVICE
+
+
+def test_helper_function_kats(cloudy, kats):
+    e = kats["helper_functions"]
+    npm = tuple(e["NProgMoms"])
+    for i, m, ex in e["moment_ind"]:
+        assert cloudy.get_dist_moment_ind(npm, i, m) == ex
+    for i, m in e["moment_ind_throws"]:
+        with pytest.raises((ValueError, IndexError)):
+            cloudy.get_dist_moment_ind(npm, i, m)
+    for i, a, b in e["ind_range"]:
+        assert cloudy.get_dist_moments_ind_range(npm, i) == range(a, b + 1)
+    with pytest.raises(IndexError):
+        cloudy.get_dist_moments_ind_range(npm, 4)
+    assert np.allclose(cloudy.get_moments_normalizing_factors(npm, e["norms"]), e["norm_factors"], atol=e["atol"], rtol=0)
+    assert cloudy.rflatten(((1, 2), (3.2, (1.2, 1.0)), (1,))) == (1, 2, 3.2, 1.2, 1.0, 1)
+
+
+def test_kernel_tensor_and_function_kats(cloudy, kats, oracle):
+    e = kats["normalized_kernel_tensor"]
+    kn = cloudy.get_normalized_kernel_tensor(cloudy.CoalescenceTensor(e["c"]), e["norms"])
+    assert np.allclose(kn.c, e["expected"], atol=e["atol"], rtol=0)
+    assert np.array_equal(kn.c, oracle.get_normalized_kernel_tensor(e["c"], e["norms"]))
+    for c in kats["check_symmetry"]["ok"]:
+        cloudy.check_symmetry(c)
+    for c in kats["check_symmetry"]["throws"]:
+        with pytest.raises(ValueError):
+            cloudy.CoalescenceTensor(c)
+    kn = kats["kernel_normalization"]
+    norms = kn["norms"]
+    assert cloudy.get_normalized_kernel_func(cloudy.ConstantKernelFunction(1.0), norms).coll_coal_rate == 100.0
+    assert cloudy.get_normalized_kernel_func(cloudy.LinearKernelFunction(1.0), norms).coll_coal_rate == 1.0 * 100.0 * 0.001
+    h = cloudy.get_normalized_kernel_func(cloudy.HydrodynamicKernelFunction(1.0), norms)
+    assert abs(h.coal_eff - 100.0 * 0.001 ** (4.0 / 3)) < 1e-12
+    lg = cloudy.get_normalized_kernel_func(cloudy.LongKernelFunction(1.0, 10.0, 5.0), norms)
+    assert (lg.x_threshold, lg.coal_rate_below_threshold, lg.coal_rate_above_threshold) == (
+        1.0 / 0.001, 10.0 * 100.0 * 0.001**2, 5.0 * 100.0 * 0.001)
+    for e in kats["kernel_functions"]:
+        cls = {"constant": cloudy.ConstantKernelFunction, "linear": cloudy.LinearKernelFunction,
+               "hydrodynamic": cloudy.HydrodynamicKernelFunction, "long": cloudy.LongKernelFunction}[e["kind"]]
+        k = cls(*e["params"])
+        if "expected" in e:
+            assert k(e["x"], e["y"]) == e["expected"]
+        assert k(e["x"], e["y"]) == k(e["y"], e["x"])
+    # exact tensors of polynomial kernels, with the forced C_1_1 = max(eps, K(0,0)) of KernelTensors.jl:115
+    eps = np.finfo(np.float64).eps
+    t = cloudy.CoalescenceTensor(cloudy.LinearKernelFunction(5e-3), 1, 10.0)
+    assert np.array_equal(t.c, [[eps, 5e-3], [5e-3, 0.0]])
+    lk = cloudy.LongKernelFunction(5.236e-10, 9.44e9, 5.78)   # box_gamma_mixture_long.jl:20-30
+    assert np.array_equal(cloudy.CoalescenceTensor(lk, 2, 5e-10).c, [[eps, 0, 9.44e9], [0, 0, 0], [9.44e9, 0, 0]])
+    assert np.array_equal(cloudy.CoalescenceTensor(lk, 2, 1e-6, 5e-10).c, [[eps, 5.78, 0], [5.78, 0, 0], [0, 0, 0]])
+    with pytest.raises(NotImplementedError):
+        cloudy.CoalescenceTensor(cloudy.HydrodynamicKernelFunction(1.0), 4, 1e-6)
+
+
+def test_coalescence_data_fields_match_oracle(cloudy, oracle):
+    rng = np.random.default_rng(5)
+    for N, P, npm in [(1, 1, (3,)), (2, 2, (3, 2)), (3, 3, (2, 2, 3)), (4, 5, (3, 3, 3, 3)), (2, 3, (2, 2))]:
+        kc = rng.uniform(0, 1, (N, N, P, P))
+        kc = kc + kc.transpose(0, 1, 3, 2)
+        thr = tuple([0.5e-9 * (i + 1) for i in range(N - 1)] + [INF])
+        kernels = tuple(tuple(cloudy.CoalescenceTensor(kc[j, k]) for k in range(N)) for j in range(N))
+        cd = cloudy.CoalescenceData(kernels, npm, thr, (1e6, 1e-9))
+        ocd = oracle.coalescence_data(kc, npm, thr, (1e6, 1e-9))
+        assert cd.N_mom_max == ocd.N_mom_max
+        assert list(cd.N_2d_ints) == [ocd.N_2d_ints[i] for i in range(N)]
+        assert np.array_equal(cd.dist_thresholds, [ocd.dist_thresholds[i] for i in range(N)])
+    with pytest.raises(ValueError):
+        cloudy.CoalescenceData(cloudy.CoalescenceTensor([[1.0]]), (3, 3), (INF,))
+
+
+def test_distribution_constructors(cloudy):
+    G, E = cloudy.GammaPrimitiveParticleDistribution, cloudy.ExponentialPrimitiveParticleDistribution
+    for bad in ((-1.0, 2.0, 3.0), (1.0, -2.0, 3.0), (1.0, 2.0, -3.0)):
+        with pytest.raises(ValueError):
+            G(*bad)
+    for bad in ((-1.0, 2.0), (1.0, -2.0)):
+        with pytest.raises(ValueError):
+            E(*bad)
+    assert cloudy.nparams(G(1.0, 1.0, 2.0)) == 3 and cloudy.nparams(E(1.0, 1.0)) == 2
+    assert cloudy.get_moments(G(1.0, 1.0, 2.0)) == [1.0, 2.0, 6.0]
+    assert cloudy.get_moments(E(1.0, 2.0)) == [1.0, 2.0]
+
+
+def test_box_model_rhs_factory_signature(cloudy):
+    rhs = cloudy.make_box_model_rhs(cloudy.AnalyticalCoalStyle())
+    import inspect
+
+    assert list(inspect.signature(rhs).parameters) == ["dm", "m", "par", "t"]  # rhs!(dm, m, par, t)
+    with pytest.raises(TypeError):
+        cloudy.make_box_model_rhs("analytical")
+    assert isinstance(cloudy.AnalyticalCoalStyle(), cloudy.CoalescenceStyle)
+    assert not isinstance(cloudy.AnalyticalCoalStyle(), cloudy.NumericalCoalStyle)
+
+
+def test_synthetic_workload_is_deterministic_and_degenerate_cases_present():
+    import bench
+
+    a = bench.synth_moments(2, 5000, seed=11)
+    b = bench.synth_moments(2, 5000, seed=11)
+    assert np.array_equal(a, b) and a.shape == (6, 5000)
+    assert (a[0] == 0).sum() > 0                      # empty parcels
+    var = a[2] / a[1] - a[1] / a[0]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        assert (var < 0).sum() > 0 and (np.abs(var) < 1e-25).sum() > 0
