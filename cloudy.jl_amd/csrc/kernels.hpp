@@ -35,7 +35,7 @@ struct KArgs {
     int32_t n_2d[N];
     int32_t n_mom_max, input_kind, rainshaft, nbpl;
     double thr[N];                     // FIXED: threshold / m0; MOVING: percentile
-    double inv_norm[3 * N], out_scale[3 * N];
+    double norm[3 * N], inv_norm[3 * N], out_scale[3 * N];
     double kmin, kmax;
     double c[N][N][P][P];              // normalised tensors, c[j][k][a][b]
 };
@@ -47,6 +47,15 @@ __host__ __device__ constexpr int tri(int p, int q) {  // packed upper triangle,
 template <int M>
 __host__ __device__ constexpr int trisym(int p, int q) {
     return p <= q ? tri<M>(p, q) : tri<M>(q, p);
+}
+
+// x / d for a wave-uniform divisor d with r = RN(1/d): q = RN(x r), e = x - q d (exact by FMA),
+// RN(q + e r) is the correctly rounded quotient (Markstein's correction step) -- 3 VALU ops, no v_div_*.
+__device__ __forceinline__ double div_by_const(double x, double d, double r) {
+    const double q = x * r;
+    const double e = fma(-q, d, x);
+    const double qc = fma(e, r, q);
+    return (q - q == 0.0) ? qc : q;  // keep Inf / NaN from the first product
 }
 
 // update_dist_from_moments, ParticleDistributions.jl:456-476 / :512-523 (normalised moments in)
@@ -388,9 +397,11 @@ __device__ __forceinline__ bool load_parcel(const KArgs<N, P> &A, size_t i, size
                 m1 = m1 < 0.0 ? 0.0 : m1;
                 m2 = m2 < 0.0 ? 0.0 : m2;
             }
-            m0 *= A.inv_norm[3 * m + 0];
-            m1 *= A.inv_norm[3 * m + 1];
-            m2 *= A.inv_norm[3 * m + 2];
+            // mom ./ mom_norms (box_model_helpers.jl:31) as a correctly rounded division: the closure inversion
+            // below is ill-conditioned at zero variance, where one ulp decides the sign of M2/M1 - M1/M0.
+            m0 = div_by_const(m0, A.norm[3 * m + 0], A.inv_norm[3 * m + 0]);
+            m1 = div_by_const(m1, A.norm[3 * m + 1], A.inv_norm[3 * m + 1]);
+            m2 = div_by_const(m2, A.norm[3 * m + 2], A.inv_norm[3 * m + 2]);
             all_small = all_small && (m0 < kEps) && (m1 < kEps) && (!three || m2 < kEps);
             invert_closure(A.dist_type[m], m0, m1, m2, A.kmin, A.kmax, nn[m], th[m], kk[m]);
         }

@@ -24,6 +24,7 @@ void fill_args(const HostPlan &h, const LaunchReq &r, KArgs<N, P> &A) {
         A.n_2d[i] = h.n_2d[i];
         A.thr[i] = h.thr[i];
         for (int m = 0; m < 3; ++m) {
+            A.norm[3 * i + m] = h.mom_norm[i][m];
             A.inv_norm[3 * i + m] = 1.0 / h.mom_norm[i][m];
             A.out_scale[3 * i + m] = r.physical_out ? h.mom_norm[i][m] : 1.0;
         }
