@@ -55,7 +55,8 @@ __device__ __forceinline__ double div_by_const(double x, double d, double r) {
     const double q = x * r;
     const double e = fma(-q, d, x);
     const double qc = fma(e, r, q);
-    return (q - q == 0.0) ? qc : q;  // keep Inf / NaN from the first product
+    return (fabs(q) <= 1.7976931348623157e308) ? qc : q;  // keep Inf / NaN from the first product
+    // (not `q - q == 0`: under -ffp-contract=fast that contracts to fma(x, r, -q), the rounding error of q)
 }
 
 // update_dist_from_moments, ParticleDistributions.jl:456-476 / :512-523 (normalised moments in)

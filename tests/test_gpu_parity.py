@@ -204,8 +204,14 @@ def test_finite_2d_integrals_and_moment_source_helper_kats(gpu_cloudy, oracle, k
             if e["dist"] == spec:
                 p1, p2 = int(e["p1"]), int(e["p2"])
                 lo, hi = min(p1, p2), max(p1, p2)
+                # get_finite_2d_integrals only ever evaluates moment_source_helper(p1 <= p2) and mirrors it
+                # (Coalescence.jl:213, 232-240); the (1, 0) KAT equals the (0, 1) entry mathematically, to the
+                # Simpson error (~7e-5) numerically.
                 assert F[0, lo, hi] == pytest.approx(e["expected"], rel=e["rtol"]), e["cite"]
-                assert F[0, lo, hi] == pytest.approx(e["restated"], rel=1e-10), e["cite"]
+                od = oracle.make_dist(t, *spec[1:])
+                assert F[0, lo, hi] == pytest.approx(oracle.moment_source_helper(od, lo, hi, 0.5, 20), rel=1e-10)
+                if p1 <= p2:
+                    assert F[0, lo, hi] == pytest.approx(e["restated"], rel=1e-10), e["cite"]
                 assert F[0, hi, lo] == F[0, lo, hi]
     # random parcels, default 15 bins, 3 modes with two finite thresholds, P = 3, vs the oracle
     rng = np.random.default_rng(4)
@@ -372,11 +378,20 @@ def test_error_behaviour_on_device(gpu_cloudy):
     with pytest.raises(cloudy.CloudyError) as e:
         cloudy.Plan([1], np.array([[1.0, 2.0], [3.0, 4.0]]), (INF,), (1.0, 1.0), 0)
     assert e.value.code == cloudy._lib.ENOTSYMMETRIC
-    # NaN moments propagate like IEEE Julia: NaN in, NaN out, other parcels untouched
+    # NaN / Inf moments behave as in the reference: a NaN M0 or M1 fails the `> eps` guard and selects the
+    # fallback distribution (ParticleDistributions.jl:461-475), a NaN M2 propagates through k; other parcels
+    # are untouched.  The oracle restates exactly that.
+    from oracle import cloudy_oracle as O
+
     mom = wl["mom"].copy()
     mom[1, 3] = np.nan
+    mom[2, 5] = np.nan
+    mom[0, 6] = np.inf
     d = run_rhs(cloudy, wl["par"], mom)
-    assert np.isnan(d[:, 3]).any() and not np.isnan(np.delete(d, 3, axis=1)).any()
+    want = O.rhs_coal_batch(bench.oracle_params("cfg3a"), mom)
+    assert np.array_equal(np.isnan(d), np.isnan(want))
+    assert np.isnan(d[:, 5]).any() and not np.isnan(d[:, 3]).any()
+    assert not np.isnan(np.delete(d, [5, 6], axis=1)).any()
 
 
 def test_full_size_properties_1e7(gpu_cloudy):
