@@ -204,11 +204,12 @@ def _cpu_baseline(name, target_seconds=12.0):
     p = oracle_params(name)
     nthreads = O.max_threads()
     n_modes = workload_spec(name)["n_modes"]
-    probe = synth_moments(n_modes, 2000, SEED)
+    probe = synth_moments(n_modes, 200 * nthreads, SEED)
+    O.rhs_coal_batch(p, probe, n_threads=nthreads)          # spawns the OpenMP team
     t0 = time.perf_counter()
     O.rhs_coal_batch(p, probe, n_threads=nthreads)
     per = max((time.perf_counter() - t0) / probe.shape[1], 1e-9)
-    n = int(min(max(target_seconds / per, 2000), 4_000_000))
+    n = int(min(max(target_seconds / per, 2000), 20_000_000))
     mom = synth_moments(n_modes, n, SEED)
     t0 = time.perf_counter()
     O.rhs_coal_batch(p, mom, n_threads=nthreads)
