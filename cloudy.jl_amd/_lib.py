@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcloudy_hip.so")
+# CLOUDY_HIP_LIB selects another build of the SAME C ABI (kernel A/B experiments); never a CPU library.
+LIB_PATH = os.environ.get("CLOUDY_HIP_LIB") or os.path.join(_HERE, "libcloudy_hip.so")
 
 MAX_MODES, MAX_P, MAX_VEL = 4, 5, 4
 OK, EINVAL, ENOTSYMMETRIC, EHIP, ENOMEM, EUNSUPPORTED, ENODEVICE = 0, -1, -2, -3, -4, -5, -6

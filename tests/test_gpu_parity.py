@@ -390,7 +390,8 @@ def test_error_behaviour_on_device(gpu_cloudy):
     mom[2, 5] = np.nan
     d = run_rhs(cloudy, wl["par"], mom)
     want = O.rhs_coal_batch(bench.oracle_params("cfg3a"), mom)
-    assert not np.isnan(d[:, 3]).any() and np.allclose(d[:, 3], want[:, 3], rtol=1e-12, atol=0)
+    _, scale = O.rhs_coal_batch(bench.oracle_params("cfg3a"), np.nan_to_num(mom, nan=0.0), with_scale=True)
+    assert not np.isnan(d[:, 3]).any() and np.all(np.abs(d[:, 3] - want[:, 3]) <= TOL_POLY * scale[:, 3])
     assert np.isnan(d[:3, 5]).all() and np.isnan(want[:3, 5]).all()
     keep = [i for i in range(8) if i != 5]
     assert not np.isnan(d[:, keep]).any()
