@@ -19,30 +19,42 @@ constexpr double kSqrtEps = 1.4901161193847656e-08;     // 2^-26: x >= 2^-26 && 
 // (the caller has E from one exp()).  z <= a+1: power series P = E * sum_n z^n / (a+1)_n evaluated as
 // a ratio N_n / D_n (no division per term).  z > a+1: Legendre continued fraction for Q = 1 - P by the
 // Wallis forward recurrence (no division per term).  *q_out gets Q on the same branch's accuracy.
+#ifndef CLOUDY_SERIES_TOL
+#define CLOUDY_SERIES_TOL 1e-17
+#endif
+#ifndef CLOUDY_CF_TOL
+#define CLOUDY_CF_TOL 1e-16
+#endif
 __device__ __forceinline__ double inc_gamma_p_from_E(double a, double z, double E, double *q_out) {
+#ifdef CLOUDY_ABLATE_PTOP  // timing experiment only: skips the series / continued fraction
+    if (q_out) *q_out = 1.0 - E;
+    return E;
+#endif
     if (z <= a + 1.0) {
-        double Nn = 1.0, Dn = 1.0, zp = 1.0, ap = a;
+        // S = sum_n z^n/(a+1)_n = N_n/D_n with both scaled by z^-n:  q_n = (a+n)/z,
+        //   N'_n = N'_{n-1} q_n + 1,  D'_n = D'_{n-1} q_n;   term_n / S_n = 1 / N'_n   (3 VALU ops per term)
+        const double invz = 1.0 / z;
+        double q = a * invz, Nn = 1.0, Dn = 1.0;
 #pragma unroll 1
         for (int it = 0; it < 100; ++it) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                ap += 1.0;
-                zp *= z;
-                Nn = fma(Nn, ap, zp);
-                Dn *= ap;
+                q += invz;
+                Nn = fma(Nn, q, 1.0);
+                Dn *= q;
             }
-            if (!(zp > Nn * 1e-17)) break;
-            if (Dn > 1e200) {
-                Nn *= 1e-200;
-                Dn *= 1e-200;
-                zp *= 1e-200;
-            }
+            if (!(Nn < 1.0 / CLOUDY_SERIES_TOL)) break;  // D' <= N': no overflow before convergence
         }
         double p = E * (Nn / Dn);
         p = p > 1.0 ? 1.0 : p;
         if (q_out) *q_out = 1.0 - p;
         return p;
     } else {
+        // Q = a E f with f < 1/2 for z > a+1: below 1e-18 it cannot change P = 1 - Q (nor any lower order)
+        if (a * E < 1e-18) {
+            if (q_out) *q_out = a * E * (1.0 / (z + 1.0 - a));
+            return 1.0;
+        }
         // f = a1/(b1 + a2/(b2 + ...)), a1 = 1, b1 = z+1-a, a_n = -(n-1)(n-1-a), b_n = b_{n-1} + 2
         double b = z + 1.0 - a;
         double Ap = 0.0, Bp = 1.0, Ac = 1.0, Bc = b;
@@ -63,7 +75,7 @@ __device__ __forceinline__ double inc_gamma_p_from_E(double a, double z, double 
             }
             // f_n - f_{n-1} = (Ac*Bp - Ap*Bc) / (Bc*Bp)
             double lhs = fabs(fma(Ac, Bp, -(Ap * Bc)));
-            if (!(lhs > 1e-16 * fabs(Ac * Bp))) break;
+            if (!(lhs > CLOUDY_CF_TOL * fabs(Ac * Bp))) break;
             if (fabs(Bc) > 1e150) {
                 Ap *= 1e-150;
                 Bp *= 1e-150;

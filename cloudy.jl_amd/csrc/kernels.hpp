@@ -440,6 +440,95 @@ __global__ void __launch_bounds__(kBlock)
     }
 }
 
+// Threshold modes (FIXED / MOVING): the cost of a parcel is dominated by the incomplete-gamma evaluations of its
+// Simpson nodes, and which algorithm a node takes (power series for z <= a+1, continued fraction above; P == 1
+// far above) is decided by r = (x_t/theta) / (a_top + 1) of the parcel.  Lanes of one wave execute every branch
+// any of them takes, so the 256 parcels of a workgroup are first ranked by r (counting sort in LDS) and each
+// lane then processes the parcel of its rank: waves become regime-homogeneous.  Parcels stay inside their
+// workgroup's 256-parcel window (2 KB per plane), so stores remain line-coalesced.
+template <int N, int P, int MODE>
+__global__ void __launch_bounds__(kBlock)
+    coal_rhs_sorted_kernel(const KArgs<N, P> A, const double *__restrict__ nodes, size_t n, size_t ld,
+                           const double *__restrict__ in, double *__restrict__ out) {
+    __shared__ double sh_par[3 * N][kBlock];
+    __shared__ unsigned int sh_key[kBlock];
+    __shared__ unsigned short sh_perm[kBlock];
+    __shared__ unsigned char sh_small[kBlock];
+    const int t = threadIdx.x;
+    const size_t base = (size_t)blockIdx.x * kBlock;
+    {
+        const size_t i0 = base + t;
+        double nn[N], th[N], kk[N];
+        bool all_small = true;
+        unsigned int key = 0xFFFFFFFFu;  // out-of-range or empty parcels rank last
+        if (i0 < n) {
+            all_small = load_parcel<N, P>(A, i0, ld, in, nn, th, kk);
+            int f = 0;  // first mode that carries a threshold (wave-uniform)
+            if (MODE == MODE_FIXED) {
+#pragma unroll
+                for (int m = N - 2; m >= 0; --m)
+                    if (A.finite[m]) f = m;
+            }
+            double nf = nn[0], thf = th[0], kf = kk[0], xtf = A.thr[0];
+#pragma unroll
+            for (int m = 1; m < N; ++m)
+                if (m == f) {
+                    nf = nn[m];
+                    thf = th[m];
+                    kf = kk[m];
+                    xtf = A.thr[m];
+                }
+            // MOVING: x_t / theta = P^-1(k; p) is a monotone function of k alone -> rank by k
+            const float r = (MODE == MODE_FIXED) ? (float)((xtf / thf) / (kf + double(P + 2))) : (float)kf;
+            if (nf > 0.0 && r == r) key = __float_as_uint(fmaxf(r, 0.0f));
+        } else {
+#pragma unroll
+            for (int m = 0; m < N; ++m) {
+                nn[m] = 0.0;
+                th[m] = 1.0;
+                kk[m] = 1.0;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+            sh_par[3 * m + 0][t] = nn[m];
+            sh_par[3 * m + 1][t] = th[m];
+            sh_par[3 * m + 2][t] = kk[m];
+        }
+        sh_key[t] = key;
+        sh_small[t] = all_small ? 1 : 0;
+        __syncthreads();
+        int rank = 0;
+#pragma unroll 8
+        for (int s2 = 0; s2 < kBlock; ++s2) {
+            const unsigned int ks = sh_key[s2];
+            rank += (ks < key || (ks == key && s2 < t)) ? 1 : 0;
+        }
+        sh_perm[rank] = (unsigned short)t;
+        __syncthreads();
+    }
+    const int src = sh_perm[t];
+    const size_t i = base + src;
+    if (i < n) {
+        double nn[N], th[N], kk[N], acc[N][3];
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+            nn[m] = sh_par[3 * m + 0][src];
+            th[m] = sh_par[3 * m + 1][src];
+            kk[m] = sh_par[3 * m + 2][src];
+        }
+        coal_ints_parcel<N, P, MODE>(A, nodes, nn, th, kk, acc);
+        const bool skip = A.rainshaft && sh_small[src];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const int off = A.off[k];
+            out[(size_t)(off + 0) * ld + i] = skip ? 0.0 : acc[k][0] * A.out_scale[3 * k + 0];
+            out[(size_t)(off + 1) * ld + i] = skip ? 0.0 : acc[k][1] * A.out_scale[3 * k + 1];
+            if (A.np[k] == 3) out[(size_t)(off + 2) * ld + i] = skip ? 0.0 : acc[k][2] * A.out_scale[3 * k + 2];
+        }
+    }
+}
+
 // ---- diagnostics / the callers either side of the operator ---------------------------------------
 
 template <int N, int P>

@@ -53,11 +53,11 @@ hipError_t launch_np(const HostPlan &h, const LaunchReq &r) {
             hipLaunchKernelGGL((coal_rhs_kernel<N, P, MODE_ALLINF>), dim3(g), dim3(kBlock), 0, r.stream, A, h.nodes_dev,
                                r.n, r.ld, r.in, r.out);
         else if (h.mode == MODE_FIXED)
-            hipLaunchKernelGGL((coal_rhs_kernel<N, P, MODE_FIXED>), dim3(g), dim3(kBlock), 0, r.stream, A, h.nodes_dev,
-                               r.n, r.ld, r.in, r.out);
+            hipLaunchKernelGGL((coal_rhs_sorted_kernel<N, P, MODE_FIXED>), dim3(g), dim3(kBlock), 0, r.stream, A,
+                               h.nodes_dev, r.n, r.ld, r.in, r.out);
         else
-            hipLaunchKernelGGL((coal_rhs_kernel<N, P, MODE_MOVING>), dim3(g), dim3(kBlock), 0, r.stream, A, h.nodes_dev,
-                               r.n, r.ld, r.in, r.out);
+            hipLaunchKernelGGL((coal_rhs_sorted_kernel<N, P, MODE_MOVING>), dim3(g), dim3(kBlock), 0, r.stream, A,
+                               h.nodes_dev, r.n, r.ld, r.in, r.out);
         break;
     }
     case OP_UPDATE_DIST:

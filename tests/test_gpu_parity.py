@@ -395,7 +395,7 @@ def test_error_behaviour_on_device(gpu_cloudy):
     assert np.isnan(d[:3, 5]).all() and np.isnan(want[:3, 5]).all()
     keep = [i for i in range(8) if i != 5]
     assert not np.isnan(d[:, keep]).any()
-    assert np.allclose(d[:, keep], want[:, keep], rtol=1e-9, atol=0)
+    assert np.all(np.abs(d[:, keep] - want[:, keep]) <= TOL_POLY * scale[:, keep])
 
 
 def test_full_size_properties_1e7(gpu_cloudy):
