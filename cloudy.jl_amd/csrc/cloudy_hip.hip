@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -247,6 +248,10 @@ int cloudy_plan_create(const cloudy_plan_desc *d, cloudy_plan **out) {
         h.device = d->device;
     } else {
         (void)hipGetDevice(&h.device);
+    }
+    {
+        const char *e = std::getenv("CLOUDY_HIP_PPL1");
+        h.force_ppl1 = (e && e[0] == '1') ? 1 : 0;
     }
     h.n_nodes = (int)(nodes.size() / kNodeStride);
     if (h.n_nodes > 0) {

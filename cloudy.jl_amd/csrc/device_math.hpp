@@ -58,20 +58,21 @@ __device__ __forceinline__ double inc_gamma_p_from_E(double a, double z, double 
         // f = a1/(b1 + a2/(b2 + ...)), a1 = 1, b1 = z+1-a, a_n = -(n-1)(n-1-a), b_n = b_{n-1} + 2
         double b = z + 1.0 - a;
         double Ap = 0.0, Bp = 1.0, Ac = 1.0, Bc = b;
-        double i = 0.0;
+        // a_{i+1} - a_i = -(2i + 1 - a) = z - b_i: the partial numerators follow by additions (7 VALU ops per step)
+        double an = a - 1.0, c = a - 1.0;  // a_1 = -(1 - a); c_i = z - b_i, c_0 = a - 1
 #pragma unroll 1
         for (int it = 0; it < 100; ++it) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                i += 1.0;
-                double an = -i * (i - a);
                 b += 2.0;
-                double An = fma(b, Ac, an * Ap);
-                double Bn = fma(b, Bc, an * Bp);
+                const double An = fma(b, Ac, an * Ap);
+                const double Bn = fma(b, Bc, an * Bp);
                 Ap = Ac;
                 Bp = Bc;
                 Ac = An;
                 Bc = Bn;
+                c -= 2.0;
+                an += c;
             }
             // f_n - f_{n-1} = (Ac*Bp - Ap*Bc) / (Bc*Bp)
             double lhs = fabs(fma(Ac, Bp, -(Ap * Bc)));

@@ -24,6 +24,7 @@ struct HostPlan {
     double vel[CLOUDY_MAX_VEL][2] = {{0}};              // physical
     double vel_n[CLOUDY_MAX_VEL][2] = {{0}};            // rainshaft_helpers.jl:74-76
     int device = 0;
+    int force_ppl1 = 0;  // CLOUDY_HIP_PPL1=1: always the one-parcel-per-lane ALLINF kernel (A/B timing)
     double *nodes_dev = nullptr;                        // [n_nodes][kNodeStride]
     int n_nodes = 0;
     double *partial_dev = nullptr;                      // moment_sums workspace

@@ -40,6 +40,21 @@ struct KArgs {
     double c[N][N][P][P];              // normalised tensors, c[j][k][a][b]
 };
 
+// Streaming accesses: every moment is read once and every tendency written once per launch, so they carry the
+// nontemporal hint (measured with tools/hbm_ceiling.hip on MI355X: 6-plane copy 5.6 -> 6.0 TB/s).
+typedef double dvec2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double ld_stream(const double *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ dvec2 ld_stream2(const double *p) {
+    return __builtin_nontemporal_load(reinterpret_cast<const dvec2 *>(p));
+}
+__device__ __forceinline__ void st_stream2(double *p, double a, double b) {
+    dvec2 v;
+    v.x = a;
+    v.y = b;
+    __builtin_nontemporal_store(v, reinterpret_cast<dvec2 *>(p));
+}
+__device__ __forceinline__ void st_stream(double *p, double v) { __builtin_nontemporal_store(v, p); }
+
 template <int M>
 __host__ __device__ constexpr int tri(int p, int q) {  // packed upper triangle, p <= q < M
     return p * M - (p * (p - 1)) / 2 + (q - p);
@@ -62,6 +77,12 @@ __device__ __forceinline__ double div_by_const(double x, double d, double r) {
 // update_dist_from_moments, ParticleDistributions.jl:456-476 / :512-523 (normalised moments in)
 __device__ __forceinline__ void invert_closure(int dist_type, double m0, double m1, double m2, double kmin,
                                                double kmax, double &n, double &th, double &k) {
+#ifdef CLOUDY_ABLATE_INV  // timing experiment only: no divisions
+    n = m0;
+    th = m1;
+    k = m2 + kmin;
+    return;
+#endif
     if (m0 > kEps && m1 > kEps) {
         n = m0;
         const double mean = m1 / m0;
@@ -320,6 +341,7 @@ __device__ __forceinline__ void coal_ints_parcel(const KArgs<N, P> &A, const dou
             }
         }
     }
+#ifndef CLOUDY_ABLATE_PAIR
     // ---- pair terms: Q - R for j < k, -R for j > k, S_1(full products) - R for j == k, with the
     //      products common to Q and R (and to S_1 and R) cancelled analytically:
     //      Q_0 = R_0;  Q_1 = R_1 + sum v1_b Mk_b;  Q_2 = R_2 + 2 sum v1_b Mk_{b+1} + sum v2_b Mk_b
@@ -377,6 +399,7 @@ __device__ __forceinline__ void coal_ints_parcel(const KArgs<N, P> &A, const dou
         }
     }
 
+#endif
 }
 
 // load one parcel (moments -> normalise -> invert, or parameters as given)
@@ -388,11 +411,11 @@ __device__ __forceinline__ bool load_parcel(const KArgs<N, P> &A, size_t i, size
 #pragma unroll
         for (int m = 0; m < N; ++m) {
             const int off = A.off[m];
-            double m0 = in[(size_t)(off + 0) * ld + i];
-            double m1 = in[(size_t)(off + 1) * ld + i];
+            double m0 = ld_stream(in + (size_t)(off + 0) * ld + i);
+            double m1 = ld_stream(in + (size_t)(off + 1) * ld + i);
             double m2 = 0.0;
             const bool three = A.np[m] == 3;
-            if (three) m2 = in[(size_t)(off + 2) * ld + i];
+            if (three) m2 = ld_stream(in + (size_t)(off + 2) * ld + i);
             if (A.rainshaft) {  // rainshaft_helpers.jl:52
                 m0 = m0 < 0.0 ? 0.0 : m0;
                 m1 = m1 < 0.0 ? 0.0 : m1;
@@ -409,9 +432,9 @@ __device__ __forceinline__ bool load_parcel(const KArgs<N, P> &A, size_t i, size
     } else {
 #pragma unroll
         for (int m = 0; m < N; ++m) {
-            nn[m] = in[(size_t)(3 * m + 0) * ld + i];
-            th[m] = in[(size_t)(3 * m + 1) * ld + i];
-            kk[m] = (A.dist_type[m] == DIST_GAMMA) ? in[(size_t)(3 * m + 2) * ld + i] : 1.0;
+            nn[m] = ld_stream(in + (size_t)(3 * m + 0) * ld + i);
+            th[m] = ld_stream(in + (size_t)(3 * m + 1) * ld + i);
+            kk[m] = (A.dist_type[m] == DIST_GAMMA) ? ld_stream(in + (size_t)(3 * m + 2) * ld + i) : 1.0;
         }
         all_small = false;
     }
@@ -433,9 +456,62 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             const int off = A.off[k];
-            out[(size_t)(off + 0) * ld + i] = skip ? 0.0 : acc[k][0] * A.out_scale[3 * k + 0];
-            out[(size_t)(off + 1) * ld + i] = skip ? 0.0 : acc[k][1] * A.out_scale[3 * k + 1];
-            if (A.np[k] == 3) out[(size_t)(off + 2) * ld + i] = skip ? 0.0 : acc[k][2] * A.out_scale[3 * k + 2];
+            st_stream(out + (size_t)(off + 0) * ld + i, skip ? 0.0 : acc[k][0] * A.out_scale[3 * k + 0]);
+            st_stream(out + (size_t)(off + 1) * ld + i, skip ? 0.0 : acc[k][1] * A.out_scale[3 * k + 1]);
+            if (A.np[k] == 3) st_stream(out + (size_t)(off + 2) * ld + i, skip ? 0.0 : acc[k][2] * A.out_scale[3 * k + 2]);
+        }
+    }
+}
+
+// ALLINF with two parcels per lane: every plane is read and written as one 16-byte access per lane (1 KiB per
+// wave instruction).  Requires 16-byte aligned planes: base pointers 16-B aligned and ld even (checked by the
+// host, which otherwise launches the one-parcel kernel).  The two parcels are independent instruction streams,
+// which also gives the scheduler ILP across the division sequences of the closure inversion.
+template <int N, int P>
+__global__ void __launch_bounds__(kBlock)
+    coal_rhs_allinf2_kernel(const KArgs<N, P> A, size_t n, size_t ld, const double *__restrict__ in,
+                            double *__restrict__ out) {
+    const size_t i = ((size_t)blockIdx.x * kBlock + threadIdx.x) * 2;
+    if (i >= n) return;
+    const bool pair = (i + 1 < n);
+    double nn[2][N], th[2][N], kk[2][N], acc[2][N][3];
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        const int off = A.off[m];
+        const bool three = A.np[m] == 3;
+        dvec2 v0, v1, v2 = {0.0, 0.0};
+        if (pair) {
+            v0 = ld_stream2(in + (size_t)(off + 0) * ld + i);
+            v1 = ld_stream2(in + (size_t)(off + 1) * ld + i);
+            if (three) v2 = ld_stream2(in + (size_t)(off + 2) * ld + i);
+        } else {
+            v0 = dvec2{in[(size_t)(off + 0) * ld + i], 0.0};
+            v1 = dvec2{in[(size_t)(off + 1) * ld + i], 0.0};
+            if (three) v2 = dvec2{in[(size_t)(off + 2) * ld + i], 0.0};
+        }
+        const double m0[2] = {v0.x, v0.y}, m1[2] = {v1.x, v1.y}, m2[2] = {v2.x, v2.y};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const double a0 = div_by_const(m0[e], A.norm[3 * m + 0], A.inv_norm[3 * m + 0]);
+            const double a1 = div_by_const(m1[e], A.norm[3 * m + 1], A.inv_norm[3 * m + 1]);
+            const double a2 = div_by_const(m2[e], A.norm[3 * m + 2], A.inv_norm[3 * m + 2]);
+            invert_closure(A.dist_type[m], a0, a1, a2, A.kmin, A.kmax, nn[e][m], th[e][m], kk[e][m]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) coal_ints_parcel<N, P, MODE_ALLINF>(A, nullptr, nn[e], th[e], kk[e], acc[e]);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int off = A.off[k];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            if (m == 2 && A.np[k] != 3) continue;
+            const double s = A.out_scale[3 * k + m];
+            double *dst = out + (size_t)(off + m) * ld + i;
+            if (pair)
+                st_stream2(dst, acc[0][k][m] * s, acc[1][k][m] * s);
+            else
+                *dst = acc[0][k][m] * s;
         }
     }
 }
@@ -522,9 +598,9 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             const int off = A.off[k];
-            out[(size_t)(off + 0) * ld + i] = skip ? 0.0 : acc[k][0] * A.out_scale[3 * k + 0];
-            out[(size_t)(off + 1) * ld + i] = skip ? 0.0 : acc[k][1] * A.out_scale[3 * k + 1];
-            if (A.np[k] == 3) out[(size_t)(off + 2) * ld + i] = skip ? 0.0 : acc[k][2] * A.out_scale[3 * k + 2];
+            st_stream(out + (size_t)(off + 0) * ld + i, skip ? 0.0 : acc[k][0] * A.out_scale[3 * k + 0]);
+            st_stream(out + (size_t)(off + 1) * ld + i, skip ? 0.0 : acc[k][1] * A.out_scale[3 * k + 1]);
+            if (A.np[k] == 3) st_stream(out + (size_t)(off + 2) * ld + i, skip ? 0.0 : acc[k][2] * A.out_scale[3 * k + 2]);
         }
     }
 }

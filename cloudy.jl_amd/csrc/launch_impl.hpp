@@ -49,7 +49,12 @@ hipError_t launch_np(const HostPlan &h, const LaunchReq &r) {
     switch (r.op) {
     case OP_COAL: {
         const unsigned g = grid_for(r.n, heavy);
-        if (h.mode == MODE_ALLINF)
+        const bool aligned16 = ((reinterpret_cast<uintptr_t>(r.in) | reinterpret_cast<uintptr_t>(r.out)) & 15u) == 0 &&
+                               (r.ld % 2 == 0);
+        if (h.mode == MODE_ALLINF && r.input_kind == IN_MOMENTS && !r.rainshaft && aligned16 && !h.force_ppl1)
+            hipLaunchKernelGGL((coal_rhs_allinf2_kernel<N, P>), dim3(grid_for((r.n + 1) / 2, false)), dim3(kBlock), 0,
+                               r.stream, A, r.n, r.ld, r.in, r.out);
+        else if (h.mode == MODE_ALLINF)
             hipLaunchKernelGGL((coal_rhs_kernel<N, P, MODE_ALLINF>), dim3(g), dim3(kBlock), 0, r.stream, A, h.nodes_dev,
                                r.n, r.ld, r.in, r.out);
         else if (h.mode == MODE_FIXED)
