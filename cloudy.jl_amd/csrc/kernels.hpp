@@ -115,59 +115,6 @@ __device__ __forceinline__ void moment_row(double n, double th, double k, int n_
         if (q >= n_mom_max) Mk[q] = 0.0;
 }
 
-// moment_source_helper on the plan's fixed log-uniform Simpson grid for all (p1 <= p2) at once.
-//   msh[p1][p2] = n M_p2 / Gamma(k) * sum_j (w_j dx) x_j^p1 t_j^k e^{-t_j} P(k + p2, z_j),
-//   t_j = x_j / theta, z_j = (x_t - x_j) / theta
-// which is ParticleDistributions.jl:589-612 (Gamma) / :567-587 (Exponential, k = 1) regrouped so that
-// one incomplete-gamma evaluation per node (at the top order) serves every p2 through the stable
-// downward recurrence P(a-1, z) = P(a, z) + z^(a-1) e^-z / Gamma(a).
-template <int P>
-__device__ __forceinline__ void msh_fixed_grid(const double *__restrict__ nd, int nb, double n, double th, double k,
-                                               bool is_gamma, const double (&Mk)[P + 2],
-                                               double (&msh)[(P + 2) * (P + 3) / 2]) {
-    constexpr int M = P + 2;
-    constexpr int T = M * (M + 1) / 2;
-    double acc[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) acc[t] = 0.0;
-    const double inv_th = 1.0 / th, lnth = log(th);
-    const double a_top = k + double(M - 1);
-    const double lg_top = lgamma(a_top + 1.0);
-#pragma unroll 1
-    for (int j = 0; j < nb; ++j) {
-        const double x = nd[kNodeStride * j + 0];
-        const double lx = nd[kNodeStride * j + 1];
-        const double xmx = nd[kNodeStride * j + 2];
-        const double lxmx = nd[kNodeStride * j + 3];
-        const double wdx = nd[kNodeStride * j + 4];
-        const double t = x * inv_th, z = xmx * inv_th;
-        const double h0 = wdx * exp(fma(k, lx - lnth, -t));
-        const double E0 = exp(fma(a_top, lxmx - lnth, -z) - lg_top);
-        double Pz[M];
-        Pz[M - 1] = inc_gamma_p_from_E(a_top, z, E0, nullptr);
-        const double invz = 1.0 / z;
-        double E = E0, a = a_top;
-#pragma unroll
-        for (int p2 = M - 2; p2 >= 0; --p2) {
-            E *= a * invz;
-            a -= 1.0;
-            Pz[p2] = Pz[p2 + 1] + E;
-        }
-        double h = h0;
-#pragma unroll
-        for (int p1 = 0; p1 < M; ++p1) {
-#pragma unroll
-            for (int p2 = p1; p2 < M; ++p2) acc[tri<M>(p1, p2)] = fma(h, Pz[p2], acc[tri<M>(p1, p2)]);
-            h *= x;
-        }
-    }
-    const double pref = is_gamma ? n / tgamma(k) : n;
-#pragma unroll
-    for (int p1 = 0; p1 < M; ++p1)
-#pragma unroll
-        for (int p2 = p1; p2 < M; ++p2) msh[tri<M>(p1, p2)] = pref * Mk[p2] * acc[tri<M>(p1, p2)];
-}
-
 // Simpson end weights of integrate_SimpsonEvenFast (ParticleDistributions.jl:698-710) as a weight per node
 __host__ __device__ inline double simpson_weight(int j /*1-based*/, int n_bins) {
     const int e = n_bins + 1;
@@ -179,33 +126,141 @@ __host__ __device__ inline double simpson_weight(int j /*1-based*/, int n_bins) 
     return w;
 }
 
-// Same integral on a per-parcel grid (MovingThreshold: the threshold, hence the grid, depends on the parcel).
-template <int P>
-__device__ __forceinline__ void msh_moving_grid(double xt, int nbpl, double n, double th, double k, bool is_gamma,
-                                                const double (&Mk)[P + 2], double (&msh)[(P + 2) * (P + 3) / 2]) {
+// One Simpson node of the log-uniform grid of moment_source_helper (ParticleDistributions.jl:604-610).
+struct SimpsonNode {
+    double x, lx, xmx, lxmx, wdx;  // x_j, ln x_j, x_t - x_j, ln(x_t - x_j), w_j * dx
+};
+// FixedThreshold: the grid depends on the plan only -> node table built on the host, read at uniform addresses.
+struct FixedGrid {
+    const double *__restrict__ nd;
+    int nb;
+    __device__ __forceinline__ int n_bins() const { return nb; }
+    __device__ __forceinline__ double node_x(int j) const { return nd[kNodeStride * j]; }
+    __device__ __forceinline__ SimpsonNode node(int j, bool /*late*/) const {
+        return SimpsonNode{nd[kNodeStride * j + 0], nd[kNodeStride * j + 1], nd[kNodeStride * j + 2],
+                           nd[kNodeStride * j + 3], nd[kNodeStride * j + 4]};
+    }
+};
+// MovingThreshold: the threshold, hence the grid, is per parcel (computed with the reference's expressions).
+struct MovingGrid {
+    double xt, x_min, dx;
+    int nb;
+    __device__ __forceinline__ MovingGrid(double xt_, int nbpl) : xt(xt_) {
+        const double x_lb = fmin(1e-5, 1e-5 * xt_);
+        nb = (int)floor(double(nbpl) * log10(xt_ / x_lb));
+        x_min = log(x_lb);
+        dx = (log(xt_) - x_min) / double(nb);
+    }
+    __device__ __forceinline__ int n_bins() const { return nb; }
+    __device__ __forceinline__ double node_x(int j) const { return exp(x_min + double(j) * dx); }
+    __device__ __forceinline__ SimpsonNode node(int j, bool late) const {
+        SimpsonNode s;
+        s.lx = x_min + double(j) * dx;  // logx(x_min, j+1, dx)
+        s.x = exp(s.lx);
+        s.xmx = xt - s.x;
+        s.lxmx = late ? log(s.xmx) : 0.0;
+        s.wdx = simpson_weight(j + 1, nb) * dx;
+        return s;
+    }
+};
+
+constexpr int kEarlyTerms = 10;  // Taylor terms of the early-node expansion (error < 1e-16 at t B <= 0.1)
+
+// moment_source_helper for all (p1 <= p2) of one mode in ONE pass over its Simpson grid:
+//   msh[p1][p2] = n M_p2 / Gamma(k) * sum_j (w_j dx) x_j^p1 t_j^k e^{-t_j} P(k + p2, z_j),
+//   t_j = x_j / theta,  z_j = (x_t - x_j) / theta = z0 - t_j,  z0 = x_t / theta
+// which is ParticleDistributions.jl:589-612 (Gamma) / :567-587 (Exponential, k = 1) regrouped.
+//
+// Late nodes: one incomplete-gamma evaluation at the top order a_top = k + M - 1 per node, every lower order
+// by the stable downward recurrence P(a-1, z) = P(a, z) + z^(a-1) e^-z / Gamma(a).
+//
+// Early nodes (t_j (1 + (a_top-1)/z0) <= 0.1; the log grid puts 30-50 of the 75 nodes there): P(a, z0 - t) is
+// expanded about z0,  P(a, z0 - t) = P(a, z0) - g_a sum_n c_n t^(n+1)/(n+1),  g_a = z0^(a-1) e^-z0 / Gamma(a),
+// c_{n+1} = ((z0 - a + 1 + n) c_n - c_{n-1}) / (z0 (n+1))  (Taylor coefficients of e^u (1 - u/z0)^(a-1)),
+// so the nodes only feed the power sums S_q = sum_j (w_j dx) t_j^(k+q) e^{-t_j} (one exp per node), and the
+// incomplete gamma is evaluated once, at z0, for the whole group.
+template <int P, typename Grid>
+__device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double n, double th, double k, bool is_gamma,
+                                         const double (&Mk)[P + 2], double (&msh)[(P + 2) * (P + 3) / 2]) {
     constexpr int M = P + 2;
     constexpr int T = M * (M + 1) / 2;
-    double acc[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) acc[t] = 0.0;
-    // ParticleDistributions.jl:604-607
-    const double x_lb = fmin(1e-5, 1e-5 * xt);
-    const int nb = (int)floor(double(nbpl) * log10(xt / x_lb));
-    const double x_min = log(x_lb);
-    const double dx = (log(xt) - x_min) / double(nb);
+    constexpr int NS = M + kEarlyTerms;
+    const int nb = grid.n_bins();
     const double inv_th = 1.0 / th, lnth = log(th);
     const double a_top = k + double(M - 1);
     const double lg_top = lgamma(a_top + 1.0);
+    const double z0 = xt * inv_th;
+    double acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = 0.0;
+
+    // ---- early nodes: power sums only
+    const double x_early = 0.1 * xt / (z0 + (a_top - 1.0));
+    int j = 0;
+#ifndef CLOUDY_NO_EARLY_NODES
+    {
+        double S[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) S[q] = 0.0;
 #pragma unroll 1
-    for (int j = 1; j <= nb; ++j) {
-        const double lx = x_min + double(j - 1) * dx;
-        const double x = exp(lx);
-        const double xmx = xt - x;
-        const double wdx = simpson_weight(j, nb) * dx;
-        const double t = x * inv_th, z = xmx * inv_th;
+        for (; j < nb; ++j) {
+            if (!(grid.node_x(j) <= x_early)) break;
+            const SimpsonNode nd = grid.node(j, false);
+            const double t = nd.x * inv_th;
+            double e = nd.wdx * exp(fma(k, nd.lx - lnth, -t));
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                S[q] += e;
+                e *= t;
+            }
+        }
+        if (j > 0) {
+            // P(a, z0) and g_a for the M orders a = k + p2 (downward from a_top)
+            const double invz0 = 1.0 / z0;
+            double E = exp(fma(a_top, log(xt) - lnth, -z0) - lg_top);  // E(a_top, z0) = z0^a e^-z0 / Gamma(a+1)
+            double Pv = inc_gamma_p_from_E(a_top, z0, E, nullptr);
+            double a = a_top;
+            double thp[M];  // theta^p1
+            thp[0] = 1.0;
+#pragma unroll
+            for (int p1 = 1; p1 < M; ++p1) thp[p1] = thp[p1 - 1] * th;
+#pragma unroll
+            for (int p2 = M - 1; p2 >= 0; --p2) {
+                // here: a = k + p2, Pv = P(a, z0), E = E(a, z0)
+                const double g = E * a * invz0;  // E(a-1, z0) = z0^(a-1) e^-z0 / Gamma(a) = dP/dz at z0
+                // G_p1 = sum_n c_n/(n+1) S[p1 + n + 1]
+                double G[M];
+#pragma unroll
+                for (int p1 = 0; p1 < M; ++p1) G[p1] = 0.0;
+                double cm = 0.0, c = 1.0;
+#pragma unroll
+                for (int nn2 = 0; nn2 < kEarlyTerms; ++nn2) {
+                    const double w = c * (1.0 / double(nn2 + 1));
+#pragma unroll
+                    for (int p1 = 0; p1 <= p2; ++p1) G[p1] = fma(w, S[p1 + nn2 + 1], G[p1]);
+                    const double cn = ((z0 - a + 1.0 + double(nn2)) * c - cm) * (invz0 * (1.0 / double(nn2 + 1)));
+                    cm = c;
+                    c = cn;
+                }
+#pragma unroll
+                for (int p1 = 0; p1 <= p2; ++p1)
+                    acc[tri<M>(p1, p2)] = thp[p1] * fma(Pv, S[p1], -(g * G[p1]));
+                // step down one order
+                Pv += g;
+                E = g;
+                a -= 1.0;
+            }
+        }
+    }
+#endif
+    // ---- late nodes: one incomplete-gamma evaluation each
+#pragma unroll 1
+    for (; j < nb; ++j) {
+        const SimpsonNode nd = grid.node(j, true);
+        const double t = nd.x * inv_th, z = nd.xmx * inv_th;
         if (!(z > 0.0)) continue;  // P(a, z <= 0) = 0
-        const double h0 = wdx * exp(fma(k, lx - lnth, -t));
-        const double E0 = exp(fma(a_top, log(xmx) - lnth, -z) - lg_top);
+        const double h0 = nd.wdx * exp(fma(k, nd.lx - lnth, -t));
+        const double E0 = exp(fma(a_top, nd.lxmx - lnth, -z) - lg_top);
         double Pz[M];
         Pz[M - 1] = inc_gamma_p_from_E(a_top, z, E0, nullptr);
         const double invz = 1.0 / z;
@@ -221,7 +276,7 @@ __device__ __forceinline__ void msh_moving_grid(double xt, int nbpl, double n, d
         for (int p1 = 0; p1 < M; ++p1) {
 #pragma unroll
             for (int p2 = p1; p2 < M; ++p2) acc[tri<M>(p1, p2)] = fma(h, Pz[p2], acc[tri<M>(p1, p2)]);
-            h *= x;
+            h *= nd.x;
         }
     }
     const double pref = is_gamma ? n / tgamma(k) : n;
@@ -309,15 +364,16 @@ __device__ __forceinline__ void coal_ints_parcel(const KArgs<N, P> &A, const dou
             if (k < N - 1 && A.finite[k]) {  // wave-uniform
                 thresholded = true;
                 if (nn[k] > 0.0)
-                    msh_fixed_grid<P>(nodes + (size_t)A.node_off[k] * kNodeStride, A.n_bins[k], nn[k], th[k], kk[k],
-                                      A.dist_type[k] == DIST_GAMMA, Mm[k], msh);
+                    msh_grid<P>(FixedGrid{nodes + (size_t)A.node_off[k] * kNodeStride, A.n_bins[k]}, A.thr[k], nn[k], th[k],
+                                kk[k], A.dist_type[k] == DIST_GAMMA, Mm[k], msh);
             }
         } else if (MODE == MODE_MOVING) {
             if (k < N - 1) {
                 const bool is_gamma = A.dist_type[k] == DIST_GAMMA;
                 const double xt = moving_threshold(is_gamma, th[k], kk[k], A.thr[k]);
                 thresholded = !(xt == INFINITY);
-                if (thresholded && nn[k] > 0.0) msh_moving_grid<P>(xt, A.nbpl, nn[k], th[k], kk[k], is_gamma, Mm[k], msh);
+                if (thresholded && nn[k] > 0.0)
+                    msh_grid<P>(MovingGrid(xt, A.nbpl), xt, nn[k], th[k], kk[k], is_gamma, Mm[k], msh);
             }
         }
         // without a threshold D is non-zero only where M_p M_q < eps: impossible when every moment >= 2^-26
@@ -654,14 +710,15 @@ __global__ void __launch_bounds__(kBlock)
                     thresholded = true;
                     xt = A.thr[k];
                     if (nn[k] > 0.0)
-                        msh_fixed_grid<P>(nodes + (size_t)A.node_off[k] * kNodeStride, A.n_bins[k], nn[k], th[k],
-                                          kk[k], is_gamma, Mk, msh);
+                        msh_grid<P>(FixedGrid{nodes + (size_t)A.node_off[k] * kNodeStride, A.n_bins[k]}, A.thr[k], nn[k],
+                                    th[k], kk[k], is_gamma, Mk, msh);
                 }
             } else if (MODE == MODE_MOVING) {
                 if (k < N - 1) {
                     xt = moving_threshold(is_gamma, th[k], kk[k], A.thr[k]);
                     thresholded = !(xt == INFINITY);
-                    if (thresholded && nn[k] > 0.0) msh_moving_grid<P>(xt, A.nbpl, nn[k], th[k], kk[k], is_gamma, Mk, msh);
+                    if (thresholded && nn[k] > 0.0)
+                        msh_grid<P>(MovingGrid(xt, A.nbpl), xt, nn[k], th[k], kk[k], is_gamma, Mk, msh);
                 }
             }
             if (thr_out) thr_out[(size_t)k * ld + i] = xt;
