@@ -260,6 +260,30 @@ def main():
             "mass_rate_residual": abs(v["mass_rate_sum"]) / max(v["mass_rate_gross"], 1e-300) if rank == 0 else None,
         }
 
+    if not args.no_variants and args.workload == "cfg3a":
+        # fused on-device SSPRK33 (cloudy_ssprk33_steps): 3 RHS evaluations per step, state in registers
+        import ctypes as C
+
+        wl = res["wl"]
+        plan = res["plan"]
+        u = pkg.DeviceArray.from_numpy(wl["mom"])
+        L = pkg.lib()
+        n_steps, dt = 4, 1e-3
+        pkg._lib.check(L.cloudy_ssprk33_steps(plan.handle, n_local, n_local, u.ptr, u.ptr, C.c_double(dt), n_steps, None))
+        pkg._lib.check(L.cloudy_stream_synchronize(None))
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            pkg._lib.check(L.cloudy_ssprk33_steps(plan.handle, n_local, n_local, u.ptr, u.ptr, C.c_double(dt), n_steps, None))
+        pkg._lib.check(L.cloudy_stream_synchronize(None))
+        dts = (time.perf_counter() - t0) / reps
+        variants["cfg3a_fused_ssprk33"] = {
+            "workload": f"cloudy_ssprk33_steps: {n_steps} SSPRK33 steps per call (3 RHS evaluations each) with the state "
+                        "in registers; one read + one write of the state per call",
+            "value": 3 * n_steps * n_local * world / dts, "unit": "parcel-RHS/s", "ms_per_call": 1e3 * dts,
+            "hbm_GBs": bytes_per_eval * n_local / dts / 1e9,
+        }
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = _cpu_baseline(args.workload)

@@ -61,3 +61,17 @@ def make_box_model_rhs(coal_type, threshold_style=None):
         return rhs_coal(coal_type, dm, m, par, ts)
 
     return rhs
+
+
+def solve_ssprk33(par, u, dt, n_steps, out=None, stream=None):
+    """solve(ODEProblem(rhs, u, tspan, par), SSPRK33(), dt = dt) for n_steps fixed steps, on the device
+    (cloudy_ssprk33_steps): the final state only (the examples' `sol.u[end]`).  `u` is advanced in place unless
+    `out` is given."""
+    plan = _plan_for(par)
+    uptr, planes, n, ld = as_device(u)
+    o = out if out is not None else u
+    optr, oplanes, on, old = as_device(o)
+    if planes != plan.nmom or oplanes != plan.nmom or on != n or old != ld:
+        raise ValueError(f"u and out must both be ({plan.nmom}, n) with equal leading dimension")
+    _lib.check(_lib.lib().cloudy_ssprk33_steps(plan.handle, n, ld, uptr, optr, float(dt), int(n_steps), stream))
+    return o

@@ -30,7 +30,7 @@ struct HostPlan {
     double *partial_dev = nullptr;                      // moment_sums workspace
 };
 
-enum Op { OP_COAL = 0, OP_UPDATE_DIST = 1, OP_FINITE_2D = 2, OP_SEDI = 3 };
+enum Op { OP_COAL = 0, OP_UPDATE_DIST = 1, OP_FINITE_2D = 2, OP_SEDI = 3, OP_SSPRK33 = 4 };
 
 struct LaunchReq {
     int op;
@@ -42,6 +42,8 @@ struct LaunchReq {
     double *out;      // OP_COAL: dmom; OP_UPDATE_DIST: params; OP_FINITE_2D: F (may be null); OP_SEDI: flux
     double *out2;     // OP_FINITE_2D: thresholds (may be null)
     hipStream_t stream;
+    double dt = 0.0;  // OP_SSPRK33
+    int n_steps = 0;  // OP_SSPRK33
 };
 
 // one per instantiation unit (inst_n1.hip ... inst_n4.hip)

@@ -662,6 +662,116 @@ __global__ void __launch_bounds__(kBlock)
     }
 }
 
+// ---- on-device explicit time stepping -------------------------------------------------------
+// The reference drivers integrate du/dt = rhs!(u) with SSPRK33 and a fixed dt (e.g. box_single_gamma.jl:35-36,
+// 3 RHS evaluations per step, each a full pass over the state in OrdinaryDiffEq).  Here a lane keeps its parcel's
+// moments in registers across all stages and steps: HBM traffic is one read and one write of the state per CALL
+// (n_steps steps), and there are no per-stage launches.
+template <int N, int P, int MODE>
+__device__ __forceinline__ void rhs_physical(const KArgs<N, P> &A, const double *__restrict__ nodes,
+                                             const double (&u)[N][3], double (&f)[N][3]) {
+    double nn[N], th[N], kk[N], acc[N][3];
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        const double m0 = div_by_const(u[m][0], A.norm[3 * m + 0], A.inv_norm[3 * m + 0]);
+        const double m1 = div_by_const(u[m][1], A.norm[3 * m + 1], A.inv_norm[3 * m + 1]);
+        const double m2 = div_by_const(u[m][2], A.norm[3 * m + 2], A.inv_norm[3 * m + 2]);
+        invert_closure(A.dist_type[m], m0, m1, m2, A.kmin, A.kmax, nn[m], th[m], kk[m]);
+    }
+    coal_ints_parcel<N, P, MODE>(A, nodes, nn, th, kk, acc);
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        f[m][0] = acc[m][0] * A.out_scale[3 * m + 0];
+        f[m][1] = acc[m][1] * A.out_scale[3 * m + 1];
+        f[m][2] = (A.np[m] == 3) ? acc[m][2] * A.out_scale[3 * m + 2] : 0.0;
+    }
+}
+
+template <int N, int P, int MODE>
+__global__ void __launch_bounds__(kBlock)
+    ssprk33_kernel(const KArgs<N, P> A, const double *__restrict__ nodes, size_t n, size_t ld,
+                   const double *u_in, double *u_out, double dt, int n_steps) {
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (MODE != MODE_ALLINF) {
+        // regime sort of the workgroup's parcels on the initial state (see coal_rhs_sorted_kernel)
+        __shared__ unsigned int sh_key[kBlock];
+        __shared__ unsigned short sh_perm[kBlock];
+        const int t = threadIdx.x;
+        unsigned int key = 0xFFFFFFFFu;
+        if (i < n) {
+            double nn[N], th[N], kk[N];
+            load_parcel<N, P>(A, i, ld, u_in, nn, th, kk);
+            int f = 0;
+            if (MODE == MODE_FIXED) {
+#pragma unroll
+                for (int m = N - 2; m >= 0; --m)
+                    if (A.finite[m]) f = m;
+            }
+            double nf = nn[0], thf = th[0], kf = kk[0], xtf = A.thr[0];
+#pragma unroll
+            for (int m = 1; m < N; ++m)
+                if (m == f) {
+                    nf = nn[m];
+                    thf = th[m];
+                    kf = kk[m];
+                    xtf = A.thr[m];
+                }
+            const float r = (MODE == MODE_FIXED) ? (float)((xtf / thf) / (kf + double(P + 2))) : (float)kf;
+            if (nf > 0.0 && r == r) key = __float_as_uint(fmaxf(r, 0.0f));
+        }
+        sh_key[t] = key;
+        __syncthreads();
+        int rank = 0;
+#pragma unroll 8
+        for (int s2 = 0; s2 < kBlock; ++s2) {
+            const unsigned int ks = sh_key[s2];
+            rank += (ks < key || (ks == key && s2 < t)) ? 1 : 0;
+        }
+        sh_perm[rank] = (unsigned short)t;
+        __syncthreads();
+        i = (size_t)blockIdx.x * kBlock + sh_perm[t];
+    }
+    if (i >= n) return;
+    double u[N][3], up[N][3], f[N][3];
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        const int off = A.off[m];
+        u[m][0] = u_in[(size_t)(off + 0) * ld + i];
+        u[m][1] = u_in[(size_t)(off + 1) * ld + i];
+        u[m][2] = (A.np[m] == 3) ? u_in[(size_t)(off + 2) * ld + i] : 0.0;
+    }
+#pragma unroll 1
+    for (int step = 0; step < n_steps; ++step) {
+#pragma unroll
+        for (int m = 0; m < N; ++m)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) up[m][q] = u[m][q];
+#pragma unroll 1
+        for (int stage = 0; stage < 3; ++stage) {
+            rhs_physical<N, P, MODE>(A, nodes, u, f);
+            // OrdinaryDiffEq SSPRK33: u = uprev + dt k;  u = (3 uprev + u + dt k)/4;  u = (uprev + 2u + 2dt k)/3
+#pragma unroll
+            for (int m = 0; m < N; ++m)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    if (stage == 0)
+                        u[m][q] = up[m][q] + dt * f[m][q];
+                    else if (stage == 1)
+                        u[m][q] = (3.0 * up[m][q] + u[m][q] + dt * f[m][q]) * 0.25;  // "/ 4" is exact
+                    else  // "/ 3" as a correctly rounded division
+                        u[m][q] = div_by_const(up[m][q] + 2.0 * u[m][q] + 2.0 * dt * f[m][q], 3.0, 1.0 / 3.0);
+                }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        const int off = A.off[m];
+        u_out[(size_t)(off + 0) * ld + i] = u[m][0];
+        u_out[(size_t)(off + 1) * ld + i] = u[m][1];
+        if (A.np[m] == 3) u_out[(size_t)(off + 2) * ld + i] = u[m][2];
+    }
+}
+
 // ---- diagnostics / the callers either side of the operator ---------------------------------------
 
 template <int N, int P>

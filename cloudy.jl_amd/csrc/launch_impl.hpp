@@ -94,6 +94,19 @@ hipError_t launch_np(const HostPlan &h, const LaunchReq &r) {
                            r.ld, r.in, r.out);
         break;
     }
+    case OP_SSPRK33: {
+        const unsigned g = grid_for(r.n, heavy);
+        if (h.mode == MODE_ALLINF)
+            hipLaunchKernelGGL((ssprk33_kernel<N, P, MODE_ALLINF>), dim3(g), dim3(kBlock), 0, r.stream, A, h.nodes_dev,
+                               r.n, r.ld, r.in, r.out, r.dt, r.n_steps);
+        else if (h.mode == MODE_FIXED)
+            hipLaunchKernelGGL((ssprk33_kernel<N, P, MODE_FIXED>), dim3(g), dim3(kBlock), 0, r.stream, A, h.nodes_dev,
+                               r.n, r.ld, r.in, r.out, r.dt, r.n_steps);
+        else
+            hipLaunchKernelGGL((ssprk33_kernel<N, P, MODE_MOVING>), dim3(g), dim3(kBlock), 0, r.stream, A, h.nodes_dev,
+                               r.n, r.ld, r.in, r.out, r.dt, r.n_steps);
+        break;
+    }
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -22,6 +22,8 @@
  *   cloudy_sedimentation_flux     <- get_sedimentation_flux(pdists, vel)   src/Sources/Sedimentation.jl:22-37
  *   cloudy_rainshaft_sources      <- the per-cell body of make_rainshaft_rhs
  *                                    test/examples/utils/rainshaft_helpers.jl:52-78
+ *   cloudy_ssprk33_steps          <- solve(ODEProblem(rhs, m0, tspan, p), SSPRK33(), dt = p.dt) of the drivers,
+ *                                    test/examples/Analytical/box_single_gamma.jl:35-36 (OrdinaryDiffEq stepping)
  *   cloudy_moment_sums            <- moments_sum diagnostic, test/examples/utils/plotting_helpers.jl:240-252
  *
  * Data layout (all batched calls): moment-major structure-of-arrays, element (q, parcel) at
@@ -114,6 +116,13 @@ int cloudy_coal_rhs(const cloudy_plan *plan, size_t n_parcels, size_t ld, const 
 /* same through host buffers (allocates a staging buffer, copies, synchronises): convenience only */
 int cloudy_coal_rhs_host(const cloudy_plan *plan, size_t n_parcels, size_t ld, const void *mom_host,
                          void *dmom_host);
+
+/* n_steps explicit SSPRK33 steps of du/dt = rhs!(u) with fixed dt, the integrator of every reference driver
+ * (solve(prob, SSPRK33(), dt = ...), test/examples/Analytical/box_single_gamma.jl:35-36), fused around the RHS:
+ * each parcel's moments stay in registers over all stages and steps (one read + one write of the state per call,
+ * no per-stage launches).  u_out_dev may equal u_in_dev. */
+int cloudy_ssprk33_steps(const cloudy_plan *plan, size_t n_parcels, size_t ld, const void *u_in_dev, void *u_out_dev,
+                         double dt, int n_steps, void *stream);
 
 /* inner operator on given distributions: params = 3N planes (n, theta, k) per mode, normalised units
  * (k plane ignored for exponential modes); out = nmom planes, normalised units. */

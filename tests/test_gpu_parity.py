@@ -447,3 +447,71 @@ def test_full_size_properties_1e7(gpu_cloudy):
             lin = outs[0] + outs[1]
             assert np.all(np.abs(lin - d) <= 1e-11 * (np.abs(outs[0]) + np.abs(outs[1]) + 1e-300))
         del m, dm, d
+
+
+def _ssprk33_host(rhs_fn, u, dt, n_steps):
+    """OrdinaryDiffEq's SSPRK33 update formulas with a host-side RHS callable (numpy)."""
+    u = u.copy()
+    for _ in range(n_steps):
+        up = u.copy()
+        k = rhs_fn(u)
+        u = up + dt * k
+        k = rhs_fn(u)
+        u = (3.0 * up + u + dt * k) / 4.0
+        k = rhs_fn(u)
+        u = (up + 2.0 * u + 2.0 * dt * k) / 3.0
+    return u
+
+
+def test_cfg1_single_box_trajectory_ssprk33(gpu_cloudy, oracle):
+    """BASELINE configs[0] / box_single_gamma.jl:15-36: one 0-D box, Gamma(1e8, 1e-10, 1), Golovin b = 5 (order-1
+    tensor), norms (1e6, 1e-9), tspan (0, 120), SSPRK33 with dt = 10.  The fused device integrator against (i) the
+    same scheme driven by the oracle RHS and (ii) by the GPU RHS called stage by stage (the OrdinaryDiffEq pattern)."""
+    cloudy = gpu_cloudy
+    kern = cloudy.CoalescenceTensor(cloudy.LinearKernelFunction(5.0), 1, 1e-6)
+    cd = cloudy.CoalescenceData(kern, (3,), (INF,), bench.NORMS)
+    par = cloudy.ODEParameters((cloudy.GammaPrimitiveParticleDistribution(1e8, 1e-10, 1.0),), cd, (3,), bench.NORMS)
+    u0 = np.tile(np.array([1e8, 1e-2, 2e-12])[:, None], (1, 64))
+    dt, n_steps = 10.0, 12
+    op = oracle.make_params([1], kern.c, (INF,), norms=bench.NORMS)
+    want = _ssprk33_host(lambda u: oracle.rhs_coal_batch(op, u), u0, dt, n_steps)
+    u = dev(cloudy, u0)
+    cloudy.solve_ssprk33(par, u, dt, n_steps)
+    got = u.to_numpy()
+    assert np.all(got == got[:, :1])
+    assert np.allclose(got, want, rtol=1e-12, atol=0)
+    staged = _ssprk33_host(lambda x: run_rhs(cloudy, par, x), u0, dt, n_steps)
+    assert np.allclose(got, staged, rtol=1e-13, atol=0)
+    # Golovin: M1 is conserved and M0(t) = M0 exp(-b M1 t) (dM0/dt = -b M0 M1); SSPRK33 is 3rd order in dt
+    assert np.allclose(got[1], 1e-2, rtol=1e-13)
+    assert got[0, 0] == pytest.approx(1e8 * math.exp(-5.0 * 1e-2 * 120.0), rel=6e-2)  # dt*b*M1 = 0.5 per step
+    # out-of-place call leaves the input untouched and n_steps = 0 is the identity
+    u_in, u_out = dev(cloudy, u0), cloudy.DeviceArray.zeros(3, 64)
+    cloudy.solve_ssprk33(par, u_in, dt, 0, out=u_out)
+    assert np.array_equal(u_out.to_numpy(), u0) and np.array_equal(u_in.to_numpy(), u0)
+
+
+@pytest.mark.parametrize("name,tol", [("cfg3a", TOL_POLY), ("cfg3b", TOL_QUAD)])
+def test_fused_ssprk33_batch_vs_oracle_stepping(gpu_cloudy, oracle, name, tol):
+    """box_gamma_mixture_long.jl:37-46 pattern on a batch of different boxes, 4 steps.  The synthetic parcels span
+    number concentrations up to 1e9 m^-3, so the explicit scheme needs dt = 1e-3 s to stay in its stability region
+    (outside it both integrations blow up and are not comparable)."""
+    cloudy = gpu_cloudy
+    n = 400
+    wl = bench.make_workload(name, n, seed=31)
+    op = bench.oracle_params(name)
+    dt, n_steps = 1e-3, 4
+    want = _ssprk33_host(lambda u: oracle.rhs_coal_batch(op, u), wl["mom"], dt, n_steps)
+    u = dev(cloudy, wl["mom"])
+    cloudy.solve_ssprk33(wl["par"], u, dt, n_steps)
+    got = u.to_numpy()
+    # regular parcels: finite and still within a factor 10 of their initial state (degenerate parcels with
+    # k = eps have tendencies ~1e30 and leave any stability region)
+    with np.errstate(all="ignore"):
+        ok = np.isfinite(want).all(axis=0) & (np.abs(want[:3]) <= 10 * np.abs(wl["mom"][:3]) + 1e-300).all(axis=0)
+    assert ok.sum() > 0.9 * n
+    # compare on the size of each moment's own trajectory (|u0| + |u|): the state is O(1) of its initial value
+    ref = np.abs(wl["mom"]) + np.abs(want)
+    err = np.abs(got - want)[:, ok] / np.maximum(ref[:, ok], 1e-300)
+    assert err.max() < max(1e3 * tol, 1e-9), err.max()
+    print(f"{name}: fused SSPRK33 vs oracle stepping, max rel err {err.max():.2e}")
