@@ -284,6 +284,22 @@ def main():
             "hbm_GBs": bytes_per_eval * n_local / dts / 1e9,
         }
 
+    if not args.no_variants and args.workload == "cfg3a":
+        # CLOUDY_F32 plan: float planes in HBM (48 B per evaluation), fp64 arithmetic in registers
+        wl = res["wl"]
+        plan32 = wl["coal_data"].plan(wl["dist_types"], dtype=1)
+        m32 = pkg.DeviceArray.from_numpy(wl["mom"].astype(np.float32))
+        dm32 = pkg.DeviceArray.zeros(nmom, n_local, np.float32)
+        for _ in range(3):
+            pkg._lib.check(pkg.lib().cloudy_coal_rhs(plan32.handle, n_local, n_local, m32.ptr, dm32.ptr, None))
+        ms32 = _event_ms(pkg, plan32, m32, dm32, args.steps)
+        variants["cfg3a_f32_planes"] = {
+            "workload": "cfg3a with CLOUDY_F32 planes (float in HBM, fp64 arithmetic): BASELINE configs[4] fp32 path",
+            "value": n_local * world / (ms32 * 1e-3), "unit": "parcel-RHS/s", "kernel_ms": ms32,
+            "hbm_GBs": 2 * nmom * 4 * n_local / (ms32 * 1e-3) / 1e9,
+        }
+        del m32, dm32
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = _cpu_baseline(args.workload)

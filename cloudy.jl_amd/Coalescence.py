@@ -15,7 +15,7 @@ class Plan:
     """Owner of a cloudy_plan handle (include/cloudy_hip.h): one immutable constant block per configuration."""
 
     def __init__(self, dist_types, kernel_c, dist_thresholds, norms, threshold_style, k_range=(EPS, 10.0),
-                 n_bins_per_log_unit=15, vel=(), kernel_is_normalized=False, device=-1):
+                 n_bins_per_log_unit=15, vel=(), kernel_is_normalized=False, device=-1, dtype=0):
         L = _lib.lib()
         d = _lib.PlanDesc()
         L.cloudy_plan_desc_init(C.byref(d))
@@ -44,6 +44,8 @@ class Plan:
         for i in range(v.shape[0]):
             d.vel[2 * i], d.vel[2 * i + 1] = v[i, 0], v[i, 1]
         d.device = int(device)
+        d.dtype = int(dtype)  # CLOUDY_F64 = 0; CLOUDY_F32 = 1: float planes in HBM, fp64 arithmetic in registers
+        self.dtype = int(dtype)
         h = C.c_void_p()
         _lib.check(L.cloudy_plan_create(C.byref(d), C.byref(h)))
         self.handle = h
@@ -117,16 +119,16 @@ class CoalescenceData:
             self.dist_thresholds = self.dist_thresholds_in
         self._plans = {}
 
-    def plan(self, dist_types, k_range=(EPS, 10.0), vel=()):
+    def plan(self, dist_types, k_range=(EPS, 10.0), vel=(), dtype=0):
         """The device plan for this data and the closure types of `pdists` (built once, cached)."""
         dist_types = tuple(int(t) for t in dist_types)
         for t, npm in zip(dist_types, self.NProgMoms):
             if (3 if t == 1 else 2) != npm:
                 raise ValueError("NProgMoms does not match nparams of the distributions")
-        key = (dist_types, tuple(k_range), tuple(map(tuple, np.asarray(vel, dtype=float).reshape(-1, 2))))
+        key = (dist_types, tuple(k_range), tuple(map(tuple, np.asarray(vel, dtype=float).reshape(-1, 2))), int(dtype))
         if key not in self._plans:
             self._plans[key] = Plan(dist_types, self.kernel_c, self.dist_thresholds_in, self.norms, self.ts,
-                                    k_range=k_range, vel=vel)
+                                    k_range=k_range, vel=vel, dtype=dtype)
         return self._plans[key]
 
 

@@ -1,5 +1,7 @@
 """Batched sedimentation flux (src/Sources/Sedimentation.jl:22-37) and the rainshaft per-cell sources
 (test/examples/utils/rainshaft_helpers.jl:52-78, without the inter-cell flux divergence)."""
+import numpy as np
+
 from . import _lib
 from .device import DeviceArray, as_device
 
@@ -7,14 +9,15 @@ from .device import DeviceArray, as_device
 def get_sedimentation_flux(plan, mom, out=None, stream=None):
     """mom (nmom, n) device, physical units -> flux (nmom, n) device, physical units."""
     ptr, planes, n, ld = as_device(mom)
-    o = out if out is not None else DeviceArray(plan.nmom, n)
+    o = out if out is not None else DeviceArray(plan.nmom, n, np.float32 if plan.dtype == 1 else np.float64)
     _lib.check(_lib.lib().cloudy_sedimentation_flux(plan.handle, n, ld, ptr, as_device(o)[0], stream))
     return o
 
 
 def rainshaft_sources(plan, mom, coal_source=None, sedi_flux=None, stream=None):
     ptr, planes, n, ld = as_device(mom)
-    cs = coal_source if coal_source is not None else DeviceArray(plan.nmom, n)
-    sf = sedi_flux if sedi_flux is not None else DeviceArray(plan.nmom, n)
+    dt = np.float32 if plan.dtype == 1 else np.float64
+    cs = coal_source if coal_source is not None else DeviceArray(plan.nmom, n, dt)
+    sf = sedi_flux if sedi_flux is not None else DeviceArray(plan.nmom, n, dt)
     _lib.check(_lib.lib().cloudy_rainshaft_sources(plan.handle, n, ld, ptr, as_device(cs)[0], as_device(sf)[0], stream))
     return cs, sf

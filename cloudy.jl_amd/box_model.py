@@ -11,7 +11,7 @@ from types import SimpleNamespace
 import numpy as np
 
 from . import _lib
-from .device import as_device
+from .device import as_device, dtype_code
 from .EquationTypes import AnalyticalCoalStyle, CoalescenceStyle, FixedThreshold, MovingThreshold, NumericalCoalStyle
 from .ParticleDistributions import nparams
 
@@ -24,13 +24,13 @@ def ODEParameters(pdists, coal_data, NProgMoms, norms, **extra):
                            **extra)
 
 
-def _plan_for(par):
+def _plan_for(par, dtype=0):
     if tuple(nparams(d) for d in par.pdists) != tuple(par.NProgMoms):
         raise ValueError("NProgMoms must equal nparams of p.pdists")
     if tuple(par.norms) != tuple(par.coal_data.norms):
         raise ValueError("p.norms differs from the norms the CoalescenceData was built with")
     return par.coal_data.plan([d.type_id for d in par.pdists], k_range=getattr(par, "k_range", (EPS, 10.0)),
-                              vel=getattr(par, "vel", ()))
+                              vel=getattr(par, "vel", ()), dtype=dtype)
 
 
 def rhs_coal(coal_type, dmom, mom, p, threshold_style, stream=None):
@@ -42,7 +42,9 @@ def rhs_coal(coal_type, dmom, mom, p, threshold_style, stream=None):
         raise ValueError("Invalid coal style!")
     if isinstance(threshold_style, MovingThreshold) != isinstance(p.coal_data.ts, MovingThreshold):
         raise ValueError("threshold style of the RHS does not match the CoalescenceData")
-    plan = _plan_for(p)
+    if dtype_code(mom) != dtype_code(dmom):
+        raise TypeError("mom and dmom must have the same element type")
+    plan = _plan_for(p, dtype_code(mom))  # float32 arrays select a CLOUDY_F32 plan (fp32 planes, fp64 arithmetic)
     mptr, planes, n, ld = as_device(mom)
     dptr, dplanes, dn, dld = as_device(dmom)
     if planes != plan.nmom or dplanes != plan.nmom or dn != n or dld != ld:
@@ -67,7 +69,7 @@ def solve_ssprk33(par, u, dt, n_steps, out=None, stream=None):
     """solve(ODEProblem(rhs, u, tspan, par), SSPRK33(), dt = dt) for n_steps fixed steps, on the device
     (cloudy_ssprk33_steps): the final state only (the examples' `sol.u[end]`).  `u` is advanced in place unless
     `out` is given."""
-    plan = _plan_for(par)
+    plan = _plan_for(par, dtype_code(u))
     uptr, planes, n, ld = as_device(u)
     o = out if out is not None else u
     optr, oplanes, on, old = as_device(o)

@@ -101,7 +101,7 @@ int cloudy_plan_create(const cloudy_plan_desc *d, cloudy_plan **out) {
     if (N < 1 || N > CLOUDY_MAX_MODES) return fail(CLOUDY_EUNSUPPORTED, "n_modes %d outside 1..%d", N, CLOUDY_MAX_MODES);
     if (P < 1 || P > CLOUDY_MAX_P) return fail(CLOUDY_EUNSUPPORTED, "tensor_p %d outside 1..%d", P, CLOUDY_MAX_P);
     if (!d->kernel_c) return fail(CLOUDY_EINVAL, "kernel_c is NULL");
-    if (d->dtype != CLOUDY_F64) return fail(CLOUDY_EUNSUPPORTED, "only CLOUDY_F64 plans are built in this revision");
+    if (d->dtype != CLOUDY_F64 && d->dtype != CLOUDY_F32) return fail(CLOUDY_EINVAL, "bad dtype");
     if (!(d->norms[0] > 0) || !(d->norms[1] > 0))
         return fail(CLOUDY_EINVAL, "norms must be positive!");  // helper_functions.jl:44-46
     if (d->threshold_style != CLOUDY_FIXED_THRESHOLD && d->threshold_style != CLOUDY_MOVING_THRESHOLD)
@@ -306,7 +306,7 @@ int cloudy_plan_get(const cloudy_plan *plan, int32_t *N_mom_max, int32_t *N_2d_i
 int cloudy_coal_rhs(const cloudy_plan *plan, size_t n, size_t ld, const void *mom_dev, void *dmom_dev, void *stream) {
     int rc = check_batch(plan, n, ld, mom_dev, dmom_dev);
     if (rc) return rc;
-    LaunchReq r{OP_COAL, IN_MOMENTS, 1, 0, n, ld, (const double *)mom_dev, (double *)dmom_dev, nullptr,
+    LaunchReq r{OP_COAL, IN_MOMENTS, 1, 0, n, ld, mom_dev, dmom_dev, nullptr,
                 (hipStream_t)stream};
     return run(plan, r);
 }
@@ -315,7 +315,7 @@ int cloudy_get_coal_ints(const cloudy_plan *plan, size_t n, size_t ld, const voi
                          void *stream) {
     int rc = check_batch(plan, n, ld, params_dev, out_dev);
     if (rc) return rc;
-    LaunchReq r{OP_COAL, IN_PARAMS, 0, 0, n, ld, (const double *)params_dev, (double *)out_dev, nullptr,
+    LaunchReq r{OP_COAL, IN_PARAMS, 0, 0, n, ld, params_dev, out_dev, nullptr,
                 (hipStream_t)stream};
     return run(plan, r);
 }
@@ -325,7 +325,7 @@ int cloudy_ssprk33_steps(const cloudy_plan *plan, size_t n, size_t ld, const voi
     int rc = check_batch(plan, n, ld, u_in_dev, u_out_dev);
     if (rc) return rc;
     if (n_steps < 0 || !(dt == dt)) return fail(CLOUDY_EINVAL, "n_steps must be >= 0 and dt not NaN");
-    LaunchReq r{OP_SSPRK33, IN_MOMENTS, 1, 0, n, ld, (const double *)u_in_dev, (double *)u_out_dev, nullptr,
+    LaunchReq r{OP_SSPRK33, IN_MOMENTS, 1, 0, n, ld, u_in_dev, u_out_dev, nullptr,
                 (hipStream_t)stream};
     r.dt = dt;
     r.n_steps = n_steps;
@@ -336,7 +336,9 @@ int cloudy_update_dist_from_moments(const cloudy_plan *plan, size_t n, size_t ld
                                     void *params_dev, void *stream) {
     int rc = check_batch(plan, n, ld, mom_dev, params_dev);
     if (rc) return rc;
-    LaunchReq r{OP_UPDATE_DIST, IN_MOMENTS, 0, 0, n, ld, (const double *)mom_dev, (double *)params_dev, nullptr,
+    if (plan->h.dtype != CLOUDY_F64)
+        return fail(CLOUDY_EUNSUPPORTED, "cloudy_update_dist_from_moments reads fp64 planes: use a CLOUDY_F64 plan");
+    LaunchReq r{OP_UPDATE_DIST, IN_MOMENTS, 0, 0, n, ld, mom_dev, params_dev, nullptr,
                 (hipStream_t)stream};
     return run(plan, r);
 }
@@ -345,7 +347,7 @@ int cloudy_finite_2d_integrals(const cloudy_plan *plan, size_t n, size_t ld, con
                                void *stream) {
     int rc = check_batch(plan, n, ld, params_dev, F_dev);
     if (rc) return rc;
-    LaunchReq r{OP_FINITE_2D, IN_PARAMS, 0, 0, n, ld, (const double *)params_dev, (double *)F_dev, nullptr,
+    LaunchReq r{OP_FINITE_2D, IN_PARAMS, 0, 0, n, ld, params_dev, F_dev, nullptr,
                 (hipStream_t)stream};
     return run(plan, r);
 }
@@ -354,7 +356,7 @@ int cloudy_compute_thresholds(const cloudy_plan *plan, size_t n, size_t ld, cons
                               void *thresholds_dev, void *stream) {
     int rc = check_batch(plan, n, ld, params_dev, thresholds_dev);
     if (rc) return rc;
-    LaunchReq r{OP_FINITE_2D, IN_PARAMS, 0, 0, n, ld, (const double *)params_dev, nullptr, (double *)thresholds_dev,
+    LaunchReq r{OP_FINITE_2D, IN_PARAMS, 0, 0, n, ld, params_dev, nullptr, thresholds_dev,
                 (hipStream_t)stream};
     return run(plan, r);
 }
@@ -364,7 +366,7 @@ int cloudy_sedimentation_flux(const cloudy_plan *plan, size_t n, size_t ld, cons
     int rc = check_batch(plan, n, ld, mom_dev, flux_dev);
     if (rc) return rc;
     if (plan->h.n_vel < 1) return fail(CLOUDY_EINVAL, "plan has no terminal-velocity coefficients (n_vel = 0)");
-    LaunchReq r{OP_SEDI, IN_MOMENTS, 1, 0, n, ld, (const double *)mom_dev, (double *)flux_dev, nullptr,
+    LaunchReq r{OP_SEDI, IN_MOMENTS, 1, 0, n, ld, mom_dev, flux_dev, nullptr,
                 (hipStream_t)stream};
     return run(plan, r);
 }
@@ -377,11 +379,11 @@ int cloudy_rainshaft_sources(const cloudy_plan *plan, size_t n, size_t ld, const
     if (plan->h.n_vel < 1) return fail(CLOUDY_EINVAL, "plan has no terminal-velocity coefficients (n_vel = 0)");
     if (plan->h.threshold_style != CLOUDY_FIXED_THRESHOLD)
         return fail(CLOUDY_EINVAL, "make_rainshaft_rhs uses FixedThreshold (rainshaft_helpers.jl:70)");
-    LaunchReq r1{OP_COAL, IN_MOMENTS, 1, 1, n, ld, (const double *)mom_dev, (double *)coal_source_dev, nullptr,
+    LaunchReq r1{OP_COAL, IN_MOMENTS, 1, 1, n, ld, mom_dev, coal_source_dev, nullptr,
                  (hipStream_t)stream};
     rc = run(plan, r1);
     if (rc) return rc;
-    LaunchReq r2{OP_SEDI, IN_MOMENTS, 1, 1, n, ld, (const double *)mom_dev, (double *)sedi_flux_dev, nullptr,
+    LaunchReq r2{OP_SEDI, IN_MOMENTS, 1, 1, n, ld, mom_dev, sedi_flux_dev, nullptr,
                  (hipStream_t)stream};
     return run(plan, r2);
 }
@@ -395,8 +397,12 @@ int cloudy_moment_sums(const cloudy_plan *plan, size_t n, size_t ld, int planes,
     size_t blocks = (n + kBlock - 1) / kBlock;
     if (blocks > (size_t)kSumBlocks) blocks = kSumBlocks;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(plane_partial_sums_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, n, ld,
-                       planes, (const double *)arr_dev, plan->h.partial_dev);
+    if (plan->h.dtype == CLOUDY_F32)
+        hipLaunchKernelGGL(plane_partial_sums_kernel<float>, dim3((unsigned)blocks), dim3(kBlock), 0,
+                           (hipStream_t)stream, n, ld, planes, (const float *)arr_dev, plan->h.partial_dev);
+    else
+        hipLaunchKernelGGL(plane_partial_sums_kernel<double>, dim3((unsigned)blocks), dim3(kBlock), 0,
+                           (hipStream_t)stream, n, ld, planes, (const double *)arr_dev, plan->h.partial_dev);
     hipLaunchKernelGGL(plane_final_sums_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, (int)blocks, planes,
                        (const double *)plan->h.partial_dev, sums_dev);
     HIP_TRY(hipGetLastError());
@@ -407,13 +413,13 @@ int cloudy_coal_rhs_host(const cloudy_plan *plan, size_t n, size_t ld, const voi
     int rc = check_batch(plan, n, ld, mom_host, dmom_host);
     if (rc) return rc;
     if (n == 0) return CLOUDY_OK;
-    const size_t bytes = (size_t)plan->h.nmom * ld * sizeof(double);
-    double *buf = nullptr;
+    const size_t bytes = (size_t)plan->h.nmom * ld * (plan->h.dtype == CLOUDY_F32 ? sizeof(float) : sizeof(double));
+    char *buf = nullptr;
     HIP_TRY(hipMalloc((void **)&buf, 2 * bytes));
     hipError_t e = hipMemcpy(buf, mom_host, bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        rc = cloudy_coal_rhs(plan, n, ld, buf, (char *)buf + bytes, nullptr);
-        if (rc == CLOUDY_OK) e = hipMemcpy(dmom_host, (char *)buf + bytes, bytes, hipMemcpyDeviceToHost);
+        rc = cloudy_coal_rhs(plan, n, ld, buf, buf + bytes, nullptr);
+        if (rc == CLOUDY_OK) e = hipMemcpy(dmom_host, buf + bytes, bytes, hipMemcpyDeviceToHost);
     }
     (void)hipFree(buf);
     if (e != hipSuccess) return fail_hip(e, "host staging copy");

@@ -38,9 +38,9 @@ struct LaunchReq {
     int physical_out; // 1: multiply by mom_norms (rhs_coal!), 0: normalised units (get_coal_ints)
     int rainshaft;    // clamp negatives + skip empty cells
     size_t n, ld;
-    const double *in;
-    double *out;      // OP_COAL: dmom; OP_UPDATE_DIST: params; OP_FINITE_2D: F (may be null); OP_SEDI: flux
-    double *out2;     // OP_FINITE_2D: thresholds (may be null)
+    const void *in;   // planes of the plan's dtype (double, or float for CLOUDY_F32 plans)
+    void *out;        // OP_COAL: dmom; OP_UPDATE_DIST: params; OP_FINITE_2D: F (may be null); OP_SEDI: flux
+    void *out2;       // OP_FINITE_2D: thresholds (may be null)
     hipStream_t stream;
     double dt = 0.0;  // OP_SSPRK33
     int n_steps = 0;  // OP_SSPRK33

@@ -54,6 +54,23 @@ __device__ __forceinline__ void st_stream2(double *p, double a, double b) {
     __builtin_nontemporal_store(v, reinterpret_cast<dvec2 *>(p));
 }
 __device__ __forceinline__ void st_stream(double *p, double v) { __builtin_nontemporal_store(v, p); }
+// CLOUDY_F32 plans: planes are float in HBM (half the traffic), arithmetic stays fp64 in registers
+typedef float fvec2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double ld_stream(const float *p) { return (double)__builtin_nontemporal_load(p); }
+__device__ __forceinline__ void st_stream(float *p, double v) { __builtin_nontemporal_store((float)v, p); }
+__device__ __forceinline__ dvec2 ld_stream2(const float *p) {
+    const fvec2 v = __builtin_nontemporal_load(reinterpret_cast<const fvec2 *>(p));
+    dvec2 r;
+    r.x = (double)v.x;
+    r.y = (double)v.y;
+    return r;
+}
+__device__ __forceinline__ void st_stream2(float *p, double a, double b) {
+    fvec2 v;
+    v.x = (float)a;
+    v.y = (float)b;
+    __builtin_nontemporal_store(v, reinterpret_cast<fvec2 *>(p));
+}
 
 template <int M>
 __host__ __device__ constexpr int tri(int p, int q) {  // packed upper triangle, p <= q < M
@@ -460,8 +477,8 @@ __device__ __forceinline__ void coal_ints_parcel(const KArgs<N, P> &A, const dou
 }
 
 // load one parcel (moments -> normalise -> invert, or parameters as given)
-template <int N, int P>
-__device__ __forceinline__ bool load_parcel(const KArgs<N, P> &A, size_t i, size_t ld, const double *__restrict__ in,
+template <int N, int P, typename TIO = double>
+__device__ __forceinline__ bool load_parcel(const KArgs<N, P> &A, size_t i, size_t ld, const TIO *__restrict__ in,
                                             double (&nn)[N], double (&th)[N], double (&kk)[N]) {
     bool all_small = true;
     if (A.input_kind == IN_MOMENTS) {
@@ -498,16 +515,16 @@ __device__ __forceinline__ bool load_parcel(const KArgs<N, P> &A, size_t i, size
     return all_small;
 }
 
-template <int N, int P, int MODE>
+template <int N, int P, int MODE, typename TIO>
 __global__ void __launch_bounds__(kBlock)
     coal_rhs_kernel(const KArgs<N, P> A, const double *__restrict__ nodes, size_t n, size_t ld,
-                    const double *__restrict__ in, double *__restrict__ out) {
+                    const TIO *__restrict__ in, TIO *__restrict__ out) {
     // one parcel per lane, no grid-stride loop: a parcel loop would let LICM hoist every libm polynomial
     // constant of the body into registers for the whole kernel (measured: 256 VGPRs + spills vs ~100).
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) {
         double nn[N], th[N], kk[N], acc[N][3];
-        const bool all_small = load_parcel<N, P>(A, i, ld, in, nn, th, kk);
+        const bool all_small = load_parcel<N, P, TIO>(A, i, ld, in, nn, th, kk);
         coal_ints_parcel<N, P, MODE>(A, nodes, nn, th, kk, acc);
         const bool skip = A.rainshaft && all_small;  // rainshaft_helpers.jl:67-68
 #pragma unroll
@@ -524,10 +541,10 @@ __global__ void __launch_bounds__(kBlock)
 // wave instruction).  Requires 16-byte aligned planes: base pointers 16-B aligned and ld even (checked by the
 // host, which otherwise launches the one-parcel kernel).  The two parcels are independent instruction streams,
 // which also gives the scheduler ILP across the division sequences of the closure inversion.
-template <int N, int P>
+template <int N, int P, typename TIO>
 __global__ void __launch_bounds__(kBlock)
-    coal_rhs_allinf2_kernel(const KArgs<N, P> A, size_t n, size_t ld, const double *__restrict__ in,
-                            double *__restrict__ out) {
+    coal_rhs_allinf2_kernel(const KArgs<N, P> A, size_t n, size_t ld, const TIO *__restrict__ in,
+                            TIO *__restrict__ out) {
     const size_t i = ((size_t)blockIdx.x * kBlock + threadIdx.x) * 2;
     if (i >= n) return;
     const bool pair = (i + 1 < n);
@@ -542,9 +559,9 @@ __global__ void __launch_bounds__(kBlock)
             v1 = ld_stream2(in + (size_t)(off + 1) * ld + i);
             if (three) v2 = ld_stream2(in + (size_t)(off + 2) * ld + i);
         } else {
-            v0 = dvec2{in[(size_t)(off + 0) * ld + i], 0.0};
-            v1 = dvec2{in[(size_t)(off + 1) * ld + i], 0.0};
-            if (three) v2 = dvec2{in[(size_t)(off + 2) * ld + i], 0.0};
+            v0 = dvec2{(double)in[(size_t)(off + 0) * ld + i], 0.0};
+            v1 = dvec2{(double)in[(size_t)(off + 1) * ld + i], 0.0};
+            if (three) v2 = dvec2{(double)in[(size_t)(off + 2) * ld + i], 0.0};
         }
         const double m0[2] = {v0.x, v0.y}, m1[2] = {v1.x, v1.y}, m2[2] = {v2.x, v2.y};
 #pragma unroll
@@ -564,11 +581,11 @@ __global__ void __launch_bounds__(kBlock)
         for (int m = 0; m < 3; ++m) {
             if (m == 2 && A.np[k] != 3) continue;
             const double s = A.out_scale[3 * k + m];
-            double *dst = out + (size_t)(off + m) * ld + i;
+            TIO *dst = out + (size_t)(off + m) * ld + i;
             if (pair)
                 st_stream2(dst, acc[0][k][m] * s, acc[1][k][m] * s);
             else
-                *dst = acc[0][k][m] * s;
+                *dst = (TIO)(acc[0][k][m] * s);
         }
     }
 }
@@ -579,10 +596,10 @@ __global__ void __launch_bounds__(kBlock)
 // any of them takes, so the 256 parcels of a workgroup are first ranked by r (counting sort in LDS) and each
 // lane then processes the parcel of its rank: waves become regime-homogeneous.  Parcels stay inside their
 // workgroup's 256-parcel window (2 KB per plane), so stores remain line-coalesced.
-template <int N, int P, int MODE>
+template <int N, int P, int MODE, typename TIO>
 __global__ void __launch_bounds__(kBlock)
     coal_rhs_sorted_kernel(const KArgs<N, P> A, const double *__restrict__ nodes, size_t n, size_t ld,
-                           const double *__restrict__ in, double *__restrict__ out) {
+                           const TIO *__restrict__ in, TIO *__restrict__ out) {
     __shared__ double sh_par[3 * N][kBlock];
     __shared__ unsigned int sh_key[kBlock];
     __shared__ unsigned short sh_perm[kBlock];
@@ -595,7 +612,7 @@ __global__ void __launch_bounds__(kBlock)
         bool all_small = true;
         unsigned int key = 0xFFFFFFFFu;  // out-of-range or empty parcels rank last
         if (i0 < n) {
-            all_small = load_parcel<N, P>(A, i0, ld, in, nn, th, kk);
+            all_small = load_parcel<N, P, TIO>(A, i0, ld, in, nn, th, kk);
             int f = 0;  // first mode that carries a threshold (wave-uniform)
             if (MODE == MODE_FIXED) {
 #pragma unroll
@@ -687,10 +704,10 @@ __device__ __forceinline__ void rhs_physical(const KArgs<N, P> &A, const double 
     }
 }
 
-template <int N, int P, int MODE>
+template <int N, int P, int MODE, typename TIO>
 __global__ void __launch_bounds__(kBlock)
     ssprk33_kernel(const KArgs<N, P> A, const double *__restrict__ nodes, size_t n, size_t ld,
-                   const double *u_in, double *u_out, double dt, int n_steps) {
+                   const TIO *u_in, TIO *u_out, double dt, int n_steps) {
     size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (MODE != MODE_ALLINF) {
         // regime sort of the workgroup's parcels on the initial state (see coal_rhs_sorted_kernel)
@@ -700,7 +717,7 @@ __global__ void __launch_bounds__(kBlock)
         unsigned int key = 0xFFFFFFFFu;
         if (i < n) {
             double nn[N], th[N], kk[N];
-            load_parcel<N, P>(A, i, ld, u_in, nn, th, kk);
+            load_parcel<N, P, TIO>(A, i, ld, u_in, nn, th, kk);
             int f = 0;
             if (MODE == MODE_FIXED) {
 #pragma unroll
@@ -736,9 +753,9 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
     for (int m = 0; m < N; ++m) {
         const int off = A.off[m];
-        u[m][0] = u_in[(size_t)(off + 0) * ld + i];
-        u[m][1] = u_in[(size_t)(off + 1) * ld + i];
-        u[m][2] = (A.np[m] == 3) ? u_in[(size_t)(off + 2) * ld + i] : 0.0;
+        u[m][0] = (double)u_in[(size_t)(off + 0) * ld + i];
+        u[m][1] = (double)u_in[(size_t)(off + 1) * ld + i];
+        u[m][2] = (A.np[m] == 3) ? (double)u_in[(size_t)(off + 2) * ld + i] : 0.0;
     }
 #pragma unroll 1
     for (int step = 0; step < n_steps; ++step) {
@@ -766,9 +783,9 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
     for (int m = 0; m < N; ++m) {
         const int off = A.off[m];
-        u_out[(size_t)(off + 0) * ld + i] = u[m][0];
-        u_out[(size_t)(off + 1) * ld + i] = u[m][1];
-        if (A.np[m] == 3) u_out[(size_t)(off + 2) * ld + i] = u[m][2];
+        u_out[(size_t)(off + 0) * ld + i] = (TIO)u[m][0];
+        u_out[(size_t)(off + 1) * ld + i] = (TIO)u[m][1];
+        if (A.np[m] == 3) u_out[(size_t)(off + 2) * ld + i] = (TIO)u[m][2];
     }
 }
 
@@ -856,16 +873,16 @@ struct SediArgs {
 
 // get_sedimentation_flux, Sedimentation.jl:22-37: flux[i][j] = -sum_v vel_v0 * M^i_{j-1+vel_v1}
 // with the fractional-order moment n theta^q Gamma(q+k)/Gamma(k).
-template <int N, int P>
+template <int N, int P, typename TIO>
 __global__ void __launch_bounds__(kBlock)
-    sedi_flux_kernel(const KArgs<N, P> A, const SediArgs S, size_t n, size_t ld, const double *__restrict__ in,
-                     double *__restrict__ out) {
+    sedi_flux_kernel(const KArgs<N, P> A, const SediArgs S, size_t n, size_t ld, const TIO *__restrict__ in,
+                     TIO *__restrict__ out) {
     // one parcel per lane, no grid-stride loop: a parcel loop would let LICM hoist every libm polynomial
     // constant of the body into registers for the whole kernel (measured: 256 VGPRs + spills vs ~100).
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) {
         double nn[N], th[N], kk[N];
-        load_parcel<N, P>(A, i, ld, in, nn, th, kk);
+        load_parcel<N, P, TIO>(A, i, ld, in, nn, th, kk);
 #pragma unroll
         for (int m = 0; m < N; ++m) {
             const int off = A.off[m];
@@ -878,7 +895,7 @@ __global__ void __launch_bounds__(kBlock)
                     const double mom = nn[m] * exp(fma(q, lnth, lgamma(q + kk[m]) - lgk));
                     s -= S.vel[v][0] * mom;
                 }
-                out[(size_t)(off + j) * ld + i] = s * A.out_scale[3 * m + j];
+                out[(size_t)(off + j) * ld + i] = (TIO)(s * A.out_scale[3 * m + j]);
             }
         }
     }

@@ -41,45 +41,30 @@ void fill_args(const HostPlan &h, const LaunchReq &r, KArgs<N, P> &A) {
                 for (int b = 0; b < P; ++b) A.c[j][k][a][b] = h.c[j][k][a][b];
 }
 
-template <int N, int P>
-hipError_t launch_np(const HostPlan &h, const LaunchReq &r) {
-    KArgs<N, P> A;
-    fill_args<N, P>(h, r, A);
+// kernels that exist for both plane types (double / float storage)
+template <int N, int P, typename TIO>
+hipError_t launch_io(const HostPlan &h, const LaunchReq &r, const KArgs<N, P> &A) {
     const bool heavy = h.mode != MODE_ALLINF;
+    const TIO *in = static_cast<const TIO *>(r.in);
+    TIO *out = static_cast<TIO *>(r.out);
     switch (r.op) {
     case OP_COAL: {
         const unsigned g = grid_for(r.n, heavy);
-        const bool aligned16 = ((reinterpret_cast<uintptr_t>(r.in) | reinterpret_cast<uintptr_t>(r.out)) & 15u) == 0 &&
-                               (r.ld % 2 == 0);
-        if (h.mode == MODE_ALLINF && r.input_kind == IN_MOMENTS && !r.rainshaft && aligned16 && !h.force_ppl1)
-            hipLaunchKernelGGL((coal_rhs_allinf2_kernel<N, P>), dim3(grid_for((r.n + 1) / 2, false)), dim3(kBlock), 0,
-                               r.stream, A, r.n, r.ld, r.in, r.out);
+        const uintptr_t amask = 2 * sizeof(TIO) - 1;  // two parcels per lane need 2-element aligned planes
+        const bool aligned2 = ((reinterpret_cast<uintptr_t>(r.in) | reinterpret_cast<uintptr_t>(r.out)) & amask) == 0 &&
+                              (r.ld % 2 == 0);
+        if (h.mode == MODE_ALLINF && r.input_kind == IN_MOMENTS && !r.rainshaft && aligned2 && !h.force_ppl1)
+            hipLaunchKernelGGL((coal_rhs_allinf2_kernel<N, P, TIO>), dim3(grid_for((r.n + 1) / 2, false)), dim3(kBlock),
+                               0, r.stream, A, r.n, r.ld, in, out);
         else if (h.mode == MODE_ALLINF)
-            hipLaunchKernelGGL((coal_rhs_kernel<N, P, MODE_ALLINF>), dim3(g), dim3(kBlock), 0, r.stream, A, h.nodes_dev,
-                               r.n, r.ld, r.in, r.out);
+            hipLaunchKernelGGL((coal_rhs_kernel<N, P, MODE_ALLINF, TIO>), dim3(g), dim3(kBlock), 0, r.stream, A,
+                               h.nodes_dev, r.n, r.ld, in, out);
         else if (h.mode == MODE_FIXED)
-            hipLaunchKernelGGL((coal_rhs_sorted_kernel<N, P, MODE_FIXED>), dim3(g), dim3(kBlock), 0, r.stream, A,
-                               h.nodes_dev, r.n, r.ld, r.in, r.out);
+            hipLaunchKernelGGL((coal_rhs_sorted_kernel<N, P, MODE_FIXED, TIO>), dim3(g), dim3(kBlock), 0, r.stream, A,
+                               h.nodes_dev, r.n, r.ld, in, out);
         else
-            hipLaunchKernelGGL((coal_rhs_sorted_kernel<N, P, MODE_MOVING>), dim3(g), dim3(kBlock), 0, r.stream, A,
-                               h.nodes_dev, r.n, r.ld, r.in, r.out);
-        break;
-    }
-    case OP_UPDATE_DIST:
-        hipLaunchKernelGGL((update_dist_kernel<N, P>), dim3(grid_for(r.n, false)), dim3(kBlock), 0, r.stream, A, r.n,
-                           r.ld, r.in, r.out);
-        break;
-    case OP_FINITE_2D: {
-        const unsigned g = grid_for(r.n, heavy);
-        if (h.mode == MODE_ALLINF)
-            hipLaunchKernelGGL((finite_2d_kernel<N, P, MODE_ALLINF>), dim3(g), dim3(kBlock), 0, r.stream, A,
-                               h.nodes_dev, r.n, r.ld, r.in, r.out, r.out2);
-        else if (h.mode == MODE_FIXED)
-            hipLaunchKernelGGL((finite_2d_kernel<N, P, MODE_FIXED>), dim3(g), dim3(kBlock), 0, r.stream, A,
-                               h.nodes_dev, r.n, r.ld, r.in, r.out, r.out2);
-        else
-            hipLaunchKernelGGL((finite_2d_kernel<N, P, MODE_MOVING>), dim3(g), dim3(kBlock), 0, r.stream, A,
-                               h.nodes_dev, r.n, r.ld, r.in, r.out, r.out2);
+            hipLaunchKernelGGL((coal_rhs_sorted_kernel<N, P, MODE_MOVING, TIO>), dim3(g), dim3(kBlock), 0, r.stream, A,
+                               h.nodes_dev, r.n, r.ld, in, out);
         break;
     }
     case OP_SEDI: {
@@ -90,21 +75,57 @@ hipError_t launch_np(const HostPlan &h, const LaunchReq &r) {
             S.vel[v][0] = v < h.n_vel ? h.vel_n[v][0] : 0.0;
             S.vel[v][1] = v < h.n_vel ? h.vel_n[v][1] : 0.0;
         }
-        hipLaunchKernelGGL((sedi_flux_kernel<N, P>), dim3(grid_for(r.n, false)), dim3(kBlock), 0, r.stream, A, S, r.n,
-                           r.ld, r.in, r.out);
+        hipLaunchKernelGGL((sedi_flux_kernel<N, P, TIO>), dim3(grid_for(r.n, false)), dim3(kBlock), 0, r.stream, A, S,
+                           r.n, r.ld, in, out);
         break;
     }
     case OP_SSPRK33: {
         const unsigned g = grid_for(r.n, heavy);
         if (h.mode == MODE_ALLINF)
-            hipLaunchKernelGGL((ssprk33_kernel<N, P, MODE_ALLINF>), dim3(g), dim3(kBlock), 0, r.stream, A, h.nodes_dev,
-                               r.n, r.ld, r.in, r.out, r.dt, r.n_steps);
+            hipLaunchKernelGGL((ssprk33_kernel<N, P, MODE_ALLINF, TIO>), dim3(g), dim3(kBlock), 0, r.stream, A,
+                               h.nodes_dev, r.n, r.ld, in, out, r.dt, r.n_steps);
         else if (h.mode == MODE_FIXED)
-            hipLaunchKernelGGL((ssprk33_kernel<N, P, MODE_FIXED>), dim3(g), dim3(kBlock), 0, r.stream, A, h.nodes_dev,
-                               r.n, r.ld, r.in, r.out, r.dt, r.n_steps);
+            hipLaunchKernelGGL((ssprk33_kernel<N, P, MODE_FIXED, TIO>), dim3(g), dim3(kBlock), 0, r.stream, A,
+                               h.nodes_dev, r.n, r.ld, in, out, r.dt, r.n_steps);
         else
-            hipLaunchKernelGGL((ssprk33_kernel<N, P, MODE_MOVING>), dim3(g), dim3(kBlock), 0, r.stream, A, h.nodes_dev,
-                               r.n, r.ld, r.in, r.out, r.dt, r.n_steps);
+            hipLaunchKernelGGL((ssprk33_kernel<N, P, MODE_MOVING, TIO>), dim3(g), dim3(kBlock), 0, r.stream, A,
+                               h.nodes_dev, r.n, r.ld, in, out, r.dt, r.n_steps);
+        break;
+    }
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+template <int N, int P>
+hipError_t launch_np(const HostPlan &h, const LaunchReq &r) {
+    KArgs<N, P> A;
+    fill_args<N, P>(h, r, A);
+    const bool heavy = h.mode != MODE_ALLINF;
+    switch (r.op) {
+    case OP_COAL:
+    case OP_SEDI:
+    case OP_SSPRK33:
+        // get_coal_ints on (n, theta, k) planes is an fp64 interface for every plan
+        if (h.dtype == CLOUDY_F32 && r.input_kind == IN_MOMENTS) return launch_io<N, P, float>(h, r, A);
+        return launch_io<N, P, double>(h, r, A);
+    case OP_UPDATE_DIST:
+        hipLaunchKernelGGL((update_dist_kernel<N, P>), dim3(grid_for(r.n, false)), dim3(kBlock), 0, r.stream, A, r.n,
+                           r.ld, static_cast<const double *>(r.in), static_cast<double *>(r.out));
+        break;
+    case OP_FINITE_2D: {
+        const unsigned g = grid_for(r.n, heavy);
+        const double *in = static_cast<const double *>(r.in);
+        double *out = static_cast<double *>(r.out), *out2 = static_cast<double *>(r.out2);
+        if (h.mode == MODE_ALLINF)
+            hipLaunchKernelGGL((finite_2d_kernel<N, P, MODE_ALLINF>), dim3(g), dim3(kBlock), 0, r.stream, A,
+                               h.nodes_dev, r.n, r.ld, in, out, out2);
+        else if (h.mode == MODE_FIXED)
+            hipLaunchKernelGGL((finite_2d_kernel<N, P, MODE_FIXED>), dim3(g), dim3(kBlock), 0, r.stream, A,
+                               h.nodes_dev, r.n, r.ld, in, out, out2);
+        else
+            hipLaunchKernelGGL((finite_2d_kernel<N, P, MODE_MOVING>), dim3(g), dim3(kBlock), 0, r.stream, A,
+                               h.nodes_dev, r.n, r.ld, in, out, out2);
         break;
     }
     default: return hipErrorInvalidValue;

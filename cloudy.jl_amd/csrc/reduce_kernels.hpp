@@ -8,14 +8,15 @@
 namespace cloudy {
 
 // per-block partial sums of `planes` planes; second pass adds the partials (deterministic order)
+template <typename TIO>
 __global__ void __launch_bounds__(kBlock)
-    plane_partial_sums_kernel(size_t n, size_t ld, int planes, const double *__restrict__ arr,
+    plane_partial_sums_kernel(size_t n, size_t ld, int planes, const TIO *__restrict__ arr,
                               double *__restrict__ partial) {
     __shared__ double red[kBlock / 64];
     const size_t stride = (size_t)gridDim.x * kBlock;
     for (int q = 0; q < planes; ++q) {
         double s = 0.0;
-        for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) s += arr[(size_t)q * ld + i];
+        for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) s += (double)arr[(size_t)q * ld + i];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;

@@ -11,34 +11,38 @@ from . import _lib
 
 
 class DeviceArray:
-    """A float64 (planes, n) buffer in HBM owned through cloudy_malloc/cloudy_free."""
+    """A float64 (or float32, for CLOUDY_F32 plans) (planes, n) buffer in HBM owned through cloudy_malloc/cloudy_free."""
 
-    def __init__(self, planes, n):
+    def __init__(self, planes, n, dtype=np.float64):
         self.shape = (int(planes), int(n))
-        self.nbytes = 8 * self.shape[0] * self.shape[1]
+        self.dtype = np.dtype(dtype)
+        if self.dtype not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise TypeError("DeviceArray holds float64 or float32")
+        self.nbytes = self.dtype.itemsize * self.shape[0] * self.shape[1]
         p = C.c_void_p()
         _lib.check(_lib.lib().cloudy_malloc(C.byref(p), max(self.nbytes, 8)))
         self.ptr = p.value
 
     @classmethod
     def from_numpy(cls, a):
-        a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+        a = np.asarray(a)
+        a = np.ascontiguousarray(a, dtype=np.float32 if a.dtype == np.float32 else np.float64)
         if a.ndim == 1:
             a = a.reshape(-1, 1)
-        d = cls(*a.shape)
+        d = cls(*a.shape, dtype=a.dtype)
         if d.nbytes:
             _lib.check(_lib.lib().cloudy_memcpy_h2d(d.ptr, a.ctypes.data, d.nbytes, None))
             _lib.check(_lib.lib().cloudy_stream_synchronize(None))
         return d
 
     @classmethod
-    def zeros(cls, planes, n):
-        d = cls(planes, n)
+    def zeros(cls, planes, n, dtype=np.float64):
+        d = cls(planes, n, dtype)
         _lib.check(_lib.lib().cloudy_memset(d.ptr, 0, d.nbytes, None))
         return d
 
     def to_numpy(self):
-        out = np.empty(self.shape, dtype=np.float64)
+        out = np.empty(self.shape, dtype=self.dtype)
         if self.nbytes:
             _lib.check(_lib.lib().cloudy_stream_synchronize(None))
             _lib.check(_lib.lib().cloudy_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes, None))
@@ -64,6 +68,13 @@ class DeviceArray:
             pass
 
 
+def dtype_code(x):
+    """CLOUDY_F64 (0) / CLOUDY_F32 (1) of a device array."""
+    if isinstance(x, DeviceArray):
+        return 1 if x.dtype == np.float32 else 0
+    return 1 if x.dtype.itemsize == 4 else 0
+
+
 def as_device(x):
     """(pointer, planes, n, ld) of a DeviceArray or of a CUDA/HIP torch tensor of shape (planes, n)."""
     if isinstance(x, DeviceArray):
@@ -71,8 +82,8 @@ def as_device(x):
     if hasattr(x, "data_ptr") and hasattr(x, "is_cuda"):
         if not x.is_cuda:
             raise TypeError("torch tensor must live on the GPU (no CPU fallback)")
-        if x.dtype.itemsize != 8 or not x.dtype.is_floating_point:
-            raise TypeError("expected a float64 tensor")
+        if x.dtype.itemsize not in (4, 8) or not x.dtype.is_floating_point:
+            raise TypeError("expected a float64 (or float32) tensor")
         if x.dim() != 2 or x.stride(1) != 1:
             raise TypeError("expected a (planes, n) tensor with contiguous parcels")
         return x.data_ptr(), x.shape[0], x.shape[1], x.stride(0) if x.shape[0] > 1 else x.shape[1]

@@ -91,7 +91,9 @@ typedef struct cloudy_plan_desc {
     double norms[2];                         /* (n0, m0), helper_functions.jl:40-53 */
     double k_range[2];                       /* param_range.k, ParticleDistributions.jl:459; default (eps, 10) */
     int32_t n_bins_per_log_unit;             /* ParticleDistributions.jl:594; default 15 */
-    int32_t dtype;                           /* CLOUDY_F64 (CLOUDY_F32: see DESIGN.md) */
+    int32_t dtype;                           /* element type of the mom / dmom / flux planes: CLOUDY_F64, or CLOUDY_F32
+                                                (float planes in HBM = half the traffic; arithmetic stays fp64 in
+                                                registers; (n, theta, k) / F diagnostics planes are always fp64) */
     int32_t n_vel;                           /* 0 = no sedimentation term */
     double vel[CLOUDY_MAX_VEL][2];           /* p.vel: terminal velocity sum_k vel[k][0] * x^vel[k][1], physical units */
     int32_t device;                          /* HIP device ordinal, -1 = current */

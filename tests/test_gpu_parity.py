@@ -515,3 +515,52 @@ def test_fused_ssprk33_batch_vs_oracle_stepping(gpu_cloudy, oracle, name, tol):
     err = np.abs(got - want)[:, ok] / np.maximum(ref[:, ok], 1e-300)
     assert err.max() < max(1e3 * tol, 1e-9), err.max()
     print(f"{name}: fused SSPRK33 vs oracle stepping, max rel err {err.max():.2e}")
+
+
+@pytest.mark.parametrize("name,n", [("cfg3a", 100_001), ("cfg3b", 10_000)])
+def test_fp32_planes_vs_fp64_oracle(gpu_cloudy, oracle, name, n):
+    """BASELINE configs[4] "fp32 path with fp64 tolerance check": CLOUDY_F32 plans keep the moment / tendency planes
+    as float in HBM (half the traffic) and compute in fp64 registers, so against the fp64 oracle evaluated on the
+    same (float-representable) inputs the only error is the final rounding of each tendency to float."""
+    cloudy = gpu_cloudy
+    wl = bench.make_workload(name, n, seed=77)
+    mom32 = wl["mom"].astype(np.float32)
+    m = cloudy.DeviceArray.from_numpy(mom32)
+    dm = cloudy.DeviceArray.zeros(6, n, np.float32)
+    cloudy.make_box_model_rhs(cloudy.AnalyticalCoalStyle())(dm, m, wl["par"], 0.0)
+    got = dm.to_numpy()
+    assert got.dtype == np.float32
+    want, scale = oracle.rhs_coal_batch(bench.oracle_params(name), mom32.astype(np.float64), with_scale=True)
+    with np.errstate(over="ignore"):
+        want32 = want.astype(np.float32)
+    fin = np.isfinite(want32)
+    assert np.array_equal(np.isfinite(got), fin)
+    err = np.abs(got.astype(np.float64)[fin] - want[fin])
+    bound = 6.0e-8 * np.abs(want[fin]) + 1e-12 * scale[fin] + 1.5e-45
+    assert np.all(err <= bound), (err / np.maximum(np.abs(want[fin]), 1e-300)).max()
+    big = np.abs(want[fin]) > 1e-3 * scale[fin]  # entries that are not cancellation residues
+    print(f"{name} fp32 planes: max rel err vs fp64 oracle {(err[big] / np.abs(want[fin][big])).max():.2e}")
+    # mixed element types are rejected
+    with pytest.raises(TypeError):
+        cloudy.make_box_model_rhs(cloudy.AnalyticalCoalStyle())(cloudy.DeviceArray.zeros(6, n), m, wl["par"], 0.0)
+
+
+def test_cfg5_long_kernel_plus_sedimentation_fp32(gpu_cloudy, oracle):
+    """BASELINE configs[4]: Long's kernel pieces + sedimentation flux (vel = ((50, 1/6),), rainshaft_gamma_mixture.jl:44),
+    fp32 planes, against the fp64 oracle of the rainshaft cell body."""
+    cloudy = gpu_cloudy
+    n = 5000
+    vel = ((50.0, 1.0 / 6),)
+    spec = bench.workload_spec("cfg3b")
+    kc = bench.kernel_matrix(spec)
+    par, op, _ = make_case(cloudy, oracle, [1, 1], kc, spec["thresholds"], bench.NORMS, vel=vel)
+    mom32 = bench.synth_moments(2, n, seed=5).astype(np.float32)
+    plan = par.coal_data.plan([1, 1], vel=vel, dtype=1)
+    cs, sf = cloudy.rainshaft_sources(plan, cloudy.DeviceArray.from_numpy(mom32))
+    wcs, wsf = oracle.rainshaft_cell_batch(op, mom32.astype(np.float64))
+    _, scale = oracle.rhs_coal_batch(op, mom32.astype(np.float64), with_scale=True)
+    g1, g2 = cs.to_numpy().astype(np.float64), sf.to_numpy().astype(np.float64)
+    with np.errstate(over="ignore"):
+        fin = np.isfinite(wcs.astype(np.float32)) & np.isfinite(wsf.astype(np.float32))
+    assert np.all(np.abs(g1 - wcs)[fin] <= 6e-8 * np.abs(wcs[fin]) + 1e-12 * scale[fin] + 1.5e-45)
+    assert np.all(np.abs(g2 - wsf)[fin] <= 6e-8 * np.abs(wsf[fin]) + 1.5e-45)

@@ -68,8 +68,8 @@ def test_plan_validation_errors_precede_device_lookup(cloudy):
     assert rc == E.EUNSUPPORTED
     rc, _ = create(lambda d, c: setattr(d, "struct_size", 8))
     assert rc == E.EINVAL
-    rc, _ = create(lambda d, c: setattr(d, "dtype", 1))
-    assert rc == E.EUNSUPPORTED
+    rc, _ = create(lambda d, c: setattr(d, "dtype", 7))
+    assert rc == E.EINVAL
     if cloudy.device_count() == 0:
         rc, msg = create(lambda d, c: None)
         assert rc == E.ENODEVICE and "no HIP device" in msg           # fails loudly, no CPU fallback
