@@ -138,9 +138,17 @@ def _dist_setup(n_gpus):
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                            device_id=torch.device("cuda", local_rank))
+    # CLOUDY_BENCH_BACKEND=gloo runs the identical multi-rank path where RCCL cannot form a communicator
+    # (all ranks on ONE GPU of a 1-GPU test box); the driver's multi-GPU runs use nccl (= RCCL).
+    backend = os.environ.get("CLOUDY_BENCH_BACKEND", "nccl")
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    else:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank, dist, torch
 
 
@@ -161,7 +169,7 @@ def _time_steps(pkg, plan, m, dm, steps, dist, torch):
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
