@@ -123,7 +123,7 @@ class CoalescenceData:
         """The device plan for this data and the closure types of `pdists` (built once, cached)."""
         dist_types = tuple(int(t) for t in dist_types)
         for t, npm in zip(dist_types, self.NProgMoms):
-            if (3 if t == 1 else 2) != npm:
+            if {0: 2, 1: 3, 2: 2, 3: 3}.get(t) != npm:
                 raise ValueError("NProgMoms does not match nparams of the distributions")
         key = (dist_types, tuple(k_range), tuple(map(tuple, np.asarray(vel, dtype=float).reshape(-1, 2))), int(dtype))
         if key not in self._plans:

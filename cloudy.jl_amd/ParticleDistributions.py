@@ -11,7 +11,8 @@ import numpy as np
 from . import _lib
 from .device import DeviceArray, as_device
 
-EXPONENTIAL, GAMMA = 0, 1
+EXPONENTIAL, GAMMA, MONODISPERSE, LOGNORMAL = 0, 1, 2, 3
+NPARAMS = {EXPONENTIAL: 2, GAMMA: 3, MONODISPERSE: 2, LOGNORMAL: 3}
 
 
 class AbstractParticleDistribution:
@@ -45,15 +46,42 @@ class GammaPrimitiveParticleDistribution(PrimitiveParticleDistribution):
             raise ValueError("n needs to be nonnegative. θ and k need to be positive.")
 
 
+@dataclass(frozen=True)
+class MonodispersePrimitiveParticleDistribution(PrimitiveParticleDistribution):
+    n: float
+    θ: float
+    type_id = MONODISPERSE
+
+    def __post_init__(self):  # ParticleDistributions.jl:126-129
+        if self.n < 0 or self.θ <= 0:
+            raise ValueError("n needs to be nonnegative. θ needs to be positive.")
+
+
+@dataclass(frozen=True)
+class LognormalPrimitiveParticleDistribution(PrimitiveParticleDistribution):
+    n: float
+    μ: float
+    σ: float
+    type_id = LOGNORMAL
+
+    def __post_init__(self):  # ParticleDistributions.jl:153-156
+        if self.n < 0 or self.σ <= 0:
+            raise ValueError("n needs to be nonnegative. σ needs to be positive.")
+
+
 def nparams(dist):
     """ParticleDistributions.jl:425-427."""
-    return 3 if isinstance(dist, GammaPrimitiveParticleDistribution) else 2
+    return NPARAMS[dist.type_id]
 
 
 def get_moments(pdist):
     """First nparams moments, closed form (ParticleDistributions.jl:293-315); used to build initial conditions."""
+    import math
+
     if isinstance(pdist, GammaPrimitiveParticleDistribution):
         return [pdist.n, pdist.n * pdist.k * pdist.θ, pdist.n * pdist.k * (pdist.k + 1) * pdist.θ**2]
+    if isinstance(pdist, LognormalPrimitiveParticleDistribution):
+        return [pdist.n, pdist.n * math.exp(pdist.μ + pdist.σ**2 / 2), pdist.n * math.exp(2.0 * pdist.μ + 2.0 * pdist.σ**2)]
     return [pdist.n, pdist.n * pdist.θ]
 
 

@@ -17,6 +17,7 @@ from .KernelFunctions import (ConstantKernelFunction, HydrodynamicKernelFunction
                               LongKernelFunction, get_normalized_kernel_func)
 from .KernelTensors import CoalescenceTensor, check_symmetry, get_normalized_kernel_tensor
 from .ParticleDistributions import (ExponentialPrimitiveParticleDistribution, GammaPrimitiveParticleDistribution,
+                                    LognormalPrimitiveParticleDistribution, MonodispersePrimitiveParticleDistribution,
                                     compute_thresholds, get_moments, nparams, pack_params, update_dist_from_moments)
 from .Coalescence import CoalescenceData, Plan, get_coal_ints, get_finite_2d_integrals
 from .Sedimentation import get_sedimentation_flux, rainshaft_sources

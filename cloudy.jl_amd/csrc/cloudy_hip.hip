@@ -124,14 +124,13 @@ int cloudy_plan_create(const cloudy_plan_desc *d, cloudy_plan **out) {
     h.norms[1] = d->norms[1];
     int off = 0, np_max = 0;
     for (int i = 0; i < N; ++i) {
-        if (d->dist_type[i] == CLOUDY_DIST_EXPONENTIAL)
+        if (d->dist_type[i] == CLOUDY_DIST_EXPONENTIAL || d->dist_type[i] == CLOUDY_DIST_MONODISPERSE)
             h.np[i] = 2;
-        else if (d->dist_type[i] == CLOUDY_DIST_GAMMA)
+        else if (d->dist_type[i] == CLOUDY_DIST_GAMMA || d->dist_type[i] == CLOUDY_DIST_LOGNORMAL)
             h.np[i] = 3;
         else {
             delete p;
-            return fail(CLOUDY_EUNSUPPORTED, "dist_type[%d] = %d: only Exponential and Gamma closures are built", i,
-                        d->dist_type[i]);
+            return fail(CLOUDY_EINVAL, "dist_type[%d] = %d is not a closure family", i, d->dist_type[i]);
         }
         h.dist_type[i] = d->dist_type[i];
         h.off[i] = off;
@@ -187,6 +186,17 @@ int cloudy_plan_create(const cloudy_plan_desc *d, cloudy_plan **out) {
                 delete p;
                 return fail(CLOUDY_EINVAL, "dist_thresholds[%d] must be positive or +Inf", i);
             }
+            if (h.dist_type[i] == CLOUDY_DIST_LOGNORMAL) {
+                delete p;
+                return fail(CLOUDY_EUNSUPPORTED,
+                            "finite threshold on a Lognormal mode: the reference integrates it with adaptive quadgk "
+                            "(ParticleDistributions.jl:614-625), which is not built for the GPU");
+            }
+            if (h.dist_type[i] == CLOUDY_DIST_MONODISPERSE) {  // analytic, no Simpson grid (:557-564)
+                h.finite[i] = 1;
+                any_finite = true;
+                continue;
+            }
             const double x_lb = std::fmin(1e-5, 1e-5 * xt);
             const int n_bins = (int)std::floor(h.nbpl * std::log10(xt / x_lb));
             if (n_bins < 3) {
@@ -212,11 +222,16 @@ int cloudy_plan_create(const cloudy_plan_desc *d, cloudy_plan **out) {
         h.mode = any_finite ? MODE_FIXED : MODE_ALLINF;
     } else {
         h.mode = (N > 1) ? MODE_MOVING : MODE_ALLINF;
-        for (int i = 0; i < N - 1; ++i)
+        for (int i = 0; i < N - 1; ++i) {
             if (!(h.thr[i] >= 0.0 && h.thr[i] <= 1.0)) {
                 delete p;
                 return fail(CLOUDY_EINVAL, "MovingThreshold percentile %d outside [0, 1]", i);
             }
+            if (h.dist_type[i] != CLOUDY_DIST_EXPONENTIAL && h.dist_type[i] != CLOUDY_DIST_GAMMA) {
+                delete p;  // compute_threshold has methods for Exponential and Gamma only (:747-761)
+                return fail(CLOUDY_EINVAL, "no method compute_threshold for dist_type[%d] = %d", i, h.dist_type[i]);
+            }
+        }
     }
 
     // sedimentation velocity, rescaled as the rainshaft caller does (rainshaft_helpers.jl:74-76)

@@ -23,7 +23,7 @@ namespace cloudy {
 
 enum { IN_MOMENTS = 0, IN_PARAMS = 1 };
 enum { MODE_ALLINF = 0, MODE_FIXED = 1, MODE_MOVING = 2 };
-enum { DIST_EXP = 0, DIST_GAMMA = 1 };
+enum { DIST_EXP = 0, DIST_GAMMA = 1, DIST_MONO = 2, DIST_LOGNORMAL = 3 };
 constexpr int kNodeStride = 5;  // x, ln x, x_t - x, ln(x_t - x), w * dx
 constexpr int kBlock = 256;
 
@@ -100,6 +100,24 @@ __device__ __forceinline__ void invert_closure(int dist_type, double m0, double 
     k = m2 + kmin;
     return;
 #endif
+    if (dist_type == DIST_LOGNORMAL) {
+        // ParticleDistributions.jl:483-505: (n, mu, sigma) kept in the (n, theta, k) slots
+        if (m0 > kEps && m1 > kEps && m2 > kEps) {
+            const double mu = log((m1 * m1) / pow(m0, 1.5) / pow(m2, 0.5));
+            const double sg0 = sqrt(log(m0 * m2 / (m1 * m1)));
+            // max(eps, min(Inf, .)); moments with M0 M2 < M1^2 make Julia's sqrt throw a DomainError -- a batch cannot
+            // throw per parcel, so they take the sigma = eps clamp as well (the oracle does the same)
+            const double sg = (sg0 > kEps) ? sg0 : kEps;
+            th = mu;
+            k = sg;
+            n = m1 / exp(mu + 0.5 * (sg * sg));
+        } else {
+            n = 0.0;
+            th = 1.0;
+            k = 1.0;
+        }
+        return;
+    }
     if (m0 > kEps && m1 > kEps) {
         n = m0;
         const double mean = m1 / m0;
@@ -109,7 +127,7 @@ __device__ __forceinline__ void invert_closure(int dist_type, double m0, double 
             double inner = (kk < kmax || kk != kk) ? kk : kmax;
             k = (inner > kmin || inner != inner) ? inner : kmin;
             th = mean / k;
-        } else {
+        } else {  // Exponential :512-523, Monodisperse :530-541
             k = 1.0;
             th = mean;
         }
@@ -120,16 +138,33 @@ __device__ __forceinline__ void invert_closure(int dist_type, double m0, double 
     }
 }
 
-// get_moments_matrix row, Coalescence.jl:187-198: M_q = n theta^q Gamma(q+k)/Gamma(k), q = 0..M-1,
-// columns >= N_mom_max zero.
+// get_moments_matrix row, Coalescence.jl:187-198, columns >= N_mom_max zero.  Integer-order moments by recurrence:
+//   Gamma / Exponential (k = 1):  M_q = n theta^q Gamma(q+k)/Gamma(k)  ->  M_q = M_{q-1} theta (k + q - 1)
+//   Monodisperse:                 M_q = n theta^q                      ->  M_q = M_{q-1} theta
+//   Lognormal (theta = mu, k = sigma): M_q = n exp(q mu + q^2 sigma^2/2) -> M_{q+1}/M_q = e^(mu + sigma^2/2) (e^(sigma^2))^q
 template <int M>
-__device__ __forceinline__ void moment_row(double n, double th, double k, int n_mom_max, double (&Mk)[M]) {
+__device__ __forceinline__ void moment_row(int dist_type, double n, double th, double k, int n_mom_max, double (&Mk)[M]) {
     Mk[0] = n;
+    if (dist_type == DIST_LOGNORMAL) {
+        double ratio = exp(th + 0.5 * (k * k));
+        const double r = exp(k * k);
 #pragma unroll
-    for (int q = 1; q < M; ++q) Mk[q] = Mk[q - 1] * (th * (k + double(q - 1)));
+        for (int q = 1; q < M; ++q) {
+            Mk[q] = Mk[q - 1] * ratio;
+            ratio *= r;
+        }
+    } else {
+        const double base = (dist_type == DIST_MONO) ? 0.0 : k;  // Monodisperse: multiplier theta * 1
+        const double step = (dist_type == DIST_MONO) ? 0.0 : 1.0;
 #pragma unroll
-    for (int q = 0; q < M; ++q)
-        if (q >= n_mom_max) Mk[q] = 0.0;
+        for (int q = 1; q < M; ++q)
+            Mk[q] = Mk[q - 1] * (th * ((dist_type == DIST_MONO) ? 1.0 : (base + step * double(q - 1))));
+    }
+    if (n_mom_max < M) {
+#pragma unroll
+        for (int q = 0; q < M; ++q)
+            if (q >= n_mom_max) Mk[q] = 0.0;
+    }
 }
 
 // Simpson end weights of integrate_SimpsonEvenFast (ParticleDistributions.jl:698-710) as a weight per node
@@ -367,7 +402,7 @@ __device__ __forceinline__ void coal_ints_parcel(const KArgs<N, P> &A, const dou
     constexpr int T = M * (M + 1) / 2;
     double Mm[N][M];
 #pragma unroll
-    for (int i = 0; i < N; ++i) moment_row<M>(nn[i], th[i], kk[i], A.n_mom_max, Mm[i]);
+    for (int i = 0; i < N; ++i) moment_row<M>(A.dist_type[i], nn[i], th[i], kk[i], A.n_mom_max, Mm[i]);
 #pragma unroll
     for (int k = 0; k < N; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.0;
 
@@ -381,7 +416,14 @@ __device__ __forceinline__ void coal_ints_parcel(const KArgs<N, P> &A, const dou
         if (MODE == MODE_FIXED) {
             if (k < N - 1 && A.finite[k]) {  // wave-uniform
                 thresholded = true;
-                if (nn[k] > 0.0)
+                if (A.dist_type[k] == DIST_MONO) {
+                    // moment_source_helper, ParticleDistributions.jl:557-564: n^2 theta^(p1+p2) if theta < x_t/2, else 0
+                    const bool below = th[k] < 0.5 * A.thr[k];
+#pragma unroll
+                    for (int p1 = 0; p1 < M; ++p1)
+#pragma unroll
+                        for (int p2 = p1; p2 < M; ++p2) msh[tri<M>(p1, p2)] = below ? Mm[k][p1] * Mm[k][p2] : 0.0;
+                } else if (nn[k] > 0.0)
                     msh_grid<P>(FixedGrid{nodes + (size_t)A.node_off[k] * kNodeStride, A.n_bins[k]}, A.thr[k], nn[k], th[k],
                                 kk[k], A.dist_type[k] == DIST_GAMMA, Mm[k], msh);
             }
@@ -508,7 +550,7 @@ __device__ __forceinline__ bool load_parcel(const KArgs<N, P> &A, size_t i, size
         for (int m = 0; m < N; ++m) {
             nn[m] = ld_stream(in + (size_t)(3 * m + 0) * ld + i);
             th[m] = ld_stream(in + (size_t)(3 * m + 1) * ld + i);
-            kk[m] = (A.dist_type[m] == DIST_GAMMA) ? ld_stream(in + (size_t)(3 * m + 2) * ld + i) : 1.0;
+            kk[m] = (A.np[m] == 3) ? ld_stream(in + (size_t)(3 * m + 2) * ld + i) : 1.0;
         }
         all_small = false;
     }
@@ -826,7 +868,7 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             double Mk[M];
-            moment_row<M>(nn[k], th[k], kk[k], A.n_mom_max, Mk);
+            moment_row<M>(A.dist_type[k], nn[k], th[k], kk[k], A.n_mom_max, Mk);
             bool thresholded = false;
             double xt = INFINITY;
             double msh[T];
@@ -837,7 +879,13 @@ __global__ void __launch_bounds__(kBlock)
                 if (k < N - 1 && A.finite[k]) {
                     thresholded = true;
                     xt = A.thr[k];
-                    if (nn[k] > 0.0)
+                    if (A.dist_type[k] == DIST_MONO) {
+                        const bool below = th[k] < 0.5 * A.thr[k];
+#pragma unroll
+                        for (int p1 = 0; p1 < M; ++p1)
+#pragma unroll
+                            for (int p2 = p1; p2 < M; ++p2) msh[tri<M>(p1, p2)] = below ? Mk[p1] * Mk[p2] : 0.0;
+                    } else if (nn[k] > 0.0)
                         msh_grid<P>(FixedGrid{nodes + (size_t)A.node_off[k] * kNodeStride, A.n_bins[k]}, A.thr[k], nn[k],
                                     th[k], kk[k], is_gamma, Mk, msh);
                 }
@@ -886,13 +934,22 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
         for (int m = 0; m < N; ++m) {
             const int off = A.off[m];
-            const double lnth = log(th[m]);
-            const double lgk = lgamma(kk[m]);
+            const int dtp = A.dist_type[m];
+            const bool gam = (dtp == DIST_GAMMA || dtp == DIST_EXP);
+            const double lnth = (dtp == DIST_LOGNORMAL) ? th[m] : log(th[m]);
+            const double lgk = gam ? lgamma(kk[m]) : 0.0;
             for (int j = 0; j < A.np[m]; ++j) {
                 double s = 0.0;
                 for (int v = 0; v < S.n_vel; ++v) {
                     const double q = double(j) + S.vel[v][1];
-                    const double mom = nn[m] * exp(fma(q, lnth, lgamma(q + kk[m]) - lgk));
+                    double e;  // log(M_q / n), ParticleDistributions.jl:177-207
+                    if (gam)
+                        e = fma(q, lnth, lgamma(q + kk[m]) - lgk);
+                    else if (dtp == DIST_MONO)
+                        e = q * lnth;
+                    else
+                        e = fma(q, lnth, 0.5 * q * q * (kk[m] * kk[m]));
+                    const double mom = nn[m] * exp(e);
                     s -= S.vel[v][0] * mom;
                 }
                 out[(size_t)(off + j) * ld + i] = (TIO)(s * A.out_scale[3 * m + j]);

@@ -56,8 +56,9 @@ extern "C" {
 #define CLOUDY_MAX_VEL 4    /* terms of the terminal-velocity power series */
 #define CLOUDY_MAX_MOMENTS (3 * CLOUDY_MAX_MODES)
 
-/* distribution families, ParticleDistributions.jl:66-107 */
-enum { CLOUDY_DIST_EXPONENTIAL = 0, CLOUDY_DIST_GAMMA = 1 };
+/* distribution families, ParticleDistributions.jl:66-159.  Parameter planes are (n, theta, k); Monodisperse uses
+ * (n, theta), Lognormal keeps (n, mu, sigma) in the same three slots. */
+enum { CLOUDY_DIST_EXPONENTIAL = 0, CLOUDY_DIST_GAMMA = 1, CLOUDY_DIST_MONODISPERSE = 2, CLOUDY_DIST_LOGNORMAL = 3 };
 /* EquationTypes.jl:20-22 */
 enum { CLOUDY_FIXED_THRESHOLD = 0, CLOUDY_MOVING_THRESHOLD = 1 };
 enum { CLOUDY_F64 = 0, CLOUDY_F32 = 1 };

@@ -42,11 +42,14 @@ def make_case(cloudy, oracle, dist_types, kc, thr, norms, moving=False, k_range=
     if kc.ndim == 2:
         kc = np.broadcast_to(kc, (N, N) + kc.shape).copy()
     kernels = tuple(tuple(cloudy.CoalescenceTensor(kc[j, k]) for k in range(N)) for j in range(N))
-    npm = tuple(3 if t == 1 else 2 for t in dist_types)
+    npm = tuple({0: 2, 1: 3, 2: 2, 3: 3}[t] for t in dist_types)
     ts = cloudy.MovingThreshold() if moving else cloudy.FixedThreshold()
     cd = cloudy.CoalescenceData(kernels, npm, thr, norms, ts)
-    pd = tuple(cloudy.GammaPrimitiveParticleDistribution(1.0, 1.0, 1.0) if t == 1 else
-               cloudy.ExponentialPrimitiveParticleDistribution(1.0, 1.0) for t in dist_types)
+    mk = {0: lambda: cloudy.ExponentialPrimitiveParticleDistribution(1.0, 1.0),
+          1: lambda: cloudy.GammaPrimitiveParticleDistribution(1.0, 1.0, 1.0),
+          2: lambda: cloudy.MonodispersePrimitiveParticleDistribution(1.0, 1.0),
+          3: lambda: cloudy.LognormalPrimitiveParticleDistribution(1.0, 1.0, 1.0)}
+    pd = tuple(mk[t]() for t in dist_types)
     extra = {"vel": vel} if len(vel) else {}
     par = cloudy.ODEParameters(pd, cd, npm, norms, k_range=k_range, **extra)
     op = oracle.make_params(list(dist_types), kc, thr, norms=norms, threshold_style=1 if moving else 0,
@@ -72,7 +75,7 @@ def mixed_moments(dist_types, n, seed):
     full = bench.synth_moments(len(dist_types), n, seed)
     rows = []
     for i, t in enumerate(dist_types):
-        rows += [full[3 * i], full[3 * i + 1]] + ([full[3 * i + 2]] if t == 1 else [])
+        rows += [full[3 * i], full[3 * i + 1]] + ([full[3 * i + 2]] if t in (1, 3) else [])
     return np.ascontiguousarray(np.stack(rows))
 
 
@@ -564,3 +567,44 @@ def test_cfg5_long_kernel_plus_sedimentation_fp32(gpu_cloudy, oracle):
         fin = np.isfinite(wcs.astype(np.float32)) & np.isfinite(wsf.astype(np.float32))
     assert np.all(np.abs(g1 - wcs)[fin] <= 6e-8 * np.abs(wcs[fin]) + 1e-12 * scale[fin] + 1.5e-45)
     assert np.all(np.abs(g2 - wsf)[fin] <= 6e-8 * np.abs(wsf[fin]) + 1.5e-45)
+
+
+@pytest.mark.parametrize("dist_types,thr", [
+    ([2, 1], (5e-10, INF)),          # box_mono_gamma_mixture.jl:14-28: Monodisperse + Gamma, Golovin, thr (5e-10, Inf)
+    ([3], (INF,)),                   # box_single_lognorm.jl:14-24
+    ([1, 3], (5e-10, INF)),          # Gamma cloud mode + Lognormal rain mode
+    ([2, 3, 1], (INF, INF, INF)),
+])
+def test_monodisperse_and_lognormal_closures_vs_oracle(gpu_cloudy, oracle, dist_types, thr):
+    """the other two closure families (ParticleDistributions.jl:193-207, 483-505, 530-541,
+    557-564) wherever the reference needs no adaptive quadrature for them."""
+    cloudy = gpu_cloudy
+    kern = cloudy.CoalescenceTensor(cloudy.LinearKernelFunction(5.0), 1, 1e-6)
+    par, op, _ = make_case(cloudy, oracle, dist_types, kern.c, thr, bench.NORMS)
+    n = 2000
+    mom = mixed_moments(dist_types, n, seed=3)
+    d = run_rhs(cloudy, par, mom)
+    want, scale = oracle.rhs_coal_batch(op, mom, with_scale=True)
+    tol = TOL_QUAD if any(np.isfinite(thr)) else TOL_POLY
+    worst = assert_close_scaled(d, want, scale, tol, f"closures {dist_types}")
+    print(f"closures {dist_types}: max |hip-oracle|/scale = {worst:.2e}")
+    # the closure inversion itself, incl. the Lognormal KAT (10, 50, 300) -> (10, 1.518, 0.427)
+    if dist_types == [3]:
+        plan = par.coal_data.plan([3])
+        kat = np.array([[10.0e6], [50.0e-3], [300.0e-12]])  # physical = normalised x (n0, n0 m0, n0 m0^2)
+        g = cloudy.update_dist_from_moments(plan, dev(cloudy, kat)).to_numpy()[:, 0]
+        assert g[0] == pytest.approx(10.0, rel=1e-3) and g[1] == pytest.approx(1.518, rel=1e-3)
+        assert g[2] == pytest.approx(0.427, rel=1e-3)
+        o = oracle.update_dist_from_moments(3, [10.0, 50.0, 300.0])
+        assert np.allclose(g, [o.n, o.theta, o.k], rtol=1e-14)
+
+
+def test_unsupported_closure_threshold_combinations(gpu_cloudy):
+    cloudy = gpu_cloudy
+    kern = cloudy.CoalescenceTensor([[1.0]])
+    with pytest.raises(cloudy.CloudyError) as e:   # box_lognorm_mixture.jl:27 needs nested quadgk
+        cloudy.CoalescenceData(kern, (3, 3), (5e-10, INF), bench.NORMS).plan([3, 3])
+    assert e.value.code == cloudy._lib.EUNSUPPORTED and "quadgk" in e.value.msg
+    with pytest.raises(cloudy.CloudyError) as e:   # no compute_threshold method for Monodisperse
+        cloudy.CoalescenceData(kern, (2, 3), (0.9, 1.0), bench.NORMS, cloudy.MovingThreshold()).plan([2, 1])
+    assert e.value.code == cloudy._lib.EINVAL

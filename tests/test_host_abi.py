@@ -64,8 +64,8 @@ def test_plan_validation_errors_precede_device_lookup(cloudy):
     assert rc == E.EUNSUPPORTED
     rc, _ = create(lambda d, c: setattr(d, "tensor_p", 6))
     assert rc == E.EUNSUPPORTED
-    rc, _ = create(lambda d, c: d.dist_type.__setitem__(0, 3))
-    assert rc == E.EUNSUPPORTED
+    rc, _ = create(lambda d, c: d.dist_type.__setitem__(0, 9))
+    assert rc == E.EINVAL
     rc, _ = create(lambda d, c: setattr(d, "struct_size", 8))
     assert rc == E.EINVAL
     rc, _ = create(lambda d, c: setattr(d, "dtype", 7))

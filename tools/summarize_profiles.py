@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Condenses gpurun_out/<tag>_* (tools/profile_round.sh) into profiles/<tag>_*: kernel stats CSV, per-kernel PMC
+table (median per dispatch), the HBM traffic JSON that bench.py reports as roofline.traffic, and the bench line."""
+import csv, glob, json, os, shutil, statistics, sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+for f in glob.glob(os.path.join(src, f"{tag}_stats", "*", "*kernel_stats.csv")):
+    shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+for name in ("bench.json", "hbm_ceiling.txt"):
+    f = os.path.join(src, f"{tag}_{name}")
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(dst, f"{tag}_{name}"))
+table = {}
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+    for f in glob.glob(os.path.join(src, f"{tag}_{d}", "*", "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if "cloudy::" not in k:
+                continue
+            short = k.split("cloudy::")[1].split("(")[0]
+            table.setdefault((short, int(r["Grid_Size"])), {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+rows = []
+for (k, grid), cs in sorted(table.items()):
+    row = {"kernel": k, "grid_size": grid}
+    row.update({c: statistics.median(v) for c, v in cs.items()})
+    rows.append(row)
+json.dump(rows, open(os.path.join(dst, f"{tag}_pmc_per_dispatch_median.json"), "w"), indent=1)
+traffic = {}
+for row in rows:
+    if "FETCH_SIZE" in row and "WRITE_SIZE" in row:
+        # gfx950: FETCH_SIZE tallies 128-B requests at 64 B -> x2 for coalesced streaming reads (MI355X_MICROARCH.md, HBM)
+        traffic[f'{row["kernel"]}@{row["grid_size"]}'] = {
+            "fetch_size_kib": row["FETCH_SIZE"], "write_size_kib": row["WRITE_SIZE"],
+            "hbm_bytes_per_launch": 2 * row["FETCH_SIZE"] * 1024 + row["WRITE_SIZE"] * 1024}
+json.dump(traffic, open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w"), indent=1)
+print(json.dumps(traffic, indent=1))
