@@ -21,3 +21,16 @@ def rainshaft_sources(plan, mom, coal_source=None, sedi_flux=None, stream=None):
     sf = sedi_flux if sedi_flux is not None else DeviceArray(plan.nmom, n, dt)
     _lib.check(_lib.lib().cloudy_rainshaft_sources(plan.handle, n, ld, ptr, as_device(cs)[0], as_device(sf)[0], stream))
     return cs, sf
+
+
+def rhs_condensation(plan, dmom, mom, xi, s, stream=None):
+    """rhs_condensation!(dmom, mom, p, s) (box_model_helpers.jl:55-67) -> get_cond_evap (Condensation.jl:22-37),
+    batched.  `s`: scalar supersaturation or an (1, n) fp64 device array (one value per parcel); xi = p.xi."""
+    ptr, planes, n, ld = as_device(mom)
+    optr = as_device(dmom)[0]
+    if hasattr(s, "data_ptr") or isinstance(s, DeviceArray):
+        sptr, sval = as_device(s)[0], 0.0
+    else:
+        sptr, sval = None, float(s)
+    _lib.check(_lib.lib().cloudy_cond_evap(plan.handle, n, ld, ptr, sptr, sval, float(xi), optr, stream))
+    return dmom

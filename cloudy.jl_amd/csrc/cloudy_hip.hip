@@ -386,6 +386,19 @@ int cloudy_sedimentation_flux(const cloudy_plan *plan, size_t n, size_t ld, cons
     return run(plan, r);
 }
 
+int cloudy_cond_evap(const cloudy_plan *plan, size_t n, size_t ld, const void *mom_dev, const double *s_dev, double s,
+                     double xi, void *dmom_dev, void *stream) {
+    int rc = check_batch(plan, n, ld, mom_dev, dmom_dev);
+    if (rc) return rc;
+    LaunchReq r{OP_COND, IN_MOMENTS, 1, 0, n, ld, mom_dev, dmom_dev, nullptr, (hipStream_t)stream};
+    // rhs_condensation!: xi_normalized = p.xi / norms[2]^(2/3) (box_model_helpers.jl:65); rho_l = 1000 (Condensation.jl:26)
+    const double xi_n = xi / std::pow(plan->h.norms[1], 2.0 / 3.0);
+    r.coef = 3 * xi_n * std::pow(4 * M_PI / 3, 2.0 / 3.0) / std::pow(1000.0, 1.0 / 3.0);
+    r.s_scalar = s;
+    r.s_dev = s_dev;
+    return run(plan, r);
+}
+
 int cloudy_rainshaft_sources(const cloudy_plan *plan, size_t n, size_t ld, const void *mom_dev, void *coal_source_dev,
                              void *sedi_flux_dev, void *stream) {
     int rc = check_batch(plan, n, ld, mom_dev, coal_source_dev);

@@ -30,7 +30,7 @@ struct HostPlan {
     double *partial_dev = nullptr;                      // moment_sums workspace
 };
 
-enum Op { OP_COAL = 0, OP_UPDATE_DIST = 1, OP_FINITE_2D = 2, OP_SEDI = 3, OP_SSPRK33 = 4 };
+enum Op { OP_COAL = 0, OP_UPDATE_DIST = 1, OP_FINITE_2D = 2, OP_SEDI = 3, OP_SSPRK33 = 4, OP_COND = 5 };
 
 struct LaunchReq {
     int op;
@@ -44,6 +44,8 @@ struct LaunchReq {
     hipStream_t stream;
     double dt = 0.0;  // OP_SSPRK33
     int n_steps = 0;  // OP_SSPRK33
+    double coef = 0.0, s_scalar = 0.0;  // OP_COND
+    const double *s_dev = nullptr;      // OP_COND (optional per-parcel supersaturation)
 };
 
 // one per instantiation unit (inst_n1.hip ... inst_n4.hip)

@@ -958,4 +958,40 @@ __global__ void __launch_bounds__(kBlock)
     }
 }
 
+// get_cond_evap, src/Sources/Condensation.jl:22-37, behind rhs_condensation! (box_model_helpers.jl:55-67):
+//   d(mom_j)/dt = 3 xi s j M_{j - 2/3} (4 pi/3)^(2/3) / rho_l^(1/3)   (0-based order j; zero for j = 0)
+// `coef` = 3 xi_normalised (4 pi/3)^(2/3) / rho_l^(1/3) is folded on the host; s is a scalar or one value per parcel.
+template <int N, int P, typename TIO>
+__global__ void __launch_bounds__(kBlock)
+    cond_evap_kernel(const KArgs<N, P> A, double coef, double s_scalar, const double *__restrict__ s_dev, size_t n,
+                     size_t ld, const TIO *__restrict__ in, TIO *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) {
+        double nn[N], th[N], kk[N];
+        load_parcel<N, P, TIO>(A, i, ld, in, nn, th, kk);
+        const double sv = s_dev ? s_dev[i] : s_scalar;
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+            const int off = A.off[m];
+            const int dtp = A.dist_type[m];
+            const bool gam = (dtp == DIST_GAMMA || dtp == DIST_EXP);
+            const double lnth = (dtp == DIST_LOGNORMAL) ? th[m] : log(th[m]);
+            const double lgk = gam ? lgamma(kk[m]) : 0.0;
+            out[(size_t)off * ld + i] = (TIO)0.0;
+            for (int j = 1; j < A.np[m]; ++j) {
+                const double q = double(j) - 2.0 / 3.0;
+                double e;
+                if (gam)
+                    e = fma(q, lnth, lgamma(q + kk[m]) - lgk);
+                else if (dtp == DIST_MONO)
+                    e = q * lnth;
+                else
+                    e = fma(q, lnth, 0.5 * q * q * (kk[m] * kk[m]));
+                const double mom = nn[m] * exp(e);
+                out[(size_t)(off + j) * ld + i] = (TIO)(coef * sv * double(j) * mom * A.out_scale[3 * m + j]);
+            }
+        }
+    }
+}
+
 }  // namespace cloudy

@@ -79,6 +79,10 @@ hipError_t launch_io(const HostPlan &h, const LaunchReq &r, const KArgs<N, P> &A
                            r.n, r.ld, in, out);
         break;
     }
+    case OP_COND:
+        hipLaunchKernelGGL((cond_evap_kernel<N, P, TIO>), dim3(grid_for(r.n, false)), dim3(kBlock), 0, r.stream, A,
+                           r.coef, r.s_scalar, r.s_dev, r.n, r.ld, in, out);
+        break;
     case OP_SSPRK33: {
         const unsigned g = grid_for(r.n, heavy);
         if (h.mode == MODE_ALLINF)
@@ -105,6 +109,7 @@ hipError_t launch_np(const HostPlan &h, const LaunchReq &r) {
     switch (r.op) {
     case OP_COAL:
     case OP_SEDI:
+    case OP_COND:
     case OP_SSPRK33:
         // get_coal_ints on (n, theta, k) planes is an fp64 interface for every plan
         if (h.dtype == CLOUDY_F32 && r.input_kind == IN_MOMENTS) return launch_io<N, P, float>(h, r, A);

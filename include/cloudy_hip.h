@@ -22,6 +22,8 @@
  *   cloudy_sedimentation_flux     <- get_sedimentation_flux(pdists, vel)   src/Sources/Sedimentation.jl:22-37
  *   cloudy_rainshaft_sources      <- the per-cell body of make_rainshaft_rhs
  *                                    test/examples/utils/rainshaft_helpers.jl:52-78
+ *   cloudy_cond_evap              <- rhs_condensation!(dmom, mom, p, s) / get_cond_evap
+ *                                    test/examples/utils/box_model_helpers.jl:55-67, src/Sources/Condensation.jl:22-37
  *   cloudy_ssprk33_steps          <- solve(ODEProblem(rhs, m0, tspan, p), SSPRK33(), dt = p.dt) of the drivers,
  *                                    test/examples/Analytical/box_single_gamma.jl:35-36 (OrdinaryDiffEq stepping)
  *   cloudy_moment_sums            <- moments_sum diagnostic, test/examples/utils/plotting_helpers.jl:240-252
@@ -147,6 +149,12 @@ int cloudy_compute_thresholds(const cloudy_plan *plan, size_t n_parcels, size_t 
 /* sedimentation flux of every prognostic moment, physical units (plan must have n_vel > 0) */
 int cloudy_sedimentation_flux(const cloudy_plan *plan, size_t n_parcels, size_t ld, const void *mom_dev,
                               void *flux_dev, void *stream);
+
+/* condensation / evaporation tendency of every prognostic moment, rhs_condensation!(dmom, mom, p, s)
+ * (test/examples/utils/box_model_helpers.jl:55-67 -> get_cond_evap, src/Sources/Condensation.jl:22-37).
+ * xi = p.xi in physical units; supersaturation s per parcel (s_dev, fp64, n values) or, if s_dev is NULL, `s`. */
+int cloudy_cond_evap(const cloudy_plan *plan, size_t n_parcels, size_t ld, const void *mom_dev, const double *s_dev,
+                     double s, double xi, void *dmom_dev, void *stream);
 
 /* coalescence source and sedimentation flux of each cell in one fused pass
  * (negative moments clamped to zero, empty cells skipped) */

@@ -726,6 +726,23 @@ void co_get_sedimentation_flux(const co_dist *pdists, int N, const double (*vel)
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* src/Sources/Condensation.jl:22-37                                                           */
+/* ------------------------------------------------------------------------------------------ */
+void co_get_cond_evap(const co_dist *pdists, int N, double s, double xi, double rho_l, double *out) {
+    int idx = 0;
+    for (int i = 0; i < N; ++i) {
+        int np = co_nparams(pdists[i].type);
+        for (int j = 1; j <= np; ++j) {
+            if (j < 2)
+                out[idx++] = 0.0;
+            else /* 3 * xi * s * (j - 1) * moment(pdist, j - 1 - 2/3) * (4pi/3)^(2/3) / rho_l^(1/3) */
+                out[idx++] = 3 * xi * s * (j - 1) * co_moment(&pdists[i], (double)j - 1.0 - 2.0 / 3.0) *
+                             pow(4 * M_PI / 3, 2.0 / 3.0) / pow(rho_l, 1.0 / 3.0);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* test/examples/utils/box_model_helpers.jl:29-53  rhs_coal!                                    */
 /* ------------------------------------------------------------------------------------------ */
 static int co_invert_all(const co_params *p, const double *mom_normalized, co_dist *pdists) {
@@ -750,6 +767,33 @@ int co_rhs_coal(const co_params *p, const double *mom, double *dmom, double *sca
     for (int q = 0; q < nmom; ++q) {
         dmom[q] = coal_ints[q] * mom_norms[q]; /* :52 */
         if (scale) scale[q] *= mom_norms[q];
+    }
+    return nmom;
+}
+
+/* rhs_condensation!, box_model_helpers.jl:55-67: xi_normalized = p.xi / norms[2]^(2/3) */
+int co_rhs_condensation(const co_params *p, double xi, double s, const double *mom, double *dmom) {
+    double mom_norms[CO_MAX_MODES * 3], mom_normalized[CO_MAX_MODES * 3], ce[CO_MAX_MODES * 3];
+    co_dist pdists[CO_MAX_MODES];
+    int nmom = co_get_moments_normalizing_factors(p->NProgMoms, p->N, p->norms, mom_norms);
+    if (nmom < 0) return -1;
+    for (int q = 0; q < nmom; ++q) mom_normalized[q] = mom[q] / mom_norms[q];
+    if (co_invert_all(p, mom_normalized, pdists) < 0) return -1;
+    double xi_normalized = xi / pow(p->norms[1], 2.0 / 3.0);
+    co_get_cond_evap(pdists, p->N, s, xi_normalized, 1000.0, ce);
+    for (int q = 0; q < nmom; ++q) dmom[q] = ce[q] * mom_norms[q];
+    return nmom;
+}
+
+int co_rhs_condensation_batch(const co_params *p, double xi, const double *s_per_parcel, double s_scalar, long n,
+                              long ld, const double *mom, double *dmom) {
+    int nmom = 0;
+    for (int i = 0; i < p->N; ++i) nmom += p->NProgMoms[i];
+    for (long i = 0; i < n; ++i) {
+        double m[CO_MAX_MODES * 3], d[CO_MAX_MODES * 3];
+        for (int q = 0; q < nmom; ++q) m[q] = mom[(size_t)q * ld + i];
+        co_rhs_condensation(p, xi, s_per_parcel ? s_per_parcel[i] : s_scalar, m, d);
+        for (int q = 0; q < nmom; ++q) dmom[(size_t)q * ld + i] = d[q];
     }
     return nmom;
 }

@@ -114,6 +114,12 @@ double co_weighting_fn(double x, int k, const co_dist *pdists, int N);         /
 /* ---- Sedimentation.jl ---- */
 void co_get_sedimentation_flux(const co_dist *pdists, int N, const double (*vel)[2], int n_vel, double *out);
 
+/* ---- Condensation.jl / rhs_condensation! (box_model_helpers.jl:55-67) ---- */
+void co_get_cond_evap(const co_dist *pdists, int N, double s, double xi, double rho_l, double *out);
+int co_rhs_condensation(const co_params *p, double xi, double s, const double *mom, double *dmom);
+int co_rhs_condensation_batch(const co_params *p, double xi, const double *s_per_parcel, double s_scalar, long n,
+                              long ld, const double *mom, double *dmom);
+
 /* ---- box_model_helpers.jl rhs_coal!, one parcel and a moment-major SoA batch ---- */
 int co_rhs_coal(const co_params *p, const double *mom, double *dmom, double *scale);
 int co_rhs_coal_batch(const co_params *p, long n_parcels, long ld, const double *mom, double *dmom,

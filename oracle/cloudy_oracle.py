@@ -105,6 +105,8 @@ def lib():
         L.co_weighting_fn.restype = C.c_double
         L.co_weighting_fn.argtypes = [C.c_double, C.c_int, C.POINTER(Dist), C.c_int]
         L.co_get_sedimentation_flux.argtypes = [C.POINTER(Dist), C.c_int, _dp, C.c_int, _dp]
+        L.co_get_cond_evap.argtypes = [C.POINTER(Dist), C.c_int, C.c_double, C.c_double, C.c_double, _dp]
+        L.co_rhs_condensation_batch.argtypes = [C.POINTER(Params), C.c_double, _dp, C.c_double, C.c_long, C.c_long, _dp, _dp]
         L.co_rhs_coal.argtypes = [C.POINTER(Params), _dp, _dp, _dp]
         L.co_rhs_coal_batch.argtypes = [C.POINTER(Params), C.c_long, C.c_long, _dp, _dp, _dp, C.c_int]
         L.co_rainshaft_cell_batch.argtypes = [C.POINTER(Params), C.c_long, C.c_long, _dp, _dp, _dp, C.c_int]
@@ -303,6 +305,25 @@ def get_sedimentation_flux(pdists, vel):
     out = np.zeros(nm)
     lib().co_get_sedimentation_flux(arr, len(pdists), _d(v), v.shape[0], _d(out))
     return out
+
+
+def get_cond_evap(pdists, s, xi, rho_l=1000.0):
+    arr = (Dist * len(pdists))(*pdists)
+    nm = sum(nparams(d.type) for d in pdists)
+    out = np.zeros(nm)
+    lib().co_get_cond_evap(arr, len(pdists), float(s), float(xi), float(rho_l), _d(out))
+    return out
+
+
+def rhs_condensation_batch(p, xi, s, mom):
+    """rhs_condensation! (box_model_helpers.jl:55-67) for a batch; s scalar or per-parcel array."""
+    m = _darr(mom)
+    nm, n = m.shape
+    d = np.empty_like(m)
+    sa = _darr(s) if np.ndim(s) else None
+    lib().co_rhs_condensation_batch(C.byref(p), float(xi), _d(sa) if sa is not None else None,
+                                    0.0 if sa is not None else float(s), n, n, _d(m), _d(d))
+    return d
 
 
 # ---- box_model_helpers.jl / rainshaft_helpers.jl --------------------------------------------

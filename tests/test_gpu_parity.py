@@ -608,3 +608,32 @@ def test_unsupported_closure_threshold_combinations(gpu_cloudy):
     with pytest.raises(cloudy.CloudyError) as e:   # no compute_threshold method for Monodisperse
         cloudy.CoalescenceData(kern, (2, 3), (0.9, 1.0), bench.NORMS, cloudy.MovingThreshold()).plan([2, 1])
     assert e.value.code == cloudy._lib.EINVAL
+
+
+def test_condensation_rhs_vs_oracle(gpu_cloudy, oracle, kats):
+    """rhs_condensation! (condensation_single_gamma.jl:17-27: s = 0.05, xi = 1e-8; condensation_exp_gamma.jl) batched,
+    scalar and per-parcel supersaturation, all four closure families."""
+    cloudy = gpu_cloudy
+    dist_types = [0, 1, 2, 3]
+    par, op, _ = make_case(cloudy, oracle, dist_types, [[1.0]], (INF,) * 4, bench.NORMS)
+    plan = par.coal_data.plan(dist_types)
+    n = 3000
+    mom = mixed_moments(dist_types, n, seed=12)
+    m = dev(cloudy, mom)
+    dm = cloudy.DeviceArray.zeros(*mom.shape)
+    xi, s = 1e-8, 0.05
+    cloudy.rhs_condensation(plan, dm, m, xi, s)
+    want = oracle.rhs_condensation_batch(op, xi, s, mom)
+    assert np.allclose(dm.to_numpy(), want, rtol=1e-11, atol=0)
+    rng = np.random.default_rng(0)
+    s_arr = rng.uniform(-0.02, 0.05, n)
+    cloudy.rhs_condensation(plan, dm, m, xi, dev(cloudy, s_arr[None, :]))
+    want = oracle.rhs_condensation_batch(op, xi, s_arr, mom)
+    assert np.allclose(dm.to_numpy(), want, rtol=1e-11, atol=0)
+    assert np.all(dm.to_numpy()[[0, 2, 5, 7]] == 0.0)  # number is not changed by condensation
+    # reference KAT (test_Sources_correctness.jl:274-283): Exp(1,1), norms (1,1)
+    cd = cloudy.CoalescenceData(cloudy.CoalescenceTensor([[1.0]]), (2,), (INF,))
+    out = cloudy.DeviceArray.zeros(2, 4)
+    cloudy.rhs_condensation(cd.plan([0]), out, dev(cloudy, np.ones((2, 4))), 1e-6, 0.01)
+    C = (4 * math.pi / 3) ** (2 / 3) / 1000.0 ** (1 / 3)
+    assert np.allclose(out.to_numpy()[:, 0], [0.0, 3 * 1e-6 * 0.01 * math.gamma(4 / 3) * C], rtol=1e-13, atol=0)

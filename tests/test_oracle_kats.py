@@ -332,3 +332,20 @@ def test_rhs_coal_batch_matches_single(oracle):
     # small difference of large Q/R/S terms, so the residual is measured against `scale`,
     # the sum of |terms| the oracle reports per output.
     assert np.all(np.abs(d[1] + d[4]) <= 1e-12 * scale[1])
+
+
+def test_condensation_kats(oracle, kats):
+    """test_Sources_correctness.jl:274-308: get_cond_evap closed forms (moments via the oracle's own moment())."""
+    C = (4 * math.pi / 3) ** (2 / 3) / 1000.0 ** (1 / 3)
+    for e in kats["condensation"]:
+        pd = [mk(oracle, s) for s in e["pdists"]]
+        got = oracle.get_cond_evap(pd, e["s"], e["xi"])
+        want = []
+        for d in pd:
+            want.append(0.0)
+            for j in range(1, oracle.nparams(d.type)):
+                want.append(3 * j * e["xi"] * e["s"] * oracle.moment(d, j - 2 / 3) * C)
+        assert np.allclose(got, want, rtol=1.5e-8, atol=0)
+    # independent value of the fractional moment: Exp(1,1): M_{1/3} = Gamma(4/3)
+    got = oracle.get_cond_evap([mk(oracle, ["exponential", 1.0, 1.0])], 0.01, 1e-6)
+    assert got[1] == pytest.approx(3 * 1e-6 * 0.01 * math.gamma(4 / 3) * C, rel=1e-14)
