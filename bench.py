@@ -84,7 +84,7 @@ def workload_spec(name):
 def kernel_matrix(spec):
     """[N, N, P, P] un-normalised coefficient tensors (physical units)."""
     N = spec["n_modes"]
-    eps = float(np.finfo(np.float64).eps)
+    eps = float(np.finfo(np.float64).eps) / NORMS[0]  # forced constant term C_1_1 = eps (normalised), KernelTensors.jl:115
     if spec["kernel"] == "golovin":
         c = np.array([[eps, 5.0], [5.0, 0.0]])  # CoalescenceTensor(LinearKernelFunction(5.0), 1, 1e-6): C_1_1 = eps
         return np.broadcast_to(c, (N, N, 2, 2)).copy()

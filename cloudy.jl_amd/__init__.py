@@ -15,7 +15,7 @@ from .helper_functions import (get_dist_moment_ind, get_dist_moments_ind_range, 
                                rflatten)
 from .KernelFunctions import (ConstantKernelFunction, HydrodynamicKernelFunction, LinearKernelFunction,
                               LongKernelFunction, get_normalized_kernel_func)
-from .KernelTensors import CoalescenceTensor, check_symmetry, get_normalized_kernel_tensor
+from .KernelTensors import CoalescenceTensor, check_symmetry, get_normalized_kernel_tensor, polyfit
 from .ParticleDistributions import (ExponentialPrimitiveParticleDistribution, GammaPrimitiveParticleDistribution,
                                     LognormalPrimitiveParticleDistribution, MonodispersePrimitiveParticleDistribution,
                                     compute_thresholds, get_moments, nparams, pack_params, update_dist_from_moments)

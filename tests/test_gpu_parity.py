@@ -637,3 +637,25 @@ def test_condensation_rhs_vs_oracle(gpu_cloudy, oracle, kats):
     cloudy.rhs_condensation(cd.plan([0]), out, dev(cloudy, np.ones((2, 4))), 1e-6, 0.01)
     C = (4 * math.pi / 3) ** (2 / 3) / 1000.0 ** (1 / 3)
     assert np.allclose(out.to_numpy()[:, 0], [0.0, 3 * 1e-6 * 0.01 * math.gamma(4 / 3) * C], rtol=1e-13, atol=0)
+
+
+def test_hydrodynamic_order4_tensor_config(gpu_cloudy, oracle):
+    """BASELINE configs[3] in the reference's own formulation: the hydrodynamic kernel enters as an
+    order-4 fitted CoalescenceTensor (box_gamma_mixture_hydro.jl:22-29: E = 1e2 pi, limit 1e-6, thr (4e-9, Inf));
+    here with three Gamma modes and thresholds (1e-9, 1e-7, Inf) (box_gamma_mixture_3modes.jl:29), 9 moments.  The
+    fitted tensor is an INPUT to both sides."""
+    cloudy = gpu_cloudy
+    t = cloudy.CoalescenceTensor(cloudy.HydrodynamicKernelFunction(1e2 * np.pi), 4, 1e-6)
+    for dist_types, thr, n in (([1, 1], (4e-9, INF), 1500), ([1, 1, 1], (1e-9, 1e-7, INF), 1000)):
+        par, op, _ = make_case(cloudy, oracle, dist_types, t.c, thr, bench.NORMS)
+        mom = mixed_moments(dist_types, n, seed=8)
+        d = run_rhs(cloudy, par, mom)
+        want, scale = oracle.rhs_coal_batch(op, mom, with_scale=True)
+        worst = assert_close_scaled(d, want, scale, TOL_QUAD, f"hydro N={len(dist_types)}")
+        print(f"hydro order-4, N={len(dist_types)}: max |hip-oracle|/scale = {worst:.2e}")
+    # the example's own initial condition, one box
+    par, op, _ = make_case(cloudy, oracle, [1, 1], t.c, (4e-9, INF), bench.NORMS)
+    u0 = np.array([1e8, 1e-2, 2e-12, 1.0, 3e-9, 12e-18])[:, None].repeat(4, axis=1)
+    d = run_rhs(cloudy, par, u0)
+    want, scale = oracle.rhs_coal_batch(op, u0, with_scale=True)
+    assert_close_scaled(d, want, scale, TOL_QUAD, "hydro example IC")

@@ -136,13 +136,14 @@ def test_kernel_tensor_and_function_kats(cloudy, kats, oracle):
         assert k(e["x"], e["y"]) == k(e["y"], e["x"])
     # exact tensors of polynomial kernels, with the forced C_1_1 = max(eps, K(0,0)) of KernelTensors.jl:115
     eps = np.finfo(np.float64).eps
+    # (the constant is forced in normalised units, default norms (1e6, 1e-9): eps / 1e6 after de-normalisation)
     t = cloudy.CoalescenceTensor(cloudy.LinearKernelFunction(5e-3), 1, 10.0)
-    assert np.array_equal(t.c, [[eps, 5e-3], [5e-3, 0.0]])
+    assert np.array_equal(t.c, [[eps / 1e6, 5e-3], [5e-3, 0.0]])
     lk = cloudy.LongKernelFunction(5.236e-10, 9.44e9, 5.78)   # box_gamma_mixture_long.jl:20-30
-    assert np.array_equal(cloudy.CoalescenceTensor(lk, 2, 5e-10).c, [[eps, 0, 9.44e9], [0, 0, 0], [9.44e9, 0, 0]])
-    assert np.array_equal(cloudy.CoalescenceTensor(lk, 2, 1e-6, 5e-10).c, [[eps, 5.78, 0], [5.78, 0, 0], [0, 0, 0]])
-    with pytest.raises(NotImplementedError):
-        cloudy.CoalescenceTensor(cloudy.HydrodynamicKernelFunction(1.0), 4, 1e-6)
+    e6 = eps / 1e6
+    assert np.array_equal(cloudy.CoalescenceTensor(lk, 2, 5e-10).c, [[e6, 0, 9.44e9], [0, 0, 0], [9.44e9, 0, 0]])
+    assert np.array_equal(cloudy.CoalescenceTensor(lk, 2, 1e-6, 5e-10).c, [[e6, 5.78, 0], [5.78, 0, 0], [0, 0, 0]])
+    assert cloudy.CoalescenceTensor(cloudy.ConstantKernelFunction(1.0), 0, 100.0).c[0, 0] == 1.0
 
 
 def test_coalescence_data_fields_match_oracle(cloudy, oracle):
@@ -195,3 +196,25 @@ def test_synthetic_workload_is_deterministic_and_degenerate_cases_present():
     var = a[2] / a[1] - a[1] / a[0]
     with np.errstate(invalid="ignore", divide="ignore"):
         assert (var < 0).sum() > 0 and (np.abs(var) < 1e-25).sum() > 0
+
+
+def test_polyfit_reference_kats(cloudy):
+    """test_KernelTensors_correctness.jl:17-20, 36-46 (rtol 1e-5 there: Nelder-Mead; the direct least-squares solve
+    here is exact for polynomial targets)."""
+    t = cloudy.CoalescenceTensor(lambda x, y: 0.02 + x + y, 1, 10.0)
+    assert np.allclose(t.c, [[0.02, 1.0], [1.0, 0.0]], rtol=1e-5, atol=1e-12)
+    assert np.allclose(cloudy.polyfit(lambda x, y: 0.1 + 0.2 * x * y, 1, 10.0), [[0.1, 0.0], [0.0, 0.2]], rtol=1e-5, atol=1e-12)
+    f = lambda x, y: 0.1 - 0.23 * x - 0.23 * y + 0.2 * x * y  # noqa: E731
+    for lim in (10.0, 100.0, 1000.0):
+        assert np.allclose(cloudy.polyfit(f, 1, lim), [[0.1, -0.23], [-0.23, 0.2]], rtol=1e-5, atol=0)
+    with pytest.raises(ValueError):
+        cloudy.polyfit(lambda x, y: x - y, 1, 10.0)        # "function likely not symmetric."
+    with pytest.raises(ValueError):
+        cloudy.polyfit(f, 1, 1.0, 2.0)                      # limits improperly specified
+    # type-stability KAT (:56-61): a linear kernel fitted at order 1 is a 2 x 2 symmetric tensor
+    t = cloudy.CoalescenceTensor(cloudy.LinearKernelFunction(5.0), 1, 5e-10)
+    assert t.c.shape == (2, 2) and t.c[0, 1] == t.c[1, 0] == 5.0
+    # the hydrodynamic kernel of box_gamma_mixture_hydro.jl:22-23 (order 4): symmetric, C_1_1 = eps / n0
+    h = cloudy.CoalescenceTensor(cloudy.HydrodynamicKernelFunction(1e2 * np.pi), 4, 1e-6)
+    assert h.c.shape == (5, 5) and np.array_equal(h.c, h.c.T)
+    assert h.c[0, 0] == np.finfo(np.float64).eps / 1e6
