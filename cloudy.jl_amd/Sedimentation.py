@@ -34,3 +34,27 @@ def rhs_condensation(plan, dmom, mom, xi, s, stream=None):
         sptr, sval = None, float(s)
     _lib.check(_lib.lib().cloudy_cond_evap(plan.handle, n, ld, ptr, sptr, sval, float(xi), optr, stream))
     return dmom
+
+
+def make_rainshaft_rhs(coal_type=None):
+    """make_rainshaft_rhs(coal_type) (rainshaft_helpers.jl:45-89): returns rhs(m, p, t) -> d(m)/dt for a column
+    (or a batch of columns stacked along the cell axis, `p.nz` cells each) -- coalescence source plus the upwind
+    divergence of the sedimentation flux.  `m` is an (nmom, nz * n_columns) device array; `p` carries coal_data,
+    pdists, NProgMoms, norms, vel and dz."""
+    from .box_model import _plan_for
+    from .device import dtype_code
+
+    def rhs(m, p, t, out=None, work=None):
+        plan = _plan_for(p, dtype_code(m))
+        ptr, planes, n, ld = as_device(m)
+        nz = int(getattr(p, "nz", n))
+        if n % nz:
+            raise ValueError("number of cells must be a multiple of p.nz")
+        dt = np.float32 if plan.dtype == 1 else np.float64
+        o = out if out is not None else DeviceArray(plan.nmom, n, dt)
+        w = work if work is not None else DeviceArray(plan.nmom, n, dt)
+        _lib.check(_lib.lib().cloudy_rainshaft_rhs(plan.handle, nz, n // nz, ld, ptr, float(p.dz), as_device(w)[0],
+                                                  as_device(o)[0], None))
+        return o
+
+    return rhs

@@ -416,6 +416,25 @@ int cloudy_rainshaft_sources(const cloudy_plan *plan, size_t n, size_t ld, const
     return run(plan, r2);
 }
 
+int cloudy_rainshaft_rhs(const cloudy_plan *plan, size_t nz, size_t n_columns, size_t ld, const void *mom_dev, double dz,
+                         void *flux_work_dev, void *rhs_dev, void *stream) {
+    const size_t n = nz * n_columns;
+    int rc = check_batch(plan, n, ld, mom_dev, rhs_dev);
+    if (rc) return rc;
+    if (nz < 1 || !(dz > 0)) return fail(CLOUDY_EINVAL, "nz must be >= 1 and dz positive");
+    rc = cloudy_rainshaft_sources(plan, n, ld, mom_dev, rhs_dev, flux_work_dev, stream);
+    if (rc || n == 0) return rc;
+    const unsigned g = (unsigned)((n + kBlock - 1) / kBlock);
+    if (plan->h.dtype == CLOUDY_F32)
+        hipLaunchKernelGGL(rainshaft_divergence_kernel<float>, dim3(g), dim3(kBlock), 0, (hipStream_t)stream, n, ld,
+                           plan->h.nmom, nz, 1.0 / dz, (const float *)flux_work_dev, (float *)rhs_dev);
+    else
+        hipLaunchKernelGGL(rainshaft_divergence_kernel<double>, dim3(g), dim3(kBlock), 0, (hipStream_t)stream, n, ld,
+                           plan->h.nmom, nz, 1.0 / dz, (const double *)flux_work_dev, (double *)rhs_dev);
+    HIP_TRY(hipGetLastError());
+    return CLOUDY_OK;
+}
+
 int cloudy_moment_sums(const cloudy_plan *plan, size_t n, size_t ld, int planes, const void *arr_dev, double *sums_dev,
                        void *stream) {
     if (!plan) return fail(CLOUDY_EINVAL, "plan is NULL");

@@ -49,4 +49,21 @@ __global__ void __launch_bounds__(kBlock)
     }
 }
 
+// Upwind flux divergence of make_rainshaft_rhs (test/examples/utils/rainshaft_helpers.jl:80-86), columns of nz cells
+// stored contiguously (cell index fastest): rhs[q][i] = coal[q][i] - (flux[q][i+1] - flux[q][i]) / dz, flux above the
+// top cell of a column = 0.  `rhs` holds the coalescence source on entry.
+template <typename TIO>
+__global__ void __launch_bounds__(kBlock)
+    rainshaft_divergence_kernel(size_t n, size_t ld, int planes, size_t nz, double inv_dz, const TIO *__restrict__ flux,
+                                TIO *__restrict__ rhs) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const bool top = ((i % nz) == nz - 1);
+    for (int q = 0; q < planes; ++q) {
+        const double f0 = (double)flux[(size_t)q * ld + i];
+        const double f1 = top ? 0.0 : (double)flux[(size_t)q * ld + i + 1];
+        rhs[(size_t)q * ld + i] = (TIO)((double)rhs[(size_t)q * ld + i] + (-(f1 - f0) * inv_dz));
+    }
+}
+
 }  // namespace cloudy

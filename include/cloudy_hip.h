@@ -22,6 +22,8 @@
  *   cloudy_sedimentation_flux     <- get_sedimentation_flux(pdists, vel)   src/Sources/Sedimentation.jl:22-37
  *   cloudy_rainshaft_sources      <- the per-cell body of make_rainshaft_rhs
  *                                    test/examples/utils/rainshaft_helpers.jl:52-78
+ *   cloudy_rainshaft_rhs          <- rhs(m, p, t) of make_rainshaft_rhs incl. the flux divergence
+ *                                    test/examples/utils/rainshaft_helpers.jl:45-89
  *   cloudy_cond_evap              <- rhs_condensation!(dmom, mom, p, s) / get_cond_evap
  *                                    test/examples/utils/box_model_helpers.jl:55-67, src/Sources/Condensation.jl:22-37
  *   cloudy_ssprk33_steps          <- solve(ODEProblem(rhs, m0, tspan, p), SSPRK33(), dt = p.dt) of the drivers,
@@ -160,6 +162,13 @@ int cloudy_cond_evap(const cloudy_plan *plan, size_t n_parcels, size_t ld, const
  * (negative moments clamped to zero, empty cells skipped) */
 int cloudy_rainshaft_sources(const cloudy_plan *plan, size_t n_cells, size_t ld, const void *mom_dev,
                              void *coal_source_dev, void *sedi_flux_dev, void *stream);
+
+/* the full right-hand side of make_rainshaft_rhs (rainshaft_helpers.jl:45-89) for n_columns columns of nz cells
+ * (cell index fastest, bottom to top): coalescence source + upwind divergence of the sedimentation flux,
+ * rhs[i] = coal[i] - (flux[i+1] - flux[i]) / dz with zero flux above the top cell.  flux_work_dev: nmom planes of
+ * scratch (holds the cell fluxes on return). */
+int cloudy_rainshaft_rhs(const cloudy_plan *plan, size_t nz, size_t n_columns, size_t ld, const void *mom_dev, double dz,
+                         void *flux_work_dev, void *rhs_dev, void *stream);
 
 /* sums_dev[q] = sum over parcels of plane q (fp64 accumulate); `planes` planes are reduced.
  * The multi-GPU conservation check all-reduces these nmom doubles (RCCL), see INTEGRATION.md. */

@@ -659,3 +659,30 @@ def test_hydrodynamic_order4_tensor_config(gpu_cloudy, oracle):
     d = run_rhs(cloudy, par, u0)
     want, scale = oracle.rhs_coal_batch(op, u0, with_scale=True)
     assert_close_scaled(d, want, scale, TOL_QUAD, "hydro example IC")
+
+
+def test_rainshaft_column_rhs(gpu_cloudy, oracle):
+    """make_rainshaft_rhs (rainshaft_gamma_mixture.jl:15-50: 20 cells over 3 km, two Gamma modes, Golovin b = 5,
+    thr (2e-10, Inf), vel ((50, 1/6),)): coalescence source + upwind flux divergence, for 3 stacked columns."""
+    cloudy = gpu_cloudy
+    nz, ncol, dz = 20, 3, 150.0
+    vel = ((50.0, 1.0 / 6),)
+    par, op, _ = make_case(cloudy, oracle, [1, 1], [[EPS / 1e6, 5.0], [5.0, 0.0]], (2e-10, INF), bench.NORMS, vel=vel)
+    par.dz, par.nz = dz, nz
+    # initial_condition (rainshaft_helpers.jl:17-36): a slab between 0.5 and 0.75 of the column, plus random columns
+    z = (np.arange(nz) + 0.5) * dz
+    at = ((z >= 0.5 * z.max() - dz / 2) & (z < 0.75 * z.max() - dz / 2)).astype(float)
+    col0 = np.outer([1e7, 1e-3, 2e-13, 0.0, 0.0, 0.0], at)
+    rest = bench.synth_moments(2, nz * (ncol - 1), seed=4)
+    mom = np.concatenate([col0, rest], axis=1)
+    got = cloudy.make_rainshaft_rhs()(dev(cloudy, mom), par, 0.0).to_numpy()
+    cs, sf = oracle.rainshaft_cell_batch(op, mom)
+    want = np.empty_like(mom)
+    for c in range(ncol):
+        s = slice(c * nz, (c + 1) * nz)
+        fl = np.concatenate([sf[:, s], np.zeros((6, 1))], axis=1)   # sedi_flux_top = 0 (:80-81)
+        want[:, s] = cs[:, s] + (-(fl[:, 1:] - fl[:, :-1]) / dz)
+    _, scale = oracle.rhs_coal_batch(op, np.maximum(mom, 0.0), with_scale=True)
+    tol = TOL_QUAD * scale + 1e-12 * (np.abs(sf) + np.abs(np.roll(sf, -1, axis=1))) / dz + 1e-300
+    assert np.all(np.abs(got - want) <= tol)
+    assert np.all(got[:, :5] == 0.0)  # empty cells below the slab receive nothing from below and hold nothing
