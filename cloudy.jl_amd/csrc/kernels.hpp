@@ -313,6 +313,20 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double n, 
         const double t = nd.x * inv_th, z = nd.xmx * inv_th;
         if (!(z > 0.0)) continue;  // P(a, z <= 0) = 0
         const double h0 = nd.wdx * exp(fma(k, nd.lx - lnth, -t));
+#ifndef CLOUDY_NO_NODE_SKIP
+        {
+            // every term is >= 0 and P <= 1, P decreasing in the order: the node adds at most h0 x^p1 to
+            // acc[p1][.], whose smallest entry is acc[p1][M-1]; below 1e-19 of the running sums it cannot be seen
+            bool negligible = true;
+            double hx = h0;
+#pragma unroll
+            for (int p1 = 0; p1 < M; ++p1) {
+                negligible = negligible && (hx <= 1e-19 * acc[tri<M>(p1, M - 1)]);
+                hx *= nd.x;
+            }
+            if (negligible) continue;
+        }
+#endif
         const double E0 = exp(fma(a_top, nd.lxmx - lnth, -z) - lg_top);
         double Pz[M];
         Pz[M - 1] = inc_gamma_p_from_E(a_top, z, E0, nullptr);
@@ -809,17 +823,25 @@ __global__ void __launch_bounds__(kBlock)
         for (int stage = 0; stage < 3; ++stage) {
             rhs_physical<N, P, MODE>(A, nodes, u, f);
             // OrdinaryDiffEq SSPRK33: u = uprev + dt k;  u = (3 uprev + u + dt k)/4;  u = (uprev + 2u + 2dt k)/3
+            // (wave-uniform branch on the stage OUTSIDE the element loops: selects per element would triple the work)
+            if (stage == 0) {
 #pragma unroll
-            for (int m = 0; m < N; ++m)
+                for (int m = 0; m < N; ++m)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    if (stage == 0)
-                        u[m][q] = up[m][q] + dt * f[m][q];
-                    else if (stage == 1)
+                    for (int q = 0; q < 3; ++q) u[m][q] = up[m][q] + dt * f[m][q];
+            } else if (stage == 1) {
+#pragma unroll
+                for (int m = 0; m < N; ++m)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
                         u[m][q] = (3.0 * up[m][q] + u[m][q] + dt * f[m][q]) * 0.25;  // "/ 4" is exact
-                    else  // "/ 3" as a correctly rounded division
+            } else {
+#pragma unroll
+                for (int m = 0; m < N; ++m)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)  // "/ 3" as a correctly rounded division
                         u[m][q] = div_by_const(up[m][q] + 2.0 * u[m][q] + 2.0 * dt * f[m][q], 3.0, 1.0 / 3.0);
-                }
+            }
         }
     }
 #pragma unroll
