@@ -30,6 +30,16 @@ if ROOT not in sys.path:
 
 SEED = 20260723
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_VALU_PEAK_TFLOPS = 78.6  # half the guide's 157.3 TF fp32 vector peak: a wave64 fp64 FMA issues in 4 cycles per SIMD
+
+
+def _measured_latest():
+    """PMC-derived per-launch figures committed by tools/summarize_profiles.py (profiles/measured_latest.json)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "measured_latest.json")) as f:
+            return json.load(f)
+    except Exception:
+        return {}
 NORMS = (1e6, 1e-9)    # every reference example, e.g. box_single_gamma.jl:25
 INF = float("inf")
 
@@ -255,6 +265,11 @@ def main():
     value = total * args.steps / res["wall"]
     achieved = bytes_per_eval * n_local / (res["event_ms"] * 1e-3) / 1e9
 
+    measured = _measured_latest()
+    traffic = None
+    if args.workload == "cfg3a" and measured.get("n_parcels") == n_local:
+        traffic = measured.get("cfg3a_hbm_bytes_per_launch")  # 2 x FETCH_SIZE + WRITE_SIZE of the committed PMC passes
+
     variants = {}
     if not args.no_variants and args.workload == "cfg3a":
         v = _run_workload(pkg, "cfg3b", n_local, max(3, args.steps // 10), 1, rank, dist, torch)
@@ -267,6 +282,13 @@ def main():
             "hbm_GBs": bytes_per_eval * n_local / (v["event_ms"] * 1e-3) / 1e9,
             "mass_rate_residual": abs(v["mass_rate_sum"]) / max(v["mass_rate_gross"], 1e-300) if rank == 0 else None,
         }
+        if measured.get("n_parcels") == n_local and measured.get("cfg3b_fp64_flops_per_launch"):
+            tf = measured["cfg3b_fp64_flops_per_launch"] / (v["event_ms"] * 1e-3) / 1e12
+            variants["cfg3b"]["roofline"] = {
+                "bound": "fp64-valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tf / FP64_VALU_PEAK_TFLOPS,
+                "note": "fp64 flops per launch from the committed SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 counters x active-lane "
+                        "fraction (profiles/measured_latest.json); not HBM bound"}
 
     if not args.no_variants and args.workload == "cfg3a":
         # fused on-device SSPRK33 (cloudy_ssprk33_steps): 3 RHS evaluations per step, state in registers
@@ -333,7 +355,7 @@ def main():
                                    f"{nmom} moments, thresholds {spec['thresholds']}, norms {NORMS}",
                        "parcels_per_gpu": n_local, "global_parcels": total, "sharding": f"parcel ranges x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "coal_rhs_kernel", "kernel_ms": res["event_ms"],
                          "algorithmic_bytes_per_launch": bytes_per_eval * n_local},
             "cpu_baseline": cpu,

@@ -313,20 +313,6 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double n, 
         const double t = nd.x * inv_th, z = nd.xmx * inv_th;
         if (!(z > 0.0)) continue;  // P(a, z <= 0) = 0
         const double h0 = nd.wdx * exp(fma(k, nd.lx - lnth, -t));
-#ifndef CLOUDY_NO_NODE_SKIP
-        {
-            // every term is >= 0 and P <= 1, P decreasing in the order: the node adds at most h0 x^p1 to
-            // acc[p1][.], whose smallest entry is acc[p1][M-1]; below 1e-19 of the running sums it cannot be seen
-            bool negligible = true;
-            double hx = h0;
-#pragma unroll
-            for (int p1 = 0; p1 < M; ++p1) {
-                negligible = negligible && (hx <= 1e-19 * acc[tri<M>(p1, M - 1)]);
-                hx *= nd.x;
-            }
-            if (negligible) continue;
-        }
-#endif
         const double E0 = exp(fma(a_top, nd.lxmx - lnth, -z) - lg_top);
         double Pz[M];
         Pz[M - 1] = inc_gamma_p_from_E(a_top, z, E0, nullptr);

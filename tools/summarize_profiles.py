@@ -37,3 +37,20 @@ for row in rows:
             "hbm_bytes_per_launch": 2 * row["FETCH_SIZE"] * 1024 + row["WRITE_SIZE"] * 1024}
 json.dump(traffic, open(os.path.join(dst, f"{tag}_hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1))
+
+# what bench.py reads back (profiles/measured_latest.json): HBM bytes per launch of the headline kernel and the fp64
+# flop count per parcel of the threshold kernel, both at the bench's 1e7-parcel workloads
+latest = {"tag": tag, "n_parcels": 10_000_000}
+for row in rows:
+    if row["kernel"].startswith("coal_rhs_allinf2_kernel<2, 3, double>") and "FETCH_SIZE" in row and "WRITE_SIZE" in row:
+        latest["cfg3a_hbm_bytes_per_launch"] = 2 * row["FETCH_SIZE"] * 1024 + row["WRITE_SIZE"] * 1024
+        latest["cfg3a_kernel"] = row["kernel"]
+    if row["kernel"].startswith("coal_rhs_sorted_kernel<2, 3, 1, double>") and "SQ_INSTS_VALU_FMA_F64" in row:
+        util = row["SQ_THREAD_CYCLES_VALU"] / (row["SQ_ACTIVE_INST_VALU"] * 64.0)
+        flops = (2 * row["SQ_INSTS_VALU_FMA_F64"] + row["SQ_INSTS_VALU_MUL_F64"] + row["SQ_INSTS_VALU_ADD_F64"]) * 64.0 * util
+        latest["cfg3b_fp64_flops_per_launch"] = flops
+        latest["cfg3b_valu_lane_utilisation"] = util
+        latest["cfg3b_valu_insts_per_parcel"] = row["SQ_INSTS_VALU"] * 64.0 / latest["n_parcels"]
+        latest["cfg3b_kernel"] = row["kernel"]
+json.dump(latest, open(os.path.join(dst, "measured_latest.json"), "w"), indent=1)
+print(json.dumps(latest, indent=1))
