@@ -8,7 +8,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out
 mkdir -p $OUT
 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline > $OUT/${TAG}_stats_bench.json 2> $OUT/${TAG}_stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline > $OUT/${TAG}_stats_bench.json 2> $OUT/${TAG}_stats.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/${TAG}_pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/${TAG}_pmc_write.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_sq -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/${TAG}_pmc_sq.err
