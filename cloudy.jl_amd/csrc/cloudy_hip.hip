@@ -291,6 +291,7 @@ void cloudy_plan_destroy(cloudy_plan *plan) {
     if (!plan) return;
     if (plan->h.nodes_dev) (void)hipFree(plan->h.nodes_dev);
     if (plan->h.partial_dev) (void)hipFree(plan->h.partial_dev);
+    if (plan->h.kargs_dev) (void)hipFree(plan->h.kargs_dev);
     delete plan;
 }
 

@@ -28,6 +28,8 @@ struct HostPlan {
     double *nodes_dev = nullptr;                        // [n_nodes][kNodeStride]
     int n_nodes = 0;
     double *partial_dev = nullptr;                      // moment_sums workspace
+    mutable void *kargs_dev = nullptr;                  // KArgs<N,P> of (moments in, physical out) for ssprk33_kernel
+    mutable int kargs_dtype = -1;
 };
 
 enum Op { OP_COAL = 0, OP_UPDATE_DIST = 1, OP_FINITE_2D = 2, OP_SEDI = 3, OP_SSPRK33 = 4, OP_COND = 5 };

@@ -85,14 +85,19 @@ hipError_t launch_io(const HostPlan &h, const LaunchReq &r, const KArgs<N, P> &A
         break;
     case OP_SSPRK33: {
         const unsigned g = grid_for(r.n, heavy);
+        if (!h.kargs_dev) {  // constant block of this plan in device memory, uploaded once (see ssprk33_kernel)
+            if (hipMalloc(&h.kargs_dev, sizeof(A)) != hipSuccess) return hipErrorOutOfMemory;
+            if (hipMemcpy(h.kargs_dev, &A, sizeof(A), hipMemcpyHostToDevice) != hipSuccess) return hipErrorUnknown;
+        }
+        const KArgs<N, P> *Ad = static_cast<const KArgs<N, P> *>(h.kargs_dev);
         if (h.mode == MODE_ALLINF)
-            hipLaunchKernelGGL((ssprk33_kernel<N, P, MODE_ALLINF, TIO>), dim3(g), dim3(kBlock), 0, r.stream, A,
+            hipLaunchKernelGGL((ssprk33_kernel<N, P, MODE_ALLINF, TIO>), dim3(g), dim3(kBlock), 0, r.stream, Ad,
                                h.nodes_dev, r.n, r.ld, in, out, r.dt, r.n_steps);
         else if (h.mode == MODE_FIXED)
-            hipLaunchKernelGGL((ssprk33_kernel<N, P, MODE_FIXED, TIO>), dim3(g), dim3(kBlock), 0, r.stream, A,
+            hipLaunchKernelGGL((ssprk33_kernel<N, P, MODE_FIXED, TIO>), dim3(g), dim3(kBlock), 0, r.stream, Ad,
                                h.nodes_dev, r.n, r.ld, in, out, r.dt, r.n_steps);
         else
-            hipLaunchKernelGGL((ssprk33_kernel<N, P, MODE_MOVING, TIO>), dim3(g), dim3(kBlock), 0, r.stream, A,
+            hipLaunchKernelGGL((ssprk33_kernel<N, P, MODE_MOVING, TIO>), dim3(g), dim3(kBlock), 0, r.stream, Ad,
                                h.nodes_dev, r.n, r.ld, in, out, r.dt, r.n_steps);
         break;
     }
