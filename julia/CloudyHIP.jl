@@ -34,6 +34,8 @@ check(rc) = rc == 0 ? nothing : error("libcloudy_hip: ", unsafe_string(ccall((:c
 
 dist_code(::ExponentialPrimitiveParticleDistribution) = Int32(0)
 dist_code(::GammaPrimitiveParticleDistribution) = Int32(1)
+dist_code(::MonodispersePrimitiveParticleDistribution) = Int32(2)
+dist_code(::LognormalPrimitiveParticleDistribution) = Int32(3)
 
 pad(t, n, z) = ntuple(i -> i <= length(t) ? t[i] : z, n)
 
@@ -84,6 +86,19 @@ function make_box_model_rhs(::AnalyticalCoalStyle, ts::ThresholdStyle = FixedThr
         return nothing
     end
     return rhs!
+end
+
+"""
+    solve_ssprk33!(u, plan, dt, n_steps; stream = C_NULL)
+
+`solve(prob, SSPRK33(), dt = dt)` for `n_steps` fixed steps on the device (final state only): the state stays in
+registers over all stages, one read and one write of `u` per call.
+"""
+function solve_ssprk33!(u, plan, dt, n_steps; stream = C_NULL)
+    check(ccall((:cloudy_ssprk33_steps, lib), Cint,
+                (Ptr{Cvoid}, Csize_t, Csize_t, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cint, Ptr{Cvoid}),
+                plan, size(u, 1), stride(u, 2), pointer(u), pointer(u), dt, n_steps, stream))
+    return u
 end
 
 # host-array convenience (copies over PCIe each call; for validation, not for production stepping)
