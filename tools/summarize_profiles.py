@@ -7,7 +7,13 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "rXX"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-for f in glob.glob(os.path.join(src, f"{tag}_stats", "*", "*kernel_stats.csv")):
+def newest(pattern):
+    """gpurun merges every call's files into gpurun_out/: keep only the most recent run of each pass"""
+    files = glob.glob(pattern)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
+for f in newest(os.path.join(src, f"{tag}_stats", "*", "*kernel_stats.csv")):
     shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 for name in ("bench.json", "hbm_ceiling.txt"):
     f = os.path.join(src, f"{tag}_{name}")
@@ -15,7 +21,7 @@ for name in ("bench.json", "hbm_ceiling.txt"):
         shutil.copy(f, os.path.join(dst, f"{tag}_{name}"))
 table = {}
 for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
-    for f in glob.glob(os.path.join(src, f"{tag}_{d}", "*", "*counter_collection.csv")):
+    for f in newest(os.path.join(src, f"{tag}_{d}", "*", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
             if "cloudy::" not in k:
