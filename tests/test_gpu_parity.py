@@ -686,3 +686,37 @@ def test_rainshaft_column_rhs(gpu_cloudy, oracle):
     tol = TOL_QUAD * scale + 1e-12 * (np.abs(sf) + np.abs(np.roll(sf, -1, axis=1))) / dz + 1e-300
     assert np.all(np.abs(got - want) <= tol)
     assert np.all(got[:, :5] == 0.0)  # empty cells below the slab receive nothing from below and hold nothing
+
+
+@pytest.mark.parametrize("thr_n,nbpl", [(1e-3, 15), (0.05, 15), (1.0, 15), (7.0, 15), (100.0, 15), (1e4, 15), (0.5, 10),
+                                        (0.5, 20), (3.0, 33)])
+def test_threshold_magnitudes_and_grid_densities(gpu_cloudy, oracle, thr_n, nbpl):
+    """The Simpson grid changes with the (normalised) threshold -- n_bins = floor(nbpl * log10(x_t / x_lb)): 75 bins
+    for x_t <= 1, 84 at 4, 105 at 100, 135 at 1e4 (ParticleDistributions.jl:604-607) -- and with n_bins_per_log_unit.
+    The early/late node split and the regime sort must hold on all of them: F matrices against the oracle's
+    moment_source_helper on every grid, for broad random (n, theta, k)."""
+    cloudy = gpu_cloudy
+    rng = np.random.default_rng(int(thr_n * 1000) + nbpl)
+    n = 300
+    kc = np.array([[0.0, 1.0, 0.5], [1.0, 0.0, 0.0], [0.5, 0.0, 0.0]])
+    plan = cloudy.Plan([1, 0, 1], kc, (thr_n, thr_n * 3.0, INF), (1.0, 1.0), 0, n_bins_per_log_unit=nbpl)
+    nn = 10 ** rng.uniform(-2, 3, (3, n))
+    th = thr_n * 10 ** rng.uniform(-3, 2, (3, n))      # x_t / theta from 1e-2 to 1e3
+    kk = rng.uniform(0.05, 10, (3, n))
+    kk[1] = 1.0
+    params = cloudy.pack_params([(nn[i], th[i], kk[i]) for i in range(3)])
+    M = 5
+    F = cloudy.get_finite_2d_integrals(plan, dev(cloudy, params)).to_numpy().reshape(3, M, M, n)
+    worst = 0.0
+    for i in range(0, n, 3):
+        for mode, t in ((0, 1), (1, 0)):
+            d = oracle.make_dist(t, nn[mode, i], th[mode, i], kk[mode, i])
+            xt = thr_n * (1.0 if mode == 0 else 3.0)
+            for p1 in range(M):
+                for p2 in range(p1, M):
+                    mm = oracle.moment(d, p1) * oracle.moment(d, p2)
+                    want = 0.0 if mm < EPS else min(mm, oracle.moment_source_helper(d, p1, p2, xt, nbpl))
+                    err = abs(F[mode, p1, p2, i] - want)
+                    assert err <= TOL_QUAD * max(mm, 1e-300), (thr_n, nbpl, i, mode, p1, p2, F[mode, p1, p2, i], want)
+                    worst = max(worst, err / max(mm, 1e-300))
+    print(f"x_t={thr_n:g} nbpl={nbpl}: max |F - oracle| / (M_p M_q) = {worst:.2e}")
