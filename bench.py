@@ -360,6 +360,18 @@ def main():
             "value": n_local * world / (ms32 * 1e-3), "unit": "parcel-RHS/s", "kernel_ms": ms32,
             "hbm_GBs": 2 * nmom * 4 * n_local / (ms32 * 1e-3) / 1e9,
         }
+        # CLOUDY_F32_FAST on the threshold workload (single-precision Simpson / incomplete-gamma pass)
+        wlb = make_workload("cfg3b", n_local, seed=SEED + 1000 * rank)
+        planf = wlb["coal_data"].plan(wlb["dist_types"], dtype=2)
+        for _ in range(3):
+            pkg._lib.check(pkg.lib().cloudy_coal_rhs(planf.handle, n_local, n_local, m32.ptr, dm32.ptr, None))
+        msf = _event_ms(pkg, planf, m32, dm32, max(3, args.steps // 10))
+        variants["cfg3b_f32_fast"] = {
+            "workload": "cfg3b with CLOUDY_F32_FAST: float planes, single-precision arithmetic in the per-node "
+                        "Simpson / incomplete-gamma pass (error vs the fp64 oracle bounded at 5e-6 of the term scale "
+                        "in tests/test_gpu_parity.py)",
+            "value": n_local * world / (msf * 1e-3), "unit": "parcel-RHS/s", "kernel_ms": msf,
+        }
         del m32, dm32
 
     cpu = None

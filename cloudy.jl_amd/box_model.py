@@ -29,6 +29,8 @@ def _plan_for(par, dtype=0):
         raise ValueError("NProgMoms must equal nparams of p.pdists")
     if tuple(par.norms) != tuple(par.coal_data.norms):
         raise ValueError("p.norms differs from the norms the CoalescenceData was built with")
+    if dtype == 1 and getattr(par, "fast_f32", False):
+        dtype = 2  # CLOUDY_F32_FAST: single-precision arithmetic in the per-node Simpson / incomplete-gamma pass
     return par.coal_data.plan([d.type_id for d in par.pdists], k_range=getattr(par, "k_range", (EPS, 10.0)),
                               vel=getattr(par, "vel", ()), dtype=dtype)
 

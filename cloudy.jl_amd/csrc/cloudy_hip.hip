@@ -101,7 +101,8 @@ int cloudy_plan_create(const cloudy_plan_desc *d, cloudy_plan **out) {
     if (N < 1 || N > CLOUDY_MAX_MODES) return fail(CLOUDY_EUNSUPPORTED, "n_modes %d outside 1..%d", N, CLOUDY_MAX_MODES);
     if (P < 1 || P > CLOUDY_MAX_P) return fail(CLOUDY_EUNSUPPORTED, "tensor_p %d outside 1..%d", P, CLOUDY_MAX_P);
     if (!d->kernel_c) return fail(CLOUDY_EINVAL, "kernel_c is NULL");
-    if (d->dtype != CLOUDY_F64 && d->dtype != CLOUDY_F32) return fail(CLOUDY_EINVAL, "bad dtype");
+    if (d->dtype != CLOUDY_F64 && d->dtype != CLOUDY_F32 && d->dtype != CLOUDY_F32_FAST)
+        return fail(CLOUDY_EINVAL, "bad dtype");
     if (!(d->norms[0] > 0) || !(d->norms[1] > 0))
         return fail(CLOUDY_EINVAL, "norms must be positive!");  // helper_functions.jl:44-46
     if (d->threshold_style != CLOUDY_FIXED_THRESHOLD && d->threshold_style != CLOUDY_MOVING_THRESHOLD)
@@ -426,7 +427,7 @@ int cloudy_rainshaft_rhs(const cloudy_plan *plan, size_t nz, size_t n_columns, s
     rc = cloudy_rainshaft_sources(plan, n, ld, mom_dev, rhs_dev, flux_work_dev, stream);
     if (rc || n == 0) return rc;
     const unsigned g = (unsigned)((n + kBlock - 1) / kBlock);
-    if (plan->h.dtype == CLOUDY_F32)
+    if (plan->h.dtype != CLOUDY_F64)
         hipLaunchKernelGGL(rainshaft_divergence_kernel<float>, dim3(g), dim3(kBlock), 0, (hipStream_t)stream, n, ld,
                            plan->h.nmom, nz, 1.0 / dz, (const float *)flux_work_dev, (float *)rhs_dev);
     else
@@ -445,7 +446,7 @@ int cloudy_moment_sums(const cloudy_plan *plan, size_t n, size_t ld, int planes,
     size_t blocks = (n + kBlock - 1) / kBlock;
     if (blocks > (size_t)kSumBlocks) blocks = kSumBlocks;
     if (blocks < 1) blocks = 1;
-    if (plan->h.dtype == CLOUDY_F32)
+    if (plan->h.dtype != CLOUDY_F64)
         hipLaunchKernelGGL(plane_partial_sums_kernel<float>, dim3((unsigned)blocks), dim3(kBlock), 0,
                            (hipStream_t)stream, n, ld, planes, (const float *)arr_dev, plan->h.partial_dev);
     else
@@ -461,7 +462,7 @@ int cloudy_coal_rhs_host(const cloudy_plan *plan, size_t n, size_t ld, const voi
     int rc = check_batch(plan, n, ld, mom_host, dmom_host);
     if (rc) return rc;
     if (n == 0) return CLOUDY_OK;
-    const size_t bytes = (size_t)plan->h.nmom * ld * (plan->h.dtype == CLOUDY_F32 ? sizeof(float) : sizeof(double));
+    const size_t bytes = (size_t)plan->h.nmom * ld * (plan->h.dtype != CLOUDY_F64 ? sizeof(float) : sizeof(double));
     char *buf = nullptr;
     HIP_TRY(hipMalloc((void **)&buf, 2 * bytes));
     hipError_t e = hipMemcpy(buf, mom_host, bytes, hipMemcpyHostToDevice);

@@ -91,6 +91,60 @@ __device__ __forceinline__ double inc_gamma_p_from_E(double a, double z, double 
     }
 }
 
+// fp32 variant of inc_gamma_p_from_E for the CLOUDY_F32_FAST plans: same two algorithms, single precision,
+// convergence to ~1e-7 (a third of the terms), v_rcp_f32-class divisions.
+__device__ __forceinline__ float inc_gamma_p_from_E_f32(float a, float z, float E) {
+    if (z <= a + 1.0f) {
+        if (z < 1e-3f * (a + 1.0f))  // two terms suffice (rel. error < 1e-9) and (a+n)/z would overflow single precision
+            return E * (1.0f + (z / (a + 1.0f)) * (1.0f + z / (a + 2.0f)));
+        const float invz = 1.0f / z;
+        float q = a * invz, Nn = 1.0f, Dn = 1.0f;
+#pragma unroll 1
+        for (int it = 0; it < 50; ++it) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                q += invz;
+                Nn = fmaf(Nn, q, 1.0f);
+                Dn *= q;
+            }
+            if (!(Nn < 2.0e7f)) break;  // term/sum = 1/N' < 5e-8; D' <= N': no overflow before convergence
+        }
+        const float p = E * (Nn / Dn);
+        return p > 1.0f ? 1.0f : p;
+    } else {
+        if (a * E < 1e-9f) return 1.0f;
+        float b = z + 1.0f - a;
+        float Ap = 0.0f, Bp = 1.0f, Ac = 1.0f, Bc = b;
+        float an = a - 1.0f, c = a - 1.0f;
+#pragma unroll 1
+        for (int it = 0; it < 50; ++it) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                b += 2.0f;
+                const float An = fmaf(b, Ac, an * Ap);
+                const float Bn = fmaf(b, Bc, an * Bp);
+                Ap = Ac;
+                Bp = Bc;
+                Ac = An;
+                Bc = Bn;
+                c -= 2.0f;
+                an += c;
+            }
+            const float lhs = fabsf(fmaf(Ac, Bp, -(Ap * Bc)));
+            if (!(lhs > 1e-7f * fabsf(Ac * Bp))) break;
+            if (fabsf(Bc) > 1e15f) {
+                Ap *= 1e-15f;
+                Bp *= 1e-15f;
+                Ac *= 1e-15f;
+                Bc *= 1e-15f;
+            }
+        }
+        float qv = a * E * (Ac / Bc);
+        qv = qv < 0.0f ? 0.0f : qv;
+        return 1.0f - qv;
+    }
+}
+
 // P(a, z), Q(a, z) for a standalone call (one exp + one lgamma)
 __device__ __forceinline__ double inc_gamma_p(double a, double z, double lgamma_a1, double *q_out) {
     if (!(z > 0.0)) {

@@ -339,6 +339,118 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double n, 
         for (int p2 = p1; p2 < M; ++p2) msh[tri<M>(p1, p2)] = pref * Mk[p2] * acc[tri<M>(p1, p2)];
 }
 
+// CLOUDY_F32_FAST plans: the same Simpson pass with single-precision arithmetic for everything that is done per
+// node (exp via v_exp_f32, series / continued fraction to ~1e-7, fp32 accumulators); the exponents of the two
+// exp() calls are still formed in fp64 (they are differences of O(100) terms).  Early-node expansion with 10 terms
+// and the wider radius t <= 2, t max(a-1,2)/z0 <= 0.4 (truncation < 4e-10, checked against mpmath).  Everything
+// outside this function (closure inversion, moments, F/min, Q/R/S) stays fp64.  Expected accuracy of the msh
+// entries ~1e-6 relative; tests report the error against the fp64 oracle.
+template <int P, typename Grid>
+__device__ __forceinline__ void msh_grid_f32(const Grid &grid, double xt, double n, double th, double k, bool is_gamma,
+                                             const double (&Mk)[P + 2], double (&msh)[(P + 2) * (P + 3) / 2]) {
+    constexpr int M = P + 2;
+    constexpr int T = M * (M + 1) / 2;
+    constexpr int NT = 10;
+    constexpr int NS = M + NT;
+    const int nb = grid.n_bins();
+    const double inv_th = 1.0 / th, lnth = log(th);
+    const double a_top = k + double(M - 1);
+    const double lg_top = lgamma(a_top + 1.0);
+    const double z0 = xt * inv_th;
+    const float a_topf = (float)a_top;
+    float acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = 0.0f;
+    const double x_early = fmin(2.0 * th, 0.4 * xt / fmax(a_top - 1.0, 2.0));
+    int j = 0;
+    {
+        // power sums in u = x / x_t (<= 1: no single-precision range problems even for theta ~ 1e15 of clamped
+        // closures); the expansion is then in b_n = c_n z0^n:  b_{n+1} = ((z0 - a + 1 + n) b_n - z0 b_{n-1}) / (n+1),
+        // P(a, z0 - z0 u) = P(a, z0) - g z0 sum_n b_n u^(n+1) / (n+1)
+        float U[NS];
+#pragma unroll
+        for (int q = 0; q < NS; ++q) U[q] = 0.0f;
+        const double inv_xt = 1.0 / xt;
+#pragma unroll 1
+        for (; j < nb; ++j) {
+            if (!(grid.node_x(j) <= x_early)) break;
+            const SimpsonNode nd = grid.node(j, false);
+            const double td = nd.x * inv_th;
+            const float u = (float)(nd.x * inv_xt);
+            float e = (float)nd.wdx * __expf((float)fma(k, nd.lx - lnth, -td));
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                U[q] += e;
+                e *= u;
+            }
+        }
+        if (j > 0) {
+            const float z0f = (float)z0, invz0 = (float)(1.0 / z0);
+            float E = __expf((float)(fma(a_top, log(xt) - lnth, -z0) - lg_top));
+            float Pv = inc_gamma_p_from_E_f32(a_topf, z0f, E);
+            float a = a_topf;
+            float xtp[M];  // x_t^p1
+            xtp[0] = 1.0f;
+#pragma unroll
+            for (int p1 = 1; p1 < M; ++p1) xtp[p1] = xtp[p1 - 1] * (float)xt;
+#pragma unroll
+            for (int p2 = M - 1; p2 >= 0; --p2) {
+                const float g = E * a * invz0;  // dP/dz at z0
+                float G[M];
+#pragma unroll
+                for (int p1 = 0; p1 < M; ++p1) G[p1] = 0.0f;
+                float bm = 0.0f, bc = 1.0f;
+#pragma unroll
+                for (int nn2 = 0; nn2 < NT; ++nn2) {
+                    const float w = bc * (1.0f / float(nn2 + 1));
+#pragma unroll
+                    for (int p1 = 0; p1 <= p2; ++p1) G[p1] = fmaf(w, U[p1 + nn2 + 1], G[p1]);
+                    const float bn = ((z0f - a + 1.0f + float(nn2)) * bc - z0f * bm) * (1.0f / float(nn2 + 1));
+                    bm = bc;
+                    bc = bn;
+                }
+                const float gz = g * z0f;
+#pragma unroll
+                for (int p1 = 0; p1 <= p2; ++p1) acc[tri<M>(p1, p2)] = xtp[p1] * fmaf(Pv, U[p1], -(gz * G[p1]));
+                Pv += g;
+                E = g;
+                a -= 1.0f;
+            }
+        }
+    }
+#pragma unroll 1
+    for (; j < nb; ++j) {
+        const SimpsonNode nd = grid.node(j, true);
+        const double td = nd.x * inv_th, zd = nd.xmx * inv_th;
+        if (!(zd > 0.0)) continue;
+        const float z = (float)zd, xf = (float)nd.x;
+        const float h0 = (float)nd.wdx * __expf((float)fma(k, nd.lx - lnth, -td));
+        const float E0 = __expf((float)(fma(a_top, nd.lxmx - lnth, -zd) - lg_top));
+        float Pz[M];
+        Pz[M - 1] = inc_gamma_p_from_E_f32(a_topf, z, E0);
+        const float invz = 1.0f / z;
+        float E = E0, a = a_topf;
+#pragma unroll
+        for (int p2 = M - 2; p2 >= 0; --p2) {
+            E *= a * invz;
+            a -= 1.0f;
+            Pz[p2] = Pz[p2 + 1] + E;
+        }
+        float h = h0;
+#pragma unroll
+        for (int p1 = 0; p1 < M; ++p1) {
+#pragma unroll
+            for (int p2 = p1; p2 < M; ++p2) acc[tri<M>(p1, p2)] = fmaf(h, Pz[p2], acc[tri<M>(p1, p2)]);
+            h *= xf;
+        }
+    }
+    const double pref = is_gamma ? n / tgamma(k) : n;
+#pragma unroll
+    for (int p1 = 0; p1 < M; ++p1)
+#pragma unroll
+        for (int p2 = p1; p2 < M; ++p2) msh[tri<M>(p1, p2)] = pref * Mk[p2] * (double)acc[tri<M>(p1, p2)];
+}
+
 // compute_threshold, ParticleDistributions.jl:747-761
 __device__ __forceinline__ double moving_threshold(bool is_gamma, double th, double k, double percentile) {
     const double minx = 1e-18;
@@ -394,7 +506,7 @@ __device__ __forceinline__ void contract_promoted(const double (&ckk)[P][P], con
 }
 
 // get_coal_ints for one parcel: acc[k][m], normalised units.
-template <int N, int P, int MODE>
+template <int N, int P, int MODE, bool FAST = false>
 __device__ __forceinline__ void coal_ints_parcel(const KArgs<N, P> &A, const double *__restrict__ nodes,
                                                  const double (&nn)[N], const double (&th)[N], const double (&kk)[N],
                                                  double (&acc)[N][3]) {
@@ -423,17 +535,25 @@ __device__ __forceinline__ void coal_ints_parcel(const KArgs<N, P> &A, const dou
                     for (int p1 = 0; p1 < M; ++p1)
 #pragma unroll
                         for (int p2 = p1; p2 < M; ++p2) msh[tri<M>(p1, p2)] = below ? Mm[k][p1] * Mm[k][p2] : 0.0;
-                } else if (nn[k] > 0.0)
-                    msh_grid<P>(FixedGrid{nodes + (size_t)A.node_off[k] * kNodeStride, A.n_bins[k]}, A.thr[k], nn[k], th[k],
-                                kk[k], A.dist_type[k] == DIST_GAMMA, Mm[k], msh);
+                } else if (nn[k] > 0.0) {
+                    const FixedGrid grid{nodes + (size_t)A.node_off[k] * kNodeStride, A.n_bins[k]};
+                    if (FAST)
+                        msh_grid_f32<P>(grid, A.thr[k], nn[k], th[k], kk[k], A.dist_type[k] == DIST_GAMMA, Mm[k], msh);
+                    else
+                        msh_grid<P>(grid, A.thr[k], nn[k], th[k], kk[k], A.dist_type[k] == DIST_GAMMA, Mm[k], msh);
+                }
             }
         } else if (MODE == MODE_MOVING) {
             if (k < N - 1) {
                 const bool is_gamma = A.dist_type[k] == DIST_GAMMA;
                 const double xt = moving_threshold(is_gamma, th[k], kk[k], A.thr[k]);
                 thresholded = !(xt == INFINITY);
-                if (thresholded && nn[k] > 0.0)
-                    msh_grid<P>(MovingGrid(xt, A.nbpl), xt, nn[k], th[k], kk[k], is_gamma, Mm[k], msh);
+                if (thresholded && nn[k] > 0.0) {
+                    if (FAST)
+                        msh_grid_f32<P>(MovingGrid(xt, A.nbpl), xt, nn[k], th[k], kk[k], is_gamma, Mm[k], msh);
+                    else
+                        msh_grid<P>(MovingGrid(xt, A.nbpl), xt, nn[k], th[k], kk[k], is_gamma, Mm[k], msh);
+                }
             }
         }
         // without a threshold D is non-zero only where M_p M_q < eps: impossible when every moment >= 2^-26
@@ -638,7 +758,7 @@ __global__ void __launch_bounds__(kBlock)
 // any of them takes, so the 256 parcels of a workgroup are first ranked by r (counting sort in LDS) and each
 // lane then processes the parcel of its rank: waves become regime-homogeneous.  Parcels stay inside their
 // workgroup's 256-parcel window (2 KB per plane), so stores remain line-coalesced.
-template <int N, int P, int MODE, typename TIO>
+template <int N, int P, int MODE, typename TIO, bool FAST = false>
 __global__ void __launch_bounds__(kBlock)
     coal_rhs_sorted_kernel(const KArgs<N, P> A, const double *__restrict__ nodes, size_t n, size_t ld,
                            const TIO *__restrict__ in, TIO *__restrict__ out) {
@@ -709,7 +829,7 @@ __global__ void __launch_bounds__(kBlock)
             th[m] = sh_par[3 * m + 1][src];
             kk[m] = sh_par[3 * m + 2][src];
         }
-        coal_ints_parcel<N, P, MODE>(A, nodes, nn, th, kk, acc);
+        coal_ints_parcel<N, P, MODE, FAST>(A, nodes, nn, th, kk, acc);
         const bool skip = A.rainshaft && sh_small[src];
 #pragma unroll
         for (int k = 0; k < N; ++k) {

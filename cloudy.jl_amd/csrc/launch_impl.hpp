@@ -59,7 +59,14 @@ hipError_t launch_io(const HostPlan &h, const LaunchReq &r, const KArgs<N, P> &A
         else if (h.mode == MODE_ALLINF)
             hipLaunchKernelGGL((coal_rhs_kernel<N, P, MODE_ALLINF, TIO>), dim3(g), dim3(kBlock), 0, r.stream, A,
                                h.nodes_dev, r.n, r.ld, in, out);
-        else if (h.mode == MODE_FIXED)
+        else if (h.dtype == CLOUDY_F32_FAST && sizeof(TIO) == 4 && r.input_kind == IN_MOMENTS) {
+            if (h.mode == MODE_FIXED)
+                hipLaunchKernelGGL((coal_rhs_sorted_kernel<N, P, MODE_FIXED, TIO, true>), dim3(g), dim3(kBlock), 0,
+                                   r.stream, A, h.nodes_dev, r.n, r.ld, in, out);
+            else
+                hipLaunchKernelGGL((coal_rhs_sorted_kernel<N, P, MODE_MOVING, TIO, true>), dim3(g), dim3(kBlock), 0,
+                                   r.stream, A, h.nodes_dev, r.n, r.ld, in, out);
+        } else if (h.mode == MODE_FIXED)
             hipLaunchKernelGGL((coal_rhs_sorted_kernel<N, P, MODE_FIXED, TIO>), dim3(g), dim3(kBlock), 0, r.stream, A,
                                h.nodes_dev, r.n, r.ld, in, out);
         else
@@ -117,7 +124,7 @@ hipError_t launch_np(const HostPlan &h, const LaunchReq &r) {
     case OP_COND:
     case OP_SSPRK33:
         // get_coal_ints on (n, theta, k) planes is an fp64 interface for every plan
-        if (h.dtype == CLOUDY_F32 && r.input_kind == IN_MOMENTS) return launch_io<N, P, float>(h, r, A);
+        if (h.dtype != CLOUDY_F64 && r.input_kind == IN_MOMENTS) return launch_io<N, P, float>(h, r, A);
         return launch_io<N, P, double>(h, r, A);
     case OP_UPDATE_DIST:
         hipLaunchKernelGGL((update_dist_kernel<N, P>), dim3(grid_for(r.n, false)), dim3(kBlock), 0, r.stream, A, r.n,

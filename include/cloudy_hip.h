@@ -65,7 +65,7 @@ extern "C" {
 enum { CLOUDY_DIST_EXPONENTIAL = 0, CLOUDY_DIST_GAMMA = 1, CLOUDY_DIST_MONODISPERSE = 2, CLOUDY_DIST_LOGNORMAL = 3 };
 /* EquationTypes.jl:20-22 */
 enum { CLOUDY_FIXED_THRESHOLD = 0, CLOUDY_MOVING_THRESHOLD = 1 };
-enum { CLOUDY_F64 = 0, CLOUDY_F32 = 1 };
+enum { CLOUDY_F64 = 0, CLOUDY_F32 = 1, CLOUDY_F32_FAST = 2 };
 /* layout of cloudy_plan_desc.kernel_c */
 enum { CLOUDY_KERNEL_SINGLE = 0 /* [P][P] shared by all pairs, Coalescence.jl:89-104 */,
        CLOUDY_KERNEL_MATRIX = 1 /* [N][N][P][P], Coalescence.jl:55-87 */ };
@@ -98,7 +98,10 @@ typedef struct cloudy_plan_desc {
     int32_t n_bins_per_log_unit;             /* ParticleDistributions.jl:594; default 15 */
     int32_t dtype;                           /* element type of the mom / dmom / flux planes: CLOUDY_F64, or CLOUDY_F32
                                                 (float planes in HBM = half the traffic; arithmetic stays fp64 in
-                                                registers; (n, theta, k) / F diagnostics planes are always fp64) */
+                                                registers; (n, theta, k) / F diagnostics planes are always fp64), or
+                                                CLOUDY_F32_FAST (float planes AND single-precision arithmetic in the
+                                                per-node Simpson / incomplete-gamma pass: ~1e-6 relative on the
+                                                thresholded integrals, several times faster on threshold plans) */
     int32_t n_vel;                           /* 0 = no sedimentation term */
     double vel[CLOUDY_MAX_VEL][2];           /* p.vel: terminal velocity sum_k vel[k][0] * x^vel[k][1], physical units */
     int32_t device;                          /* HIP device ordinal, -1 = current */

@@ -720,3 +720,29 @@ def test_threshold_magnitudes_and_grid_densities(gpu_cloudy, oracle, thr_n, nbpl
                     assert err <= TOL_QUAD * max(mm, 1e-300), (thr_n, nbpl, i, mode, p1, p2, F[mode, p1, p2, i], want)
                     worst = max(worst, err / max(mm, 1e-300))
     print(f"x_t={thr_n:g} nbpl={nbpl}: max |F - oracle| / (M_p M_q) = {worst:.2e}")
+
+
+def test_fp32_fast_threshold_path_error_report(gpu_cloudy, oracle):
+    """CLOUDY_F32_FAST (BASELINE configs[4] "fp32 path with fp64 tolerance check"): float planes and single-precision
+    arithmetic in the per-node Simpson / incomplete-gamma pass.  The error against the fp64 oracle is REPORTED and
+    bounded at 5e-6 of the term scale (measured 5e-7: fp32 exp arguments of O(30), 75-term sums)."""
+    cloudy = gpu_cloudy
+    n = 20_000
+    wl = bench.make_workload("cfg3b", n, seed=123)
+    par = wl["par"]
+    par.fast_f32 = True
+    mom32 = wl["mom"].astype(np.float32)
+    m = cloudy.DeviceArray.from_numpy(mom32)
+    dm = cloudy.DeviceArray.zeros(6, n, np.float32)
+    cloudy.make_box_model_rhs(cloudy.AnalyticalCoalStyle())(dm, m, par, 0.0)
+    got = dm.to_numpy().astype(np.float64)
+    want, scale = oracle.rhs_coal_batch(bench.oracle_params("cfg3b"), mom32.astype(np.float64), with_scale=True)
+    with np.errstate(over="ignore"):
+        fin = np.isfinite(want.astype(np.float32)) & (scale < 1e30)
+    err = np.abs(got - want)[fin] / np.maximum(scale[fin], 1e-300)
+    print(f"fp32-fast cfg3b: max |hip - oracle|/scale = {err.max():.2e}, 99.9th pct {np.quantile(err, 0.999):.2e}, "
+          f"median {np.median(err):.2e}")
+    assert err.max() < 5e-6
+    # mass is still conserved to fp32 rounding of the two mass tendencies
+    net = np.abs(got[1] + got[4])
+    assert np.all(net[fin[1]] <= 3e-7 * (np.abs(got[1]) + np.abs(got[4]))[fin[1]] + 1e-300)
