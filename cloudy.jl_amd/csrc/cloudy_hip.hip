@@ -48,13 +48,14 @@ int fail_hip(hipError_t e, const char *what) {
 constexpr int kSumBlocks = 1024;
 
 hipError_t dispatch(const HostPlan &h, const LaunchReq &r) {
-    switch (h.N) {
-    case 1: return launch_n1(h, r);
-    case 2: return launch_n2(h, r);
-    case 3: return launch_n3(h, r);
-    case 4: return launch_n4(h, r);
-    default: return hipErrorInvalidValue;
-    }
+    using Fn = hipError_t (*)(const HostPlan &, const LaunchReq &);
+    static const Fn table[CLOUDY_MAX_MODES][CLOUDY_MAX_P] = {
+        {launch_n1_p1, launch_n1_p2, launch_n1_p3, launch_n1_p4, launch_n1_p5},
+        {launch_n2_p1, launch_n2_p2, launch_n2_p3, launch_n2_p4, launch_n2_p5},
+        {launch_n3_p1, launch_n3_p2, launch_n3_p3, launch_n3_p4, launch_n3_p5},
+        {launch_n4_p1, launch_n4_p2, launch_n4_p3, launch_n4_p4, launch_n4_p5}};
+    if (h.N < 1 || h.N > CLOUDY_MAX_MODES || h.P < 1 || h.P > CLOUDY_MAX_P) return hipErrorInvalidValue;
+    return table[h.N - 1][h.P - 1](h, r);
 }
 
 int check_batch(const cloudy_plan *plan, size_t n, size_t ld, const void *a, const void *b) {

@@ -50,10 +50,26 @@ struct LaunchReq {
     const double *s_dev = nullptr;      // OP_COND (optional per-parcel supersaturation)
 };
 
-// one per instantiation unit (inst_n1.hip ... inst_n4.hip)
-hipError_t launch_n1(const HostPlan &h, const LaunchReq &r);
-hipError_t launch_n2(const HostPlan &h, const LaunchReq &r);
-hipError_t launch_n3(const HostPlan &h, const LaunchReq &r);
-hipError_t launch_n4(const HostPlan &h, const LaunchReq &r);
+// one per instantiation unit (inst_n<N>_p<P>.hip), so that the kernel families compile in parallel
+hipError_t launch_n1_p1(const HostPlan &h, const LaunchReq &r);
+hipError_t launch_n1_p2(const HostPlan &h, const LaunchReq &r);
+hipError_t launch_n1_p3(const HostPlan &h, const LaunchReq &r);
+hipError_t launch_n1_p4(const HostPlan &h, const LaunchReq &r);
+hipError_t launch_n1_p5(const HostPlan &h, const LaunchReq &r);
+hipError_t launch_n2_p1(const HostPlan &h, const LaunchReq &r);
+hipError_t launch_n2_p2(const HostPlan &h, const LaunchReq &r);
+hipError_t launch_n2_p3(const HostPlan &h, const LaunchReq &r);
+hipError_t launch_n2_p4(const HostPlan &h, const LaunchReq &r);
+hipError_t launch_n2_p5(const HostPlan &h, const LaunchReq &r);
+hipError_t launch_n3_p1(const HostPlan &h, const LaunchReq &r);
+hipError_t launch_n3_p2(const HostPlan &h, const LaunchReq &r);
+hipError_t launch_n3_p3(const HostPlan &h, const LaunchReq &r);
+hipError_t launch_n3_p4(const HostPlan &h, const LaunchReq &r);
+hipError_t launch_n3_p5(const HostPlan &h, const LaunchReq &r);
+hipError_t launch_n4_p1(const HostPlan &h, const LaunchReq &r);
+hipError_t launch_n4_p2(const HostPlan &h, const LaunchReq &r);
+hipError_t launch_n4_p3(const HostPlan &h, const LaunchReq &r);
+hipError_t launch_n4_p4(const HostPlan &h, const LaunchReq &r);
+hipError_t launch_n4_p5(const HostPlan &h, const LaunchReq &r);
 
 }  // namespace cloudy

@@ -1,0 +1,5 @@
+// instantiation unit: every kernel of the N = 1 modes, P = 4 (tensor order 3) family
+#include "launch_impl.hpp"
+namespace cloudy {
+hipError_t launch_n1_p4(const HostPlan &h, const LaunchReq &r) { return launch_np<1, 4>(h, r); }
+}  // namespace cloudy

@@ -1,0 +1,5 @@
+// instantiation unit: every kernel of the N = 3 modes, P = 2 (tensor order 1) family
+#include "launch_impl.hpp"
+namespace cloudy {
+hipError_t launch_n3_p2(const HostPlan &h, const LaunchReq &r) { return launch_np<3, 2>(h, r); }
+}  // namespace cloudy

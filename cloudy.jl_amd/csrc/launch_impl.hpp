@@ -150,16 +150,4 @@ hipError_t launch_np(const HostPlan &h, const LaunchReq &r) {
     return hipGetLastError();
 }
 
-template <int N>
-hipError_t launch_n(const HostPlan &h, const LaunchReq &r) {
-    switch (h.P) {
-    case 1: return launch_np<N, 1>(h, r);
-    case 2: return launch_np<N, 2>(h, r);
-    case 3: return launch_np<N, 3>(h, r);
-    case 4: return launch_np<N, 4>(h, r);
-    case 5: return launch_np<N, 5>(h, r);
-    default: return hipErrorInvalidValue;
-    }
-}
-
 }  // namespace cloudy
