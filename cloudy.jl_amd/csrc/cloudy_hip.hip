@@ -285,6 +285,14 @@ int cloudy_plan_create(const cloudy_plan_desc *d, cloudy_plan **out) {
         cloudy_plan_destroy(p);
         return fail_hip(e, "workspace allocation");
     }
+    {
+        LaunchReq prep{OP_PREPARE, IN_MOMENTS, 1, 0, 0, 0, nullptr, &h.kargs_dev, nullptr, nullptr};
+        e = dispatch(h, prep);
+        if (e != hipSuccess) {
+            cloudy_plan_destroy(p);
+            return fail_hip(e, "constant block upload");
+        }
+    }
     *out = p;
     return CLOUDY_OK;
 }

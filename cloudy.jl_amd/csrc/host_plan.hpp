@@ -28,11 +28,10 @@ struct HostPlan {
     double *nodes_dev = nullptr;                        // [n_nodes][kNodeStride]
     int n_nodes = 0;
     double *partial_dev = nullptr;                      // moment_sums workspace
-    mutable void *kargs_dev = nullptr;                  // KArgs<N,P> of (moments in, physical out) for ssprk33_kernel
-    mutable int kargs_dtype = -1;
+    void *kargs_dev = nullptr;                          // KArgs<N,P> of (moments in, physical out), uploaded at plan creation
 };
 
-enum Op { OP_COAL = 0, OP_UPDATE_DIST = 1, OP_FINITE_2D = 2, OP_SEDI = 3, OP_SSPRK33 = 4, OP_COND = 5 };
+enum Op { OP_COAL = 0, OP_UPDATE_DIST = 1, OP_FINITE_2D = 2, OP_SEDI = 3, OP_SSPRK33 = 4, OP_COND = 5, OP_PREPARE = 6 /* plan creation: upload the constant block */ };
 
 struct LaunchReq {
     int op;

@@ -92,10 +92,7 @@ hipError_t launch_io(const HostPlan &h, const LaunchReq &r, const KArgs<N, P> &A
         break;
     case OP_SSPRK33: {
         const unsigned g = grid_for(r.n, heavy);
-        if (!h.kargs_dev) {  // constant block of this plan in device memory, uploaded once (see ssprk33_kernel)
-            if (hipMalloc(&h.kargs_dev, sizeof(A)) != hipSuccess) return hipErrorOutOfMemory;
-            if (hipMemcpy(h.kargs_dev, &A, sizeof(A), hipMemcpyHostToDevice) != hipSuccess) return hipErrorUnknown;
-        }
+        if (!h.kargs_dev) return hipErrorNotInitialized;  // uploaded by OP_PREPARE at plan creation
         const KArgs<N, P> *Ad = static_cast<const KArgs<N, P> *>(h.kargs_dev);
         if (h.mode == MODE_ALLINF)
             hipLaunchKernelGGL((ssprk33_kernel<N, P, MODE_ALLINF, TIO>), dim3(g), dim3(kBlock), 0, r.stream, Ad,
@@ -119,6 +116,18 @@ hipError_t launch_np(const HostPlan &h, const LaunchReq &r) {
     fill_args<N, P>(h, r, A);
     const bool heavy = h.mode != MODE_ALLINF;
     switch (r.op) {
+    case OP_PREPARE: {  // constant block in device memory for ssprk33_kernel (moments in, physical units out)
+        void *dev = nullptr;
+        hipError_t e = hipMalloc(&dev, sizeof(A));
+        if (e != hipSuccess) return e;
+        e = hipMemcpy(dev, &A, sizeof(A), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(dev);
+            return e;
+        }
+        *static_cast<void **>(r.out) = dev;
+        return hipSuccess;
+    }
     case OP_COAL:
     case OP_SEDI:
     case OP_COND:

@@ -36,8 +36,10 @@
  * get_dist_moment_ind (src/helper_functions.jl:13-20), 0-based.  Values are in physical units;
  * normalisation by norms happens inside, as in rhs_coal!.
  *
- * Ownership: the caller owns every buffer; a plan owns only its constant block.  No call
- * allocates.  All device entry points are asynchronous on `stream` (a hipStream_t passed as
+ * Ownership: the caller owns every buffer; a plan owns only its constant block and a small reduction
+ * workspace (used by cloudy_moment_sums: do not run that call concurrently on ONE plan from several
+ * streams; every other batched call only reads the plan and may).  No call allocates, except the
+ * host-pointer convenience cloudy_coal_rhs_host.  All device entry points are asynchronous on `stream` (a hipStream_t passed as
  * void*; NULL = the default stream).  Errors: int status, never a C++ exception; the message
  * of the last failure on the calling thread is cloudy_last_error().
  *
