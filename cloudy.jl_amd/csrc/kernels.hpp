@@ -763,7 +763,7 @@ __global__ void __launch_bounds__(kBlock)
     coal_rhs_sorted_kernel(const KArgs<N, P> A, const double *__restrict__ nodes, size_t n, size_t ld,
                            const TIO *__restrict__ in, TIO *__restrict__ out) {
     __shared__ double sh_par[3 * N][kBlock];
-    __shared__ unsigned int sh_key[kBlock];
+    __shared__ __attribute__((aligned(16))) unsigned int sh_key[kBlock];
     __shared__ unsigned short sh_perm[kBlock];
     __shared__ unsigned char sh_small[kBlock];
     const int t = threadIdx.x;
@@ -807,14 +807,16 @@ __global__ void __launch_bounds__(kBlock)
             sh_par[3 * m + 1][t] = th[m];
             sh_par[3 * m + 2][t] = kk[m];
         }
+        key = (key & 0xFFFFFF00u) | (unsigned int)t;  // unique keys (thread id in the 8 low mantissa bits): no tie-break
         sh_key[t] = key;
         sh_small[t] = all_small ? 1 : 0;
         __syncthreads();
         int rank = 0;
+        const uint4 *sh_key4 = reinterpret_cast<const uint4 *>(sh_key);
 #pragma unroll 8
-        for (int s2 = 0; s2 < kBlock; ++s2) {
-            const unsigned int ks = sh_key[s2];
-            rank += (ks < key || (ks == key && s2 < t)) ? 1 : 0;
+        for (int s2 = 0; s2 < kBlock / 4; ++s2) {
+            const uint4 k4 = sh_key4[s2];  // wave-uniform address: one broadcast ds_read_b128 per four keys
+            rank += (k4.x < key) + (k4.y < key) + (k4.z < key) + (k4.w < key);
         }
         sh_perm[rank] = (unsigned short)t;
         __syncthreads();
@@ -879,7 +881,7 @@ __global__ void __launch_bounds__(kBlock)
     size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (MODE != MODE_ALLINF) {
         // regime sort of the workgroup's parcels on the initial state (see coal_rhs_sorted_kernel)
-        __shared__ unsigned int sh_key[kBlock];
+        __shared__ __attribute__((aligned(16))) unsigned int sh_key[kBlock];
         __shared__ unsigned short sh_perm[kBlock];
         const int t = threadIdx.x;
         unsigned int key = 0xFFFFFFFFu;
@@ -904,13 +906,15 @@ __global__ void __launch_bounds__(kBlock)
             const float r = (MODE == MODE_FIXED) ? (float)((xtf / thf) / (kf + double(P + 2))) : (float)kf;
             if (nf > 0.0 && r == r) key = __float_as_uint(fmaxf(r, 0.0f));
         }
+        key = (key & 0xFFFFFF00u) | (unsigned int)t;
         sh_key[t] = key;
         __syncthreads();
         int rank = 0;
+        const uint4 *sh_key4 = reinterpret_cast<const uint4 *>(sh_key);
 #pragma unroll 8
-        for (int s2 = 0; s2 < kBlock; ++s2) {
-            const unsigned int ks = sh_key[s2];
-            rank += (ks < key || (ks == key && s2 < t)) ? 1 : 0;
+        for (int s2 = 0; s2 < kBlock / 4; ++s2) {
+            const uint4 k4 = sh_key4[s2];
+            rank += (k4.x < key) + (k4.y < key) + (k4.z < key) + (k4.w < key);
         }
         sh_perm[rank] = (unsigned short)t;
         __syncthreads();
