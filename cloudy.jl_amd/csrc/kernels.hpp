@@ -24,7 +24,9 @@ namespace cloudy {
 enum { IN_MOMENTS = 0, IN_PARAMS = 1 };
 enum { MODE_ALLINF = 0, MODE_FIXED = 1, MODE_MOVING = 2 };
 enum { DIST_EXP = 0, DIST_GAMMA = 1, DIST_MONO = 2, DIST_LOGNORMAL = 3 };
-constexpr int kNodeStride = 5;  // x, ln x, x_t - x, ln(x_t - x), w * dx
+constexpr int kEarlyTerms = 16;  // Taylor terms of the early-node expansion (see msh_grid for the radius)
+constexpr int kNodePowers = 7 + kEarlyTerms;  // (x/x_t)^q, q = 0..M+kEarlyTerms-1, M <= 7
+constexpr int kNodeStride = 5 + kNodePowers;  // x, ln x, x_t - x, ln(x_t - x), w * dx, then the powers of x/x_t
 constexpr int kBlock = 256;
 
 template <int N, int P>
@@ -186,6 +188,8 @@ struct SimpsonNode {
 struct FixedGrid {
     const double *__restrict__ nd;
     int nb;
+    static constexpr bool kHasPowers = true;  // (x_j/x_t)^q tabulated: the early-node power sums are one FMA each
+    __device__ __forceinline__ double upow(int j, int q) const { return nd[kNodeStride * j + 5 + q]; }
     __device__ __forceinline__ int n_bins() const { return nb; }
     __device__ __forceinline__ double node_x(int j) const { return nd[kNodeStride * j]; }
     __device__ __forceinline__ SimpsonNode node(int j, bool /*late*/) const {
@@ -197,6 +201,8 @@ struct FixedGrid {
 struct MovingGrid {
     double xt, x_min, dx;
     int nb;
+    static constexpr bool kHasPowers = false;
+    __device__ __forceinline__ double upow(int, int) const { return 0.0; }
     __device__ __forceinline__ MovingGrid(double xt_, int nbpl) : xt(xt_) {
         const double x_lb = fmin(1e-5, 1e-5 * xt_);
         nb = (int)floor(double(nbpl) * log10(xt_ / x_lb));
@@ -215,8 +221,6 @@ struct MovingGrid {
         return s;
     }
 };
-
-constexpr int kEarlyTerms = 16;  // Taylor terms of the early-node expansion (see msh_grid for the radius)
 
 // moment_source_helper for all (p1 <= p2) of one mode in ONE pass over its Simpson grid:
 //   msh[p1][p2] = n M_p2 / Gamma(k) * sum_j (w_j dx) x_j^p1 t_j^k e^{-t_j} P(k + p2, z_j),
@@ -238,7 +242,11 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double n, 
     constexpr int M = P + 2;
     constexpr int T = M * (M + 1) / 2;
     constexpr int NS = M + kEarlyTerms;
+#ifdef CLOUDY_ABLATE_NODES  // timing experiment only: no Simpson nodes at all
+    const int nb = 0;
+#else
     const int nb = grid.n_bins();
+#endif
     const double inv_th = 1.0 / th, lnth = log(th);
     const double a_top = k + double(M - 1);
     const double lg_top = lgamma(a_top + 1.0);
@@ -247,57 +255,65 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double n, 
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = 0.0;
 
-    // ---- early nodes: power sums only
+    // ---- early nodes: power sums only, in u = x / x_t:
+    //   U_q = sum_j (w_j dx) t_j^k e^{-t_j} u_j^q;   P(a, z0 - z0 u) = P(a, z0) - g_a z0 sum_n b_n u^(n+1)/(n+1),
+    //   b_n = c_n z0^n:  b_{n+1} = ((z0 - a + 1 + n) b_n - z0 b_{n-1}) / (n + 1)
     const double x_early = fmin(th, 0.2 * xt / fmax(a_top - 1.0, 2.0));
     int j = 0;
 #ifndef CLOUDY_NO_EARLY_NODES
     {
-        double S[NS];
+        double U[NS];
 #pragma unroll
-        for (int q = 0; q < NS; ++q) S[q] = 0.0;
+        for (int q = 0; q < NS; ++q) U[q] = 0.0;
+        const double inv_xt = 1.0 / xt;
 #pragma unroll 1
         for (; j < nb; ++j) {
             if (!(grid.node_x(j) <= x_early)) break;
             const SimpsonNode nd = grid.node(j, false);
             const double t = nd.x * inv_th;
             double e = nd.wdx * exp(fma(k, nd.lx - lnth, -t));
+            if (Grid::kHasPowers) {
 #pragma unroll
-            for (int q = 0; q < NS; ++q) {
-                S[q] += e;
-                e *= t;
+                for (int q = 0; q < NS; ++q) U[q] = fma(e, grid.upow(j, q), U[q]);  // tabulated powers: SGPR operand
+            } else {
+                const double u = nd.x * inv_xt;
+#pragma unroll
+                for (int q = 0; q < NS; ++q) {
+                    U[q] += e;
+                    e *= u;
+                }
             }
         }
         if (j > 0) {
-            // P(a, z0) and g_a for the M orders a = k + p2 (downward from a_top)
+            // P(a, z0) and g_a = dP/dz at z0 for the M orders a = k + p2 (downward from a_top)
             const double invz0 = 1.0 / z0;
             double E = exp(fma(a_top, log(xt) - lnth, -z0) - lg_top);  // E(a_top, z0) = z0^a e^-z0 / Gamma(a+1)
             double Pv = inc_gamma_p_from_E(a_top, z0, E, nullptr);
             double a = a_top;
-            double thp[M];  // theta^p1
-            thp[0] = 1.0;
+            double xtp[M];  // x_t^p1
+            xtp[0] = 1.0;
 #pragma unroll
-            for (int p1 = 1; p1 < M; ++p1) thp[p1] = thp[p1 - 1] * th;
+            for (int p1 = 1; p1 < M; ++p1) xtp[p1] = xtp[p1 - 1] * xt;
 #pragma unroll
             for (int p2 = M - 1; p2 >= 0; --p2) {
                 // here: a = k + p2, Pv = P(a, z0), E = E(a, z0)
-                const double g = E * a * invz0;  // E(a-1, z0) = z0^(a-1) e^-z0 / Gamma(a) = dP/dz at z0
-                // G_p1 = sum_n c_n/(n+1) S[p1 + n + 1]
+                const double g = E * a * invz0;  // E(a-1, z0) = z0^(a-1) e^-z0 / Gamma(a)
                 double G[M];
 #pragma unroll
                 for (int p1 = 0; p1 < M; ++p1) G[p1] = 0.0;
-                double cm = 0.0, c = 1.0;
+                double bm = 0.0, bc = 1.0;
 #pragma unroll
                 for (int nn2 = 0; nn2 < kEarlyTerms; ++nn2) {
-                    const double w = c * (1.0 / double(nn2 + 1));
+                    const double w = bc * (1.0 / double(nn2 + 1));
 #pragma unroll
-                    for (int p1 = 0; p1 <= p2; ++p1) G[p1] = fma(w, S[p1 + nn2 + 1], G[p1]);
-                    const double cn = ((z0 - a + 1.0 + double(nn2)) * c - cm) * (invz0 * (1.0 / double(nn2 + 1)));
-                    cm = c;
-                    c = cn;
+                    for (int p1 = 0; p1 <= p2; ++p1) G[p1] = fma(w, U[p1 + nn2 + 1], G[p1]);
+                    const double bn = ((z0 - a + 1.0 + double(nn2)) * bc - z0 * bm) * (1.0 / double(nn2 + 1));
+                    bm = bc;
+                    bc = bn;
                 }
+                const double gz = g * z0;
 #pragma unroll
-                for (int p1 = 0; p1 <= p2; ++p1)
-                    acc[tri<M>(p1, p2)] = thp[p1] * fma(Pv, S[p1], -(g * G[p1]));
+                for (int p1 = 0; p1 <= p2; ++p1) acc[tri<M>(p1, p2)] = xtp[p1] * fma(Pv, U[p1], -(gz * G[p1]));
                 // step down one order
                 Pv += g;
                 E = g;
@@ -307,6 +323,9 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double n, 
     }
 #endif
     // ---- late nodes: one incomplete-gamma evaluation each
+#ifdef CLOUDY_ABLATE_LATE  // timing experiment only: early nodes and their conversion, no late nodes
+    j = nb;
+#endif
 #pragma unroll 1
     for (; j < nb; ++j) {
         const SimpsonNode nd = grid.node(j, true);
