@@ -51,7 +51,7 @@ for row in rows:
     if row["kernel"].startswith("coal_rhs_allinf2_kernel<2, 3, double>") and "FETCH_SIZE" in row and "WRITE_SIZE" in row:
         latest["cfg3a_hbm_bytes_per_launch"] = 2 * row["FETCH_SIZE"] * 1024 + row["WRITE_SIZE"] * 1024
         latest["cfg3a_kernel"] = row["kernel"]
-    if row["kernel"].startswith("coal_rhs_sorted_kernel<2, 3, 1, double>") and "SQ_INSTS_VALU_FMA_F64" in row:
+    if row["kernel"].startswith("coal_rhs_sorted_kernel<2, 3, 1, double") and "SQ_INSTS_VALU_FMA_F64" in row:
         util = row["SQ_THREAD_CYCLES_VALU"] / (row["SQ_ACTIVE_INST_VALU"] * 64.0)
         flops = (2 * row["SQ_INSTS_VALU_FMA_F64"] + row["SQ_INSTS_VALU_MUL_F64"] + row["SQ_INSTS_VALU_ADD_F64"]) * 64.0 * util
         latest["cfg3b_fp64_flops_per_launch"] = flops
