@@ -88,6 +88,9 @@ def workload_spec(name):
         return dict(n_modes=2, kernel="long", long=long_k, thresholds=(INF, INF), default_parcels=10_000_000)
     if name == "cfg3b":  # same, reference thresholds (box_gamma_mixture_long.jl:36)
         return dict(n_modes=2, kernel="long", long=long_k, thresholds=(5e-10, INF), default_parcels=10_000_000)
+    if name == "cfg4":   # BASELINE configs[3] in the reference's formulation: 3 Gamma modes, hydrodynamic kernel as an
+        # order-4 fitted tensor (box_gamma_mixture_hydro.jl:22-23), thresholds of box_gamma_mixture_3modes.jl:29
+        return dict(n_modes=3, kernel="hydro", thresholds=(1e-9, 1e-7, INF), default_parcels=12_500_000)
     raise ValueError(f"unknown workload {name}")
 
 
@@ -98,6 +101,12 @@ def kernel_matrix(spec):
     if spec["kernel"] == "golovin":
         c = np.array([[eps, 5.0], [5.0, 0.0]])  # CoalescenceTensor(LinearKernelFunction(5.0), 1, 1e-6): C_1_1 = eps
         return np.broadcast_to(c, (N, N, 2, 2)).copy()
+    if spec["kernel"] == "hydro":
+        import __graft_entry__ as ge
+
+        pkg = ge.load_package()
+        t = pkg.CoalescenceTensor(pkg.HydrodynamicKernelFunction(1e2 * np.pi), 4, 1e-6)  # least-squares fit (host)
+        return np.broadcast_to(t.c, (N, N, 5, 5)).copy()
     lk = spec["long"]
     kc = np.zeros((N, N, 3, 3))
     for j in range(N):
@@ -373,6 +382,26 @@ def main():
             "value": n_local * world / (msf * 1e-3), "unit": "parcel-RHS/s", "kernel_ms": msf,
         }
         del m32, dm32
+
+    if not args.no_variants and args.workload == "cfg3a":
+        # the other BASELINE configurations, a few launches each
+        for vname, vn in (("cfg2", 1_000_000), ("cfg4", 12_500_000)):
+            wlv = make_workload(vname, vn, seed=SEED + 1000 * rank)
+            planv = wlv["coal_data"].plan(wlv["dist_types"])
+            mv = pkg.DeviceArray.from_numpy(wlv["mom"])
+            dmv = pkg.DeviceArray.zeros(planv.nmom, vn)
+            reps = 200 if vname == "cfg2" else 3
+            for _ in range(3 if vname == "cfg4" else 200):
+                pkg._lib.check(pkg.lib().cloudy_coal_rhs(planv.handle, vn, vn, mv.ptr, dmv.ptr, None))
+            msv = _event_ms(pkg, planv, mv, dmv, reps)
+            spv = workload_spec(vname)
+            variants[vname] = {
+                "workload": f"{vname}: {vn} parcels/GPU, {spv['n_modes']} Gamma mode(s), kernel {spv['kernel']}, "
+                            f"thresholds {spv['thresholds']}, {planv.nmom} moments, fp64",
+                "value": vn * world / (msv * 1e-3), "unit": "parcel-RHS/s", "kernel_ms": msv,
+                "hbm_GBs": 2 * planv.nmom * 8 * vn / (msv * 1e-3) / 1e9,
+            }
+            del mv, dmv
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
