@@ -118,3 +118,14 @@ def compute_thresholds(plan, params, out=None, stream=None):
     optr = as_device(o)[0]
     _lib.check(_lib.lib().cloudy_compute_thresholds(plan.handle, n, ld, ptr, optr, stream))
     return o
+
+
+def get_standard_N_q(plan, mom, size_cutoff=1e-6, out=None, stream=None):
+    """get_standard_N_q(pdists, size_cutoff) (ParticleDistributions.jl:634-687), batched: mom (nmom, n) device,
+    physical units -> (4, n) device array of (N_liq, N_rai, M_liq, M_rai)."""
+    ptr, planes, n, ld = as_device(mom)
+    o = out if out is not None else DeviceArray(4, n, np.float32 if plan.dtype >= 1 else np.float64)
+    if as_device(o)[3] != ld:
+        raise ValueError("out must have the same leading dimension as mom")
+    _lib.check(_lib.lib().cloudy_standard_N_q(plan.handle, n, ld, ptr, float(size_cutoff), as_device(o)[0], stream))
+    return o

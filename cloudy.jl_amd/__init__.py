@@ -18,7 +18,7 @@ from .KernelFunctions import (ConstantKernelFunction, HydrodynamicKernelFunction
 from .KernelTensors import CoalescenceTensor, check_symmetry, get_normalized_kernel_tensor, polyfit
 from .ParticleDistributions import (ExponentialPrimitiveParticleDistribution, GammaPrimitiveParticleDistribution,
                                     LognormalPrimitiveParticleDistribution, MonodispersePrimitiveParticleDistribution,
-                                    compute_thresholds, get_moments, nparams, pack_params, update_dist_from_moments)
+                                    compute_thresholds, get_moments, get_standard_N_q, nparams, pack_params, update_dist_from_moments)
 from .Coalescence import CoalescenceData, Plan, get_coal_ints, get_finite_2d_integrals
 from .Sedimentation import get_sedimentation_flux, make_rainshaft_rhs, rainshaft_sources, rhs_condensation
 from .box_model import ODEParameters, make_box_model_rhs, rhs_coal, solve_ssprk33

@@ -60,6 +60,7 @@ SYMBOLS = {
     "cloudy_compute_thresholds": (_i, [_vp, _sz, _sz, _vp, _vp, _vp]),
     "cloudy_sedimentation_flux": (_i, [_vp, _sz, _sz, _vp, _vp, _vp]),
     "cloudy_cond_evap": (_i, [_vp, _sz, _sz, _vp, _vp, C.c_double, C.c_double, _vp, _vp]),
+    "cloudy_standard_N_q": (_i, [_vp, _sz, _sz, _vp, C.c_double, _vp, _vp]),
     "cloudy_rainshaft_sources": (_i, [_vp, _sz, _sz, _vp, _vp, _vp, _vp]),
     "cloudy_rainshaft_rhs": (_i, [_vp, _sz, _sz, _sz, _vp, C.c_double, _vp, _vp, _vp]),
     "cloudy_moment_sums": (_i, [_vp, _sz, _sz, _i, _vp, _vp, _vp]),

@@ -415,6 +415,20 @@ int cloudy_cond_evap(const cloudy_plan *plan, size_t n, size_t ld, const void *m
     return run(plan, r);
 }
 
+int cloudy_standard_N_q(const cloudy_plan *plan, size_t n, size_t ld, const void *mom_dev, double size_cutoff,
+                        void *nq_dev, void *stream) {
+    int rc = check_batch(plan, n, ld, mom_dev, nq_dev);
+    if (rc) return rc;
+    if (!(size_cutoff > 0)) return fail(CLOUDY_EINVAL, "size_cutoff must be positive");
+    for (int i = 0; i < plan->h.N; ++i)
+        if (plan->h.dist_type[i] == CLOUDY_DIST_LOGNORMAL)
+            return fail(CLOUDY_EUNSUPPORTED, "partial moments of a Lognormal mode use adaptive quadgk "
+                                             "(ParticleDistributions.jl:261-269): not built for the GPU");
+    LaunchReq r{OP_NQ, IN_MOMENTS, 1, 0, n, ld, mom_dev, nq_dev, nullptr, (hipStream_t)stream};
+    r.s_scalar = size_cutoff;
+    return run(plan, r);
+}
+
 int cloudy_rainshaft_sources(const cloudy_plan *plan, size_t n, size_t ld, const void *mom_dev, void *coal_source_dev,
                              void *sedi_flux_dev, void *stream) {
     int rc = check_batch(plan, n, ld, mom_dev, coal_source_dev);

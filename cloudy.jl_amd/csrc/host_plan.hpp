@@ -31,7 +31,7 @@ struct HostPlan {
     void *kargs_dev = nullptr;                          // KArgs<N,P> of (moments in, physical out), uploaded at plan creation
 };
 
-enum Op { OP_COAL = 0, OP_UPDATE_DIST = 1, OP_FINITE_2D = 2, OP_SEDI = 3, OP_SSPRK33 = 4, OP_COND = 5, OP_PREPARE = 6 /* plan creation: upload the constant block */ };
+enum Op { OP_COAL = 0, OP_UPDATE_DIST = 1, OP_FINITE_2D = 2, OP_SEDI = 3, OP_SSPRK33 = 4, OP_COND = 5, OP_PREPARE = 6 /* plan creation: upload the constant block */, OP_NQ = 7 };
 
 struct LaunchReq {
     int op;

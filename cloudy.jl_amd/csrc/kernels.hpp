@@ -1154,4 +1154,52 @@ __global__ void __launch_bounds__(kBlock)
     }
 }
 
+// get_standard_N_q, ParticleDistributions.jl:634-687 (cloud / rain diagnostics by a size cutoff): 4 planes
+// (N_liq, N_rai, M_liq, M_rai) in physical units from partial_moment (:226-285):
+//   Gamma / Exponential: n theta^q Gamma(q+k)/Gamma(k) P(q+k, x_c/theta) = M_q P(q+k, x_c/theta)
+//   Monodisperse:        M_q if x_c >= theta else 0
+template <int N, int P, typename TIO>
+__global__ void __launch_bounds__(kBlock)
+    standard_nq_kernel(const KArgs<N, P> A, double cutoff_n, double n0, double m0, size_t n, size_t ld,
+                       const TIO *__restrict__ in, TIO *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) {
+        double nn[N], th[N], kk[N];
+        load_parcel<N, P, TIO>(A, i, ld, in, nn, th, kk);
+        double Nl = 0.0, Nr = 0.0, Ml = 0.0, Mr = 0.0;
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+            const int dtp = A.dist_type[m];
+            const double M0 = nn[m];
+            double M1, p0, p1;
+            if (dtp == DIST_MONO) {
+                M1 = nn[m] * th[m];
+                p0 = (cutoff_n < th[m]) ? 0.0 : 1.0;
+                p1 = p0;
+            } else if (dtp == DIST_LOGNORMAL) {  // partial_moment integrates with quadgk: not built
+                M1 = nn[m] * exp(th[m] + 0.5 * kk[m] * kk[m]);
+                p0 = __builtin_nan("");
+                p1 = p0;
+            } else {
+                M1 = nn[m] * th[m] * kk[m];
+                const double z = cutoff_n / th[m];
+                const double a1 = kk[m] + 1.0;  // P(k+1, z), then P(k, z) = P(k+1, z) + z^k e^-z / Gamma(k+1)
+                const double lg = lgamma(a1 + 1.0);
+                const double E1 = exp(a1 * log(z) - z - lg);
+                p1 = (z > 0.0) ? inc_gamma_p_from_E(a1, z, E1, nullptr) : 0.0;
+                p0 = (z > 0.0) ? p1 + E1 * a1 / z : 0.0;
+                p0 = p0 > 1.0 ? 1.0 : p0;
+            }
+            Nl += M0 * p0;
+            Nr += M0 - M0 * p0;
+            Ml += M1 * p1;
+            Mr += M1 - M1 * p1;
+        }
+        out[(size_t)0 * ld + i] = (TIO)(Nl * n0);
+        out[(size_t)1 * ld + i] = (TIO)(Nr * n0);
+        out[(size_t)2 * ld + i] = (TIO)(Ml * n0 * m0);
+        out[(size_t)3 * ld + i] = (TIO)(Mr * n0 * m0);
+    }
+}
+
 }  // namespace cloudy

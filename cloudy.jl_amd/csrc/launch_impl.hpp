@@ -86,6 +86,10 @@ hipError_t launch_io(const HostPlan &h, const LaunchReq &r, const KArgs<N, P> &A
                            r.n, r.ld, in, out);
         break;
     }
+    case OP_NQ:  // r.s_scalar = size cutoff in physical mass units
+        hipLaunchKernelGGL((standard_nq_kernel<N, P, TIO>), dim3(grid_for(r.n, false)), dim3(kBlock), 0, r.stream, A,
+                           r.s_scalar / h.norms[1], h.norms[0], h.norms[1], r.n, r.ld, in, out);
+        break;
     case OP_COND:
         hipLaunchKernelGGL((cond_evap_kernel<N, P, TIO>), dim3(grid_for(r.n, false)), dim3(kBlock), 0, r.stream, A,
                            r.coef, r.s_scalar, r.s_dev, r.n, r.ld, in, out);
@@ -131,6 +135,7 @@ hipError_t launch_np(const HostPlan &h, const LaunchReq &r) {
     case OP_COAL:
     case OP_SEDI:
     case OP_COND:
+    case OP_NQ:
     case OP_SSPRK33:
         // get_coal_ints on (n, theta, k) planes is an fp64 interface for every plan
         if (h.dtype != CLOUDY_F64 && r.input_kind == IN_MOMENTS) return launch_io<N, P, float>(h, r, A);

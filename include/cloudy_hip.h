@@ -24,6 +24,7 @@
  *                                    test/examples/utils/rainshaft_helpers.jl:52-78
  *   cloudy_rainshaft_rhs          <- rhs(m, p, t) of make_rainshaft_rhs incl. the flux divergence
  *                                    test/examples/utils/rainshaft_helpers.jl:45-89
+ *   cloudy_standard_N_q           <- get_standard_N_q(pdists, size_cutoff)  ParticleDistributions.jl:634-687
  *   cloudy_cond_evap              <- rhs_condensation!(dmom, mom, p, s) / get_cond_evap
  *                                    test/examples/utils/box_model_helpers.jl:55-67, src/Sources/Condensation.jl:22-37
  *   cloudy_ssprk33_steps          <- solve(ODEProblem(rhs, m0, tspan, p), SSPRK33(), dt = p.dt) of the drivers,
@@ -162,6 +163,11 @@ int cloudy_sedimentation_flux(const cloudy_plan *plan, size_t n_parcels, size_t 
  * xi = p.xi in physical units; supersaturation s per parcel (s_dev, fp64, n values) or, if s_dev is NULL, `s`. */
 int cloudy_cond_evap(const cloudy_plan *plan, size_t n_parcels, size_t ld, const void *mom_dev, const double *s_dev,
                      double s, double xi, void *dmom_dev, void *stream);
+
+/* cloud / rain diagnostics get_standard_N_q(pdists, size_cutoff) (ParticleDistributions.jl:634-687): 4 planes
+ * (N_liq, N_rai, M_liq, M_rai) in physical units; size_cutoff in physical mass units (the examples pass 1e-6 kg). */
+int cloudy_standard_N_q(const cloudy_plan *plan, size_t n_parcels, size_t ld, const void *mom_dev, double size_cutoff,
+                        void *nq_dev, void *stream);
 
 /* coalescence source and sedimentation flux of each cell in one fused pass
  * (negative moments clamped to zero, empty cells skipped) */

@@ -280,6 +280,32 @@ double co_moment(const co_dist *d, double q) {
     }
 }
 
+/* partial_moment_func / partial_moment, ParticleDistributions.jl:226-285 (Lognormal uses quadgk: NaN here) */
+double co_partial_moment(const co_dist *d, double q, double x_threshold) {
+    switch (d->type) {
+    case CO_EXPONENTIAL:
+        return d->n * pow(d->theta, q) * co_gamma_inc_p(q + 1.0, x_threshold / d->theta) * co_gamma(q + 1.0);
+    case CO_GAMMA:
+        return d->n * pow(d->theta, q) * co_gamma_inc_p(q + d->k, x_threshold / d->theta) * co_gamma(q + d->k) /
+               co_gamma(d->k);
+    case CO_MONODISPERSE: return (x_threshold < d->theta) ? 0.0 : d->n * pow(d->theta, q);
+    default: return NAN;
+    }
+}
+
+/* get_standard_N_q, ParticleDistributions.jl:634-687: out = (N_liq, N_rai, M_liq, M_rai) */
+void co_get_standard_N_q(const co_dist *pdists, int N, double size_cutoff, double *out) {
+    double N_liq = 0, N_rai = 0, M_liq = 0, M_rai = 0;
+    for (int j = 0; j < N; ++j) N_liq += co_partial_moment(&pdists[j], 0.0, size_cutoff);
+    for (int j = 0; j < N; ++j) M_liq += co_partial_moment(&pdists[j], 1.0, size_cutoff);
+    for (int j = 0; j < N; ++j) N_rai += co_moment(&pdists[j], 0.0) - co_partial_moment(&pdists[j], 0.0, size_cutoff);
+    for (int j = 0; j < N; ++j) M_rai += co_moment(&pdists[j], 1.0) - co_partial_moment(&pdists[j], 1.0, size_cutoff);
+    out[0] = N_liq;
+    out[1] = N_rai;
+    out[2] = M_liq;
+    out[3] = M_rai;
+}
+
 /* get_moments, ParticleDistributions.jl:293-315 */
 void co_get_moments(const co_dist *d, double *out) {
     switch (d->type) {

@@ -87,6 +87,8 @@ int co_nparams(int dist_type);
 int co_dist_valid(const co_dist *d);
 double co_moment(const co_dist *d, double q);
 void co_get_moments(const co_dist *d, double *out);
+double co_partial_moment(const co_dist *d, double q, double x_threshold);
+void co_get_standard_N_q(const co_dist *pdists, int N, double size_cutoff, double *out);
 double co_density(const co_dist *d, double x);
 double co_normed_density(const co_dist *d, double x);
 int co_update_dist_from_moments(int dist_type, const double *moments, int n_moments,

@@ -88,6 +88,9 @@ def lib():
         L.co_moment.restype = C.c_double
         L.co_moment.argtypes = [C.POINTER(Dist), C.c_double]
         L.co_get_moments.argtypes = [C.POINTER(Dist), _dp]
+        L.co_partial_moment.restype = C.c_double
+        L.co_partial_moment.argtypes = [C.POINTER(Dist), C.c_double, C.c_double]
+        L.co_get_standard_N_q.argtypes = [C.POINTER(Dist), C.c_int, C.c_double, _dp]
         L.co_density.restype = C.c_double
         L.co_density.argtypes = [C.POINTER(Dist), C.c_double]
         L.co_normed_density.restype = C.c_double
@@ -203,6 +206,18 @@ def moment(d, q):
 def get_moments(d):
     out = np.zeros(nparams(d.type))
     lib().co_get_moments(C.byref(d), _d(out))
+    return out
+
+
+def partial_moment(d, q, x_threshold):
+    return lib().co_partial_moment(C.byref(d), float(q), float(x_threshold))
+
+
+def get_standard_N_q(pdists, size_cutoff=1e-6):
+    """(N_liq, N_rai, M_liq, M_rai), ParticleDistributions.jl:634-687."""
+    arr = (Dist * len(pdists))(*pdists)
+    out = np.zeros(4)
+    lib().co_get_standard_N_q(arr, len(pdists), float(size_cutoff), _d(out))
     return out
 
 

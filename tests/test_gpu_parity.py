@@ -746,3 +746,32 @@ def test_fp32_fast_threshold_path_error_report(gpu_cloudy, oracle):
     # mass is still conserved to fp32 rounding of the two mass tendencies
     net = np.abs(got[1] + got[4])
     assert np.all(net[fin[1]] <= 3e-7 * (np.abs(got[1]) + np.abs(got[4]))[fin[1]] + 1e-300)
+
+
+def test_standard_N_q_diagnostics(gpu_cloudy, oracle, kats):
+    """get_standard_N_q (ParticleDistributions.jl:634-687) batched: the reference KAT (Exp(10,1) + Gamma(5,10,2):
+    N_liq + N_rai = 15, M_liq + M_rai = 110) and random mixtures against the oracle."""
+    cloudy = gpu_cloudy
+    cd = cloudy.CoalescenceData(cloudy.CoalescenceTensor([[1.0]]), (2, 3), (INF, INF))
+    plan = cd.plan([0, 1])
+    kat = np.array([[10.0], [10.0], [5.0], [100.0], [3000.0]]).repeat(4, axis=1)   # moments of Exp(10,1), Gamma(5,10,2)
+    for cutoff in kats["get_standard_N_q"]["cutoffs"]:
+        q = cloudy.get_standard_N_q(plan, dev(cloudy, kat), cutoff).to_numpy()[:, 0]
+        assert q[0] + q[1] == pytest.approx(15.0, rel=1e-12) and q[2] + q[3] == pytest.approx(110.0, rel=1e-12)
+        want = oracle.get_standard_N_q([oracle.make_dist(0, 10.0, 1.0), oracle.make_dist(1, 5.0, 10.0, 2.0)], cutoff)
+        assert np.allclose(q, want, rtol=1e-12)
+    dist_types = [1, 2, 0]
+    par, op, _ = make_case(cloudy, oracle, dist_types, [[1.0]], (INF,) * 3, bench.NORMS)
+    plan = par.coal_data.plan(dist_types)
+    n = 500
+    mom = mixed_moments(dist_types, n, seed=2)
+    q = cloudy.get_standard_N_q(plan, dev(cloudy, mom), 1e-9).to_numpy()
+    prm = oracle.update_dist_batch(op, mom)
+    for i in range(0, n, 5):
+        pd = [oracle.make_dist(dist_types[m], prm[3 * m, i], prm[3 * m + 1, i], prm[3 * m + 2, i]) for m in range(3)]
+        w = oracle.get_standard_N_q(pd, 1e-9 / bench.NORMS[1]) * np.array([1e6, 1e6, 1e6 * 1e-9, 1e6 * 1e-9])
+        tot = np.array([w[0] + w[1], w[0] + w[1], w[2] + w[3], w[2] + w[3]])
+        assert np.all(np.abs(q[:, i] - w) <= 1e-12 * tot + 1e-300), i
+    with pytest.raises(cloudy.CloudyError):
+        cloudy.get_standard_N_q(cloudy.CoalescenceData(cloudy.CoalescenceTensor([[1.0]]), (3,), (INF,)).plan([3]),
+                                dev(cloudy, np.ones((3, 4))), 1e-6)

@@ -15,7 +15,7 @@ INF = float("inf")
 def _header_symbols():
     txt = open(os.path.join(ROOT, "include", "cloudy_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(cloudy_[a-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(cloudy_[A-Za-z0-9_]+)\s*\(", txt)))
 
 
 def test_library_exports_every_declared_symbol(cloudy):

@@ -349,3 +349,17 @@ def test_condensation_kats(oracle, kats):
     # independent value of the fractional moment: Exp(1,1): M_{1/3} = Gamma(4/3)
     got = oracle.get_cond_evap([mk(oracle, ["exponential", 1.0, 1.0])], 0.01, 1e-6)
     assert got[1] == pytest.approx(3 * 1e-6 * 0.01 * math.gamma(4 / 3) * C, rel=1e-14)
+
+
+def test_get_standard_N_q_kats(oracle, kats):
+    """test_ParticleDistributions_correctness.jl:234-247: liquid + rain number / mass add up to the totals and the
+    cloud part grows with the cutoff."""
+    e = kats["get_standard_N_q"]
+    pd = [mk(oracle, s) for s in e["pdists"]]
+    q1, q2 = (oracle.get_standard_N_q(pd, c) for c in e["cutoffs"])
+    for q in (q1, q2):
+        assert q[0] + q[1] == pytest.approx(e["N_total"], rel=e["rtol"])
+        assert q[2] + q[3] == pytest.approx(e["M_total"], rel=e["rtol"])
+    assert q1[0] > q2[0] and q1[2] > q2[2]
+    # closed form of one term: Exp(10, 1): N below 1.0 = 10 (1 - e^-1)
+    assert oracle.partial_moment(pd[0], 0.0, 1.0) == pytest.approx(10.0 * (1 - math.exp(-1.0)), rel=1e-14)
