@@ -775,3 +775,28 @@ def test_standard_N_q_diagnostics(gpu_cloudy, oracle, kats):
     with pytest.raises(cloudy.CloudyError):
         cloudy.get_standard_N_q(cloudy.CoalescenceData(cloudy.CoalescenceTensor([[1.0]]), (3,), (INF,)).plan([3]),
                                 dev(cloudy, np.ones((3, 4))), 1e-6)
+
+
+def test_unaligned_planes_take_the_one_parcel_per_lane_kernel(gpu_cloudy, oracle):
+    """The two-parcels-per-lane kernel needs 16-byte aligned planes (even ld, aligned base); otherwise the ABI falls
+    back to the one-parcel kernel.  Same numbers either way."""
+    cloudy = gpu_cloudy
+    L = cloudy.lib()
+    n, ld = 4097, 4099                      # odd leading dimension
+    wl = bench.make_workload("cfg3a", n, seed=17)
+    plan = wl["coal_data"].plan(wl["dist_types"])
+    buf = np.zeros((6, ld))
+    buf[:, :n] = wl["mom"]
+    m, dm = dev(cloudy, buf), dev(cloudy, np.zeros((6, ld)))
+    assert L.cloudy_coal_rhs(plan.handle, n, ld, m.ptr, dm.ptr, None) == 0
+    out_odd = dm.to_numpy()[:, :n]
+    # even ld but base pointers offset by one element (8-byte aligned only)
+    ld2 = 4100
+    big = np.zeros(6 * ld2 + 1)
+    big[1:].reshape(6, ld2)[:, :n] = wl["mom"]
+    mb, db = dev(cloudy, big[None, :]), dev(cloudy, np.zeros((1, 6 * ld2 + 1)))
+    assert L.cloudy_coal_rhs(plan.handle, n, ld2, mb.ptr + 8, db.ptr + 8, None) == 0
+    out_off = db.to_numpy()[0, 1:].reshape(6, ld2)[:, :n]
+    # aligned reference run (two parcels per lane)
+    d = run_rhs(cloudy, wl["par"], wl["mom"])
+    assert np.array_equal(out_odd, d) and np.array_equal(out_off, d)
