@@ -403,6 +403,34 @@ def main():
             }
             del mv, dmv
 
+    if not args.no_variants and args.workload == "cfg3a":
+        # BASELINE configs[4]: Long's kernel pieces (cfg3b thresholds) + sedimentation flux, float planes
+        n5 = 12_500_000
+        wl5 = make_workload("cfg3b", n5, seed=SEED + 1000 * rank)
+        vel = ((50.0, 1.0 / 6),)   # rainshaft_gamma_mixture.jl:44
+        m5 = pkg.DeviceArray.from_numpy(wl5["mom"].astype(np.float32))
+        cs5, sf5 = pkg.DeviceArray.zeros(nmom, n5, np.float32), pkg.DeviceArray.zeros(nmom, n5, np.float32)
+        for vname, dt_code in (("cfg5_f32_planes", 1), ("cfg5_f32_fast", 2)):
+            plan5 = wl5["coal_data"].plan(wl5["dist_types"], vel=vel, dtype=dt_code)
+            L = pkg.lib()
+            for _ in range(2):
+                pkg._lib.check(L.cloudy_rainshaft_sources(plan5.handle, n5, n5, m5.ptr, cs5.ptr, sf5.ptr, None))
+            pkg._lib.check(L.cloudy_stream_synchronize(None))
+            reps = 5
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                pkg._lib.check(L.cloudy_rainshaft_sources(plan5.handle, n5, n5, m5.ptr, cs5.ptr, sf5.ptr, None))
+            pkg._lib.check(L.cloudy_stream_synchronize(None))
+            ms5 = 1e3 * (time.perf_counter() - t0) / reps
+            variants[vname] = {
+                "workload": f"cfg5: {n5} cells/GPU, cfg3b tensors and thresholds + sedimentation flux vel={vel}, "
+                            "float planes in HBM (6 moments in, 6 coalescence sources + 6 fluxes out = 72 B/cell), "
+                            + ("fp64 arithmetic" if dt_code == 1 else "single-precision Simpson pass")
+                            + "; checked against the fp64 oracle in tests/test_gpu_parity.py",
+                "value": n5 * world / (ms5 * 1e-3), "unit": "cell-RHS/s", "launch_ms_wall": ms5,
+            }
+        del m5, cs5, sf5
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = _cpu_baseline(args.workload)

@@ -1098,22 +1098,29 @@ __global__ void __launch_bounds__(kBlock)
             const bool gam = (dtp == DIST_GAMMA || dtp == DIST_EXP);
             const double lnth = (dtp == DIST_LOGNORMAL) ? th[m] : log(th[m]);
             const double lgk = gam ? lgamma(kk[m]) : 0.0;
-            for (int j = 0; j < A.np[m]; ++j) {
-                double s = 0.0;
-                for (int v = 0; v < S.n_vel; ++v) {
-                    const double q = double(j) + S.vel[v][1];
-                    double e;  // log(M_q / n), ParticleDistributions.jl:177-207
-                    if (gam)
-                        e = fma(q, lnth, lgamma(q + kk[m]) - lgk);
-                    else if (dtp == DIST_MONO)
-                        e = q * lnth;
-                    else
-                        e = fma(q, lnth, 0.5 * q * q * (kk[m] * kk[m]));
-                    const double mom = nn[m] * exp(e);
-                    s -= S.vel[v][0] * mom;
+            double s[3] = {0.0, 0.0, 0.0};
+            for (int v = 0; v < S.n_vel; ++v) {
+                const double qv = S.vel[v][1];
+                if (gam) {
+                    // M_qv from the log-gamma difference once, the higher orders by M_{q+1} = M_q theta (k + q)
+                    double mom = nn[m] * (qv == 0.0 ? 1.0 : exp(fma(qv, lnth, lgamma(qv + kk[m]) - lgk)));
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        s[j] = fma(-S.vel[v][0], mom, s[j]);
+                        mom *= th[m] * (kk[m] + qv + double(j));
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const double q = double(j) + qv;  // log(M_q / n), ParticleDistributions.jl:193-207
+                        const double e = (dtp == DIST_MONO) ? q * lnth : fma(q, lnth, 0.5 * q * q * (kk[m] * kk[m]));
+                        s[j] = fma(-S.vel[v][0], nn[m] * exp(e), s[j]);
+                    }
                 }
-                out[(size_t)(off + j) * ld + i] = (TIO)(s * A.out_scale[3 * m + j]);
             }
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (j < A.np[m]) out[(size_t)(off + j) * ld + i] = (TIO)(s[j] * A.out_scale[3 * m + j]);
         }
     }
 }
@@ -1138,16 +1145,15 @@ __global__ void __launch_bounds__(kBlock)
             const double lnth = (dtp == DIST_LOGNORMAL) ? th[m] : log(th[m]);
             const double lgk = gam ? lgamma(kk[m]) : 0.0;
             out[(size_t)off * ld + i] = (TIO)0.0;
+            // M_{1/3} from the log-gamma difference, M_{4/3} = M_{1/3} theta (k + 1/3) for the Gamma family
+            double mom = 0.0;
             for (int j = 1; j < A.np[m]; ++j) {
                 const double q = double(j) - 2.0 / 3.0;
-                double e;
                 if (gam)
-                    e = fma(q, lnth, lgamma(q + kk[m]) - lgk);
-                else if (dtp == DIST_MONO)
-                    e = q * lnth;
+                    mom = (j == 1) ? nn[m] * exp(fma(q, lnth, lgamma(q + kk[m]) - lgk))
+                                   : mom * (th[m] * (kk[m] + (q - 1.0)));
                 else
-                    e = fma(q, lnth, 0.5 * q * q * (kk[m] * kk[m]));
-                const double mom = nn[m] * exp(e);
+                    mom = nn[m] * exp((dtp == DIST_MONO) ? q * lnth : fma(q, lnth, 0.5 * q * q * (kk[m] * kk[m])));
                 out[(size_t)(off + j) * ld + i] = (TIO)(coef * sv * double(j) * mom * A.out_scale[3 * m + j]);
             }
         }
