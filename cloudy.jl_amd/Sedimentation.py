@@ -58,3 +58,22 @@ def make_rainshaft_rhs(coal_type=None):
         return o
 
     return rhs
+
+
+def solve_rainshaft_ssprk33(par, u, n_steps, out=None, stream=None):
+    """`solve(ODEProblem(make_rainshaft_rhs(...), m, tspan, p), SSPRK33(), dt = p.dt)` of the rainshaft drivers
+    (rainshaft_gamma_mixture.jl:59-60), final state only, for a batch of independent columns of `par.nz` <= 256 cells:
+    one launch, state in registers, flux exchange through LDS (cloudy_rainshaft_ssprk33_steps).  `u` is advanced in
+    place unless `out` is given."""
+    from .box_model import _plan_for
+    from .device import dtype_code
+
+    plan = _plan_for(par, dtype_code(u))
+    ptr, planes, n, ld = as_device(u)
+    nz = int(getattr(par, "nz", n))
+    if n % nz:
+        raise ValueError("number of cells must be a multiple of par.nz")
+    optr = as_device(out)[0] if out is not None else ptr
+    _lib.check(_lib.lib().cloudy_rainshaft_ssprk33_steps(plan.handle, nz, n // nz, ld, ptr, optr, float(par.dz),
+                                                         float(par.dt), int(n_steps), stream))
+    return out if out is not None else u

@@ -63,6 +63,7 @@ SYMBOLS = {
     "cloudy_standard_N_q": (_i, [_vp, _sz, _sz, _vp, C.c_double, _vp, _vp]),
     "cloudy_rainshaft_sources": (_i, [_vp, _sz, _sz, _vp, _vp, _vp, _vp]),
     "cloudy_rainshaft_rhs": (_i, [_vp, _sz, _sz, _sz, _vp, C.c_double, _vp, _vp, _vp]),
+    "cloudy_rainshaft_ssprk33_steps": (_i, [_vp, _sz, _sz, _sz, _vp, _vp, C.c_double, C.c_double, C.c_int, _vp]),
     "cloudy_moment_sums": (_i, [_vp, _sz, _sz, _i, _vp, _vp, _vp]),
     "cloudy_device_count": (_i, []),
     "cloudy_set_device": (_i, [_i]),

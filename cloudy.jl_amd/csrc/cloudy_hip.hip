@@ -457,12 +457,36 @@ int cloudy_rainshaft_rhs(const cloudy_plan *plan, size_t nz, size_t n_columns, s
     const unsigned g = (unsigned)((n + kBlock - 1) / kBlock);
     if (plan->h.dtype != CLOUDY_F64)
         hipLaunchKernelGGL(rainshaft_divergence_kernel<float>, dim3(g), dim3(kBlock), 0, (hipStream_t)stream, n, ld,
-                           plan->h.nmom, nz, 1.0 / dz, (const float *)flux_work_dev, (float *)rhs_dev);
+                           plan->h.nmom, nz, dz, (const float *)flux_work_dev, (float *)rhs_dev);
     else
         hipLaunchKernelGGL(rainshaft_divergence_kernel<double>, dim3(g), dim3(kBlock), 0, (hipStream_t)stream, n, ld,
-                           plan->h.nmom, nz, 1.0 / dz, (const double *)flux_work_dev, (double *)rhs_dev);
+                           plan->h.nmom, nz, dz, (const double *)flux_work_dev, (double *)rhs_dev);
     HIP_TRY(hipGetLastError());
     return CLOUDY_OK;
+}
+
+int cloudy_rainshaft_ssprk33_steps(const cloudy_plan *plan, size_t nz, size_t n_columns, size_t ld, const void *u_in_dev,
+                                   void *u_out_dev, double dz, double dt, int n_steps, void *stream) {
+    const size_t n = nz * n_columns;
+    int rc = check_batch(plan, n, ld, u_in_dev, u_out_dev);
+    if (rc) return rc;
+    if (nz < 1 || !(dz > 0)) return fail(CLOUDY_EINVAL, "nz must be >= 1 and dz positive");
+    if (n_steps < 0 || !(dt == dt)) return fail(CLOUDY_EINVAL, "n_steps must be >= 0 and dt not NaN");
+    if (plan->h.n_vel < 1) return fail(CLOUDY_EINVAL, "plan has no terminal-velocity coefficients (n_vel = 0)");
+    if (plan->h.threshold_style != CLOUDY_FIXED_THRESHOLD)
+        return fail(CLOUDY_EINVAL, "make_rainshaft_rhs uses FixedThreshold (rainshaft_helpers.jl:70)");
+    if (nz > (size_t)kBlock)
+        return fail(CLOUDY_EUNSUPPORTED,
+                    "the fused column integrator keeps a column inside one workgroup: nz <= %d; step taller columns "
+                    "with cloudy_rainshaft_rhs",
+                    kBlock);
+    if (n == 0) return CLOUDY_OK;
+    LaunchReq r{OP_RAINSHAFT_SSPRK33, IN_MOMENTS, 1, 1, n, ld, u_in_dev, u_out_dev, nullptr, (hipStream_t)stream};
+    r.dt = dt;
+    r.n_steps = n_steps;
+    r.nz = nz;
+    r.dz = dz;
+    return run(plan, r);
 }
 
 int cloudy_moment_sums(const cloudy_plan *plan, size_t n, size_t ld, int planes, const void *arr_dev, double *sums_dev,

@@ -28,10 +28,10 @@ struct HostPlan {
     double *nodes_dev = nullptr;                        // [n_nodes][kNodeStride]
     int n_nodes = 0;
     double *partial_dev = nullptr;                      // moment_sums workspace
-    void *kargs_dev = nullptr;                          // KArgs<N,P> of (moments in, physical out), uploaded at plan creation
+    void *kargs_dev = nullptr;                          // KArgs<N,P> of (moments in, physical out) followed by SediArgs, uploaded at plan creation
 };
 
-enum Op { OP_COAL = 0, OP_UPDATE_DIST = 1, OP_FINITE_2D = 2, OP_SEDI = 3, OP_SSPRK33 = 4, OP_COND = 5, OP_PREPARE = 6 /* plan creation: upload the constant block */, OP_NQ = 7 };
+enum Op { OP_COAL = 0, OP_UPDATE_DIST = 1, OP_FINITE_2D = 2, OP_SEDI = 3, OP_SSPRK33 = 4, OP_COND = 5, OP_PREPARE = 6 /* plan creation: upload the constant block */, OP_NQ = 7, OP_RAINSHAFT_SSPRK33 = 8 };
 
 struct LaunchReq {
     int op;
@@ -47,6 +47,8 @@ struct LaunchReq {
     int n_steps = 0;  // OP_SSPRK33
     double coef = 0.0, s_scalar = 0.0;  // OP_COND
     const double *s_dev = nullptr;      // OP_COND (optional per-parcel supersaturation)
+    size_t nz = 0;    // OP_RAINSHAFT_SSPRK33: cells per column (n = nz * n_columns)
+    double dz = 0.0;  // OP_RAINSHAFT_SSPRK33
 };
 
 // one per instantiation unit (inst_n<N>_p<P>.hip), so that the kernel families compile in parallel

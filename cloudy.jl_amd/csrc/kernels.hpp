@@ -1080,7 +1080,41 @@ struct SediArgs {
 };
 
 // get_sedimentation_flux, Sedimentation.jl:22-37: flux[i][j] = -sum_v vel_v0 * M^i_{j-1+vel_v1}
-// with the fractional-order moment n theta^q Gamma(q+k)/Gamma(k).
+// with the fractional-order moment n theta^q Gamma(q+k)/Gamma(k); normalised units.
+template <int N>
+__device__ __forceinline__ void sedi_flux_parcel(const int32_t (&dist_type)[N], const SediArgs &S, const double (&nn)[N],
+                                                 const double (&th)[N], const double (&kk)[N], double (&fl)[N][3]) {
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        const int dtp = dist_type[m];
+        const bool gam = (dtp == DIST_GAMMA || dtp == DIST_EXP);
+        const double lnth = (dtp == DIST_LOGNORMAL) ? th[m] : log(th[m]);
+        const double lgk = gam ? lgamma(kk[m]) : 0.0;
+        double s[3] = {0.0, 0.0, 0.0};
+        for (int v = 0; v < S.n_vel; ++v) {
+            const double qv = S.vel[v][1];
+            if (gam) {
+                // M_qv from the log-gamma difference once, the higher orders by M_{q+1} = M_q theta (k + q)
+                double mom = nn[m] * (qv == 0.0 ? 1.0 : exp(fma(qv, lnth, lgamma(qv + kk[m]) - lgk)));
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    s[j] = fma(-S.vel[v][0], mom, s[j]);
+                    mom *= th[m] * (kk[m] + qv + double(j));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const double q = double(j) + qv;  // log(M_q / n), ParticleDistributions.jl:193-207
+                    const double e = (dtp == DIST_MONO) ? q * lnth : fma(q, lnth, 0.5 * q * q * (kk[m] * kk[m]));
+                    s[j] = fma(-S.vel[v][0], nn[m] * exp(e), s[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) fl[m][j] = s[j];
+    }
+}
+
 template <int N, int P, typename TIO>
 __global__ void __launch_bounds__(kBlock)
     sedi_flux_kernel(const KArgs<N, P> A, const SediArgs S, size_t n, size_t ld, const TIO *__restrict__ in,
@@ -1089,39 +1123,119 @@ __global__ void __launch_bounds__(kBlock)
     // constant of the body into registers for the whole kernel (measured: 256 VGPRs + spills vs ~100).
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) {
-        double nn[N], th[N], kk[N];
+        double nn[N], th[N], kk[N], fl[N][3];
         load_parcel<N, P, TIO>(A, i, ld, in, nn, th, kk);
+        sedi_flux_parcel<N>(A.dist_type, S, nn, th, kk, fl);
 #pragma unroll
-        for (int m = 0; m < N; ++m) {
-            const int off = A.off[m];
-            const int dtp = A.dist_type[m];
-            const bool gam = (dtp == DIST_GAMMA || dtp == DIST_EXP);
-            const double lnth = (dtp == DIST_LOGNORMAL) ? th[m] : log(th[m]);
-            const double lgk = gam ? lgamma(kk[m]) : 0.0;
-            double s[3] = {0.0, 0.0, 0.0};
-            for (int v = 0; v < S.n_vel; ++v) {
-                const double qv = S.vel[v][1];
-                if (gam) {
-                    // M_qv from the log-gamma difference once, the higher orders by M_{q+1} = M_q theta (k + q)
-                    double mom = nn[m] * (qv == 0.0 ? 1.0 : exp(fma(qv, lnth, lgamma(qv + kk[m]) - lgk)));
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        s[j] = fma(-S.vel[v][0], mom, s[j]);
-                        mom *= th[m] * (kk[m] + qv + double(j));
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const double q = double(j) + qv;  // log(M_q / n), ParticleDistributions.jl:193-207
-                        const double e = (dtp == DIST_MONO) ? q * lnth : fma(q, lnth, 0.5 * q * q * (kk[m] * kk[m]));
-                        s[j] = fma(-S.vel[v][0], nn[m] * exp(e), s[j]);
-                    }
-                }
-            }
+        for (int m = 0; m < N; ++m)
 #pragma unroll
             for (int j = 0; j < 3; ++j)
-                if (j < A.np[m]) out[(size_t)(off + j) * ld + i] = (TIO)(s[j] * A.out_scale[3 * m + j]);
+                if (j < A.np[m]) out[(size_t)(A.off[m] + j) * ld + i] = (TIO)(fl[m][j] * A.out_scale[3 * m + j]);
+    }
+}
+
+// solve(ODEProblem(make_rainshaft_rhs(...), m, tspan, p), SSPRK33(), dt) of the rainshaft drivers
+// (test/examples/Analytical/rainshaft_gamma_mixture.jl:59-60, rainshaft_helpers.jl:45-89) for many independent
+// columns of nz <= kBlock cells: a workgroup owns floor(kBlock / nz) whole columns, the state stays in registers over
+// all stages and steps, and the only cross-cell coupling -- the upwind flux of the cell above -- goes through LDS.
+// Every RHS evaluation first clamps negative moments of its argument to zero IN PLACE (rainshaft_helpers.jl:52 mutates
+// the array the integrator passed), which includes the FSAL evaluation on the final state of each step.
+template <int N, int P, int MODE, typename TIO>
+__global__ void __launch_bounds__(kBlock)
+    rainshaft_ssprk33_kernel(const KArgs<N, P> *__restrict__ Ag, const double *__restrict__ nodes, int nz,
+                             size_t n_columns, size_t ld, const TIO *u_in, TIO *u_out, double dt, double dz,
+                             int n_steps) {
+    __shared__ double sh_flux[N * 3][kBlock];
+    const KArgs<N, P> &A = *Ag;
+    const int t = threadIdx.x;
+    const int cpb = kBlock / nz;  // whole columns per workgroup
+    const int cl = t / nz, iz = t - cl * nz;
+    const size_t col = (size_t)blockIdx.x * cpb + cl;
+    const bool active = (cl < cpb) && (col < n_columns);
+    const size_t i = col * (size_t)nz + iz;
+    double u[N][3], up[N][3];
+#pragma unroll
+    for (int m = 0; m < N; ++m)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            u[m][q] = (active && q < A.np[m]) ? (double)u_in[(size_t)(A.off[m] + q) * ld + i] : 0.0;
+#pragma unroll 1
+    for (int step = 0; step < n_steps; ++step) {
+#pragma unroll 1
+        for (int stage = 0; stage < 3; ++stage) {
+            size_t opaque_zero = 0;  // see ssprk33_kernel: keeps the tensor s_loads inside the stage
+            asm volatile("" : "+s"(opaque_zero));
+            const KArgs<N, P> &As = *(Ag + opaque_zero);
+            const SediArgs &S = *reinterpret_cast<const SediArgs *>(Ag + opaque_zero + 1);
+            double f[N][3], fl[N][3];
+            if (active) {
+                double nn[N], th[N], kk[N], acc[N][3];
+                bool all_small = true;
+#pragma unroll
+                for (int m = 0; m < N; ++m) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) u[m][q] = u[m][q] < 0.0 ? 0.0 : u[m][q];  // rainshaft_helpers.jl:52
+                    const double m0 = div_by_const(u[m][0], As.norm[3 * m + 0], As.inv_norm[3 * m + 0]);
+                    const double m1 = div_by_const(u[m][1], As.norm[3 * m + 1], As.inv_norm[3 * m + 1]);
+                    const double m2 = div_by_const(u[m][2], As.norm[3 * m + 2], As.inv_norm[3 * m + 2]);
+                    all_small = all_small && (m0 < kEps) && (m1 < kEps) && (As.np[m] != 3 || m2 < kEps);
+                    invert_closure(As.dist_type[m], m0, m1, m2, As.kmin, As.kmax, nn[m], th[m], kk[m]);
+                }
+                coal_ints_parcel<N, P, MODE>(As, nodes, nn, th, kk, acc);
+                sedi_flux_parcel<N>(As.dist_type, S, nn, th, kk, fl);
+#pragma unroll
+                for (int m = 0; m < N; ++m)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const bool live = q < As.np[m];
+                        f[m][q] = (live && !all_small) ? acc[m][q] * As.out_scale[3 * m + q] : 0.0;  // :67-72
+                        fl[m][q] = live ? fl[m][q] * As.out_scale[3 * m + q] : 0.0;
+                        sh_flux[3 * m + q][t] = fl[m][q];
+                    }
+            }
+            __syncthreads();
+            if (active) {
+                const bool top = (iz == nz - 1);  // zero flux above the top cell (:80-81)
+#pragma unroll
+                for (int m = 0; m < N; ++m)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const double f_up = top ? 0.0 : sh_flux[3 * m + q][t + 1];
+                        f[m][q] += -(f_up - fl[m][q]) / dz;  // :83-85
+                    }
+                if (stage == 0) {
+#pragma unroll
+                    for (int m = 0; m < N; ++m)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            up[m][q] = u[m][q];
+                            u[m][q] = up[m][q] + dt * f[m][q];
+                        }
+                } else if (stage == 1) {
+#pragma unroll
+                    for (int m = 0; m < N; ++m)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) u[m][q] = (3.0 * up[m][q] + u[m][q] + dt * f[m][q]) * 0.25;
+                } else {
+#pragma unroll
+                    for (int m = 0; m < N; ++m)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+                            u[m][q] = div_by_const(up[m][q] + 2.0 * u[m][q] + 2.0 * dt * f[m][q], 3.0, 1.0 / 3.0);
+                }
+            }
+            __syncthreads();
         }
+    }
+    if (active) {
+#pragma unroll
+        for (int m = 0; m < N; ++m)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                if (q < A.np[m]) {
+                    const double v = (n_steps > 0 && u[m][q] < 0.0) ? 0.0 : u[m][q];  // the FSAL evaluation's clamp
+                    u_out[(size_t)(A.off[m] + q) * ld + i] = (TIO)v;
+                }
     }
 }
 

@@ -41,6 +41,15 @@ void fill_args(const HostPlan &h, const LaunchReq &r, KArgs<N, P> &A) {
                 for (int b = 0; b < P; ++b) A.c[j][k][a][b] = h.c[j][k][a][b];
 }
 
+inline void fill_sedi(const HostPlan &h, SediArgs &S) {
+    S.n_vel = h.n_vel;
+    S.pad = 0;
+    for (int v = 0; v < 4; ++v) {
+        S.vel[v][0] = v < h.n_vel ? h.vel_n[v][0] : 0.0;
+        S.vel[v][1] = v < h.n_vel ? h.vel_n[v][1] : 0.0;
+    }
+}
+
 // kernels that exist for both plane types (double / float storage)
 template <int N, int P, typename TIO>
 hipError_t launch_io(const HostPlan &h, const LaunchReq &r, const KArgs<N, P> &A) {
@@ -76,12 +85,7 @@ hipError_t launch_io(const HostPlan &h, const LaunchReq &r, const KArgs<N, P> &A
     }
     case OP_SEDI: {
         SediArgs S;
-        S.n_vel = h.n_vel;
-        S.pad = 0;
-        for (int v = 0; v < 4; ++v) {
-            S.vel[v][0] = v < h.n_vel ? h.vel_n[v][0] : 0.0;
-            S.vel[v][1] = v < h.n_vel ? h.vel_n[v][1] : 0.0;
-        }
+        fill_sedi(h, S);
         hipLaunchKernelGGL((sedi_flux_kernel<N, P, TIO>), dim3(grid_for(r.n, false)), dim3(kBlock), 0, r.stream, A, S,
                            r.n, r.ld, in, out);
         break;
@@ -109,6 +113,22 @@ hipError_t launch_io(const HostPlan &h, const LaunchReq &r, const KArgs<N, P> &A
                                h.nodes_dev, r.n, r.ld, in, out, r.dt, r.n_steps);
         break;
     }
+    case OP_RAINSHAFT_SSPRK33: {
+        if (!h.kargs_dev) return hipErrorNotInitialized;
+        if (r.nz < 1 || r.nz > (size_t)kBlock) return hipErrorInvalidValue;
+        const KArgs<N, P> *Ad = static_cast<const KArgs<N, P> *>(h.kargs_dev);
+        const size_t cpb = kBlock / r.nz, n_columns = r.n / r.nz;
+        const unsigned g = (unsigned)((n_columns + cpb - 1) / cpb);
+        if (h.mode == MODE_ALLINF)
+            hipLaunchKernelGGL((rainshaft_ssprk33_kernel<N, P, MODE_ALLINF, TIO>), dim3(g), dim3(kBlock), 0, r.stream,
+                               Ad, h.nodes_dev, (int)r.nz, n_columns, r.ld, in, out, r.dt, r.dz, r.n_steps);
+        else if (h.mode == MODE_FIXED)
+            hipLaunchKernelGGL((rainshaft_ssprk33_kernel<N, P, MODE_FIXED, TIO>), dim3(g), dim3(kBlock), 0, r.stream,
+                               Ad, h.nodes_dev, (int)r.nz, n_columns, r.ld, in, out, r.dt, r.dz, r.n_steps);
+        else
+            return hipErrorInvalidValue;  // make_rainshaft_rhs is FixedThreshold only (rainshaft_helpers.jl:70)
+        break;
+    }
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -120,11 +140,18 @@ hipError_t launch_np(const HostPlan &h, const LaunchReq &r) {
     fill_args<N, P>(h, r, A);
     const bool heavy = h.mode != MODE_ALLINF;
     switch (r.op) {
-    case OP_PREPARE: {  // constant block in device memory for ssprk33_kernel (moments in, physical units out)
+    case OP_PREPARE: {  // constant block in device memory for the fused integrators (moments in, physical units out)
+        struct Block {  // SediArgs directly behind KArgs: rainshaft_ssprk33_kernel reads it at (Ag + 1)
+            KArgs<N, P> A;
+            SediArgs S;
+        } blk;
+        static_assert(sizeof(KArgs<N, P>) % 8 == 0 && offsetof(Block, S) == sizeof(KArgs<N, P>), "block layout");
+        blk.A = A;
+        fill_sedi(h, blk.S);
         void *dev = nullptr;
-        hipError_t e = hipMalloc(&dev, sizeof(A));
+        hipError_t e = hipMalloc(&dev, sizeof(blk));
         if (e != hipSuccess) return e;
-        e = hipMemcpy(dev, &A, sizeof(A), hipMemcpyHostToDevice);
+        e = hipMemcpy(dev, &blk, sizeof(blk), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             (void)hipFree(dev);
             return e;
@@ -137,6 +164,7 @@ hipError_t launch_np(const HostPlan &h, const LaunchReq &r) {
     case OP_COND:
     case OP_NQ:
     case OP_SSPRK33:
+    case OP_RAINSHAFT_SSPRK33:
         // get_coal_ints on (n, theta, k) planes is an fp64 interface for every plan
         if (h.dtype != CLOUDY_F64 && r.input_kind == IN_MOMENTS) return launch_io<N, P, float>(h, r, A);
         return launch_io<N, P, double>(h, r, A);

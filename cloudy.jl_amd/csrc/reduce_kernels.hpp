@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(kBlock)
 // top cell of a column = 0.  `rhs` holds the coalescence source on entry.
 template <typename TIO>
 __global__ void __launch_bounds__(kBlock)
-    rainshaft_divergence_kernel(size_t n, size_t ld, int planes, size_t nz, double inv_dz, const TIO *__restrict__ flux,
+    rainshaft_divergence_kernel(size_t n, size_t ld, int planes, size_t nz, double dz, const TIO *__restrict__ flux,
                                 TIO *__restrict__ rhs) {
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(kBlock)
     for (int q = 0; q < planes; ++q) {
         const double f0 = (double)flux[(size_t)q * ld + i];
         const double f1 = top ? 0.0 : (double)flux[(size_t)q * ld + i + 1];
-        rhs[(size_t)q * ld + i] = (TIO)((double)rhs[(size_t)q * ld + i] + (-(f1 - f0) * inv_dz));
+        rhs[(size_t)q * ld + i] = (TIO)((double)rhs[(size_t)q * ld + i] + (-(f1 - f0) / dz));  // rainshaft_helpers.jl:83-85
     }
 }
 

@@ -24,6 +24,8 @@
  *                                    test/examples/utils/rainshaft_helpers.jl:52-78
  *   cloudy_rainshaft_rhs          <- rhs(m, p, t) of make_rainshaft_rhs incl. the flux divergence
  *                                    test/examples/utils/rainshaft_helpers.jl:45-89
+ *   cloudy_rainshaft_ssprk33_steps <- solve(ODEProblem(make_rainshaft_rhs(...), m, tspan, p), SSPRK33(), dt = p.dt),
+ *                                    test/examples/Analytical/rainshaft_gamma_mixture.jl:59-60
  *   cloudy_standard_N_q           <- get_standard_N_q(pdists, size_cutoff)  ParticleDistributions.jl:634-687
  *   cloudy_cond_evap              <- rhs_condensation!(dmom, mom, p, s) / get_cond_evap
  *                                    test/examples/utils/box_model_helpers.jl:55-67, src/Sources/Condensation.jl:22-37
@@ -180,6 +182,17 @@ int cloudy_rainshaft_sources(const cloudy_plan *plan, size_t n_cells, size_t ld,
  * scratch (holds the cell fluxes on return). */
 int cloudy_rainshaft_rhs(const cloudy_plan *plan, size_t nz, size_t n_columns, size_t ld, const void *mom_dev, double dz,
                          void *flux_work_dev, void *rhs_dev, void *stream);
+
+/* n_steps SSPRK33 steps of the rainshaft right-hand side above for n_columns independent columns of nz <= 256 cells
+ * (what `solve(ODEProblem(rhs, m, tspan, p), SSPRK33(), dt = p.dt)` does in rainshaft_single_gamma.jl:52-53,
+ * rainshaft_gamma_mixture.jl:59-60), in ONE launch: a workgroup owns whole columns, the state stays in registers over
+ * all stages and steps and the upwind flux of the cell above is exchanged through LDS.  As in the reference, every RHS
+ * evaluation first clamps negative moments of its argument to zero in place (rainshaft_helpers.jl:52), including the
+ * FSAL evaluation on each step's result, so the returned state is clamped.  u_out_dev may equal u_in_dev.
+ * CLOUDY_EUNSUPPORTED for nz > 256 (step those with cloudy_rainshaft_rhs). */
+int cloudy_rainshaft_ssprk33_steps(const cloudy_plan *plan, size_t nz, size_t n_columns, size_t ld,
+                                   const void *u_in_dev, void *u_out_dev, double dz, double dt, int n_steps,
+                                   void *stream);
 
 /* sums_dev[q] = sum over parcels of plane q (fp64 accumulate); `planes` planes are reduced.
  * The multi-GPU conservation check all-reduces these nmom doubles (RCCL), see INTEGRATION.md. */

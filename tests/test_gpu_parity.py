@@ -800,3 +800,91 @@ def test_unaligned_planes_take_the_one_parcel_per_lane_kernel(gpu_cloudy, oracle
     # aligned reference run (two parcels per lane)
     d = run_rhs(cloudy, wl["par"], wl["mom"])
     assert np.array_equal(out_odd, d) and np.array_equal(out_off, d)
+
+
+def _oracle_rainshaft_ssprk33(oracle, op, u, nz, dz, dt, n_steps):
+    """OrdinaryDiffEq's SSPRK33 around the rainshaft rhs restated with the oracle's cell body; each evaluation clamps
+    its argument in place first (rainshaft_helpers.jl:52), the FSAL evaluation on the step result included."""
+    nmom, n = u.shape
+
+    def f(x):
+        np.maximum(x, 0.0, out=x)
+        cs, sf = oracle.rainshaft_cell_batch(op, x)
+        out = np.empty_like(x)
+        for c in range(n // nz):
+            s = slice(c * nz, (c + 1) * nz)
+            fl = np.concatenate([sf[:, s], np.zeros((nmom, 1))], axis=1)
+            out[:, s] = cs[:, s] + (-(fl[:, 1:] - fl[:, :-1]) / dz)
+        return out
+
+    u = u.copy()
+    for _ in range(n_steps):
+        k = f(u)
+        up = u
+        u = up + dt * k
+        k = f(u)
+        u = (3.0 * up + u + dt * k) / 4.0
+        k = f(u)
+        u = (up + 2.0 * u + 2.0 * dt * k) / 3.0
+        np.maximum(u, 0.0, out=u)
+    return u
+
+
+@pytest.mark.parametrize("case", ["gamma_mixture", "single_gamma"])
+def test_rainshaft_column_integrator_ssprk33(gpu_cloudy, oracle, case):
+    """cloudy_rainshaft_ssprk33_steps (one launch, state in registers, flux exchange through LDS) against the oracle
+    stepped by a numpy SSPRK33: rainshaft_gamma_mixture.jl:15-60 (20 cells over 3 km, two Gamma modes, Golovin b = 5,
+    thr (2e-10, Inf), vel ((50, 1/6),), dt = 1) and rainshaft_single_gamma.jl (one mode, thr Inf)."""
+    cloudy = gpu_cloudy
+    nz, dz, dt, n_steps = 20, 150.0, 1.0, 40
+    vel = ((50.0, 1.0 / 6),)
+    z = (np.arange(nz) + 0.5) * dz
+    at = ((z >= 0.5 * z.max() - dz / 2) & (z < 0.75 * z.max() - dz / 2)).astype(float)
+    if case == "gamma_mixture":
+        par, op, _ = make_case(cloudy, oracle, [1, 1], [[EPS / 1e6, 5.0], [5.0, 0.0]], (2e-10, INF), bench.NORMS,
+                               vel=vel)
+        amp = np.array([1e7, 1e-3, 2e-13, 0.0, 0.0, 0.0])
+    else:
+        par, op, _ = make_case(cloudy, oracle, [1], [[EPS / 1e6, 5.0], [5.0, 0.0]], (INF,), bench.NORMS, vel=vel)
+        amp = np.array([1e7, 1e-3, 2e-13])
+    par.dz, par.nz, par.dt = dz, nz, dt
+    cols = [np.outer(amp * s, at) for s in (1.0, 0.3, 3.0)]
+    shifted = np.outer(amp, np.roll(at, 3))              # a slab touching the top cell
+    dirty = np.outer(amp, at)
+    dirty[:, 2] = -1e-30                                 # negative round-off in an empty cell is clamped
+    ncol_pad = 13                                        # 12 columns per workgroup at nz = 20: spill into a second one
+    cols += [shifted, dirty] + [np.outer(amp * (0.5 + 0.1 * i), at) for i in range(ncol_pad - 5)]
+    u0 = np.concatenate(cols, axis=1)
+    want = _oracle_rainshaft_ssprk33(oracle, op, u0, nz, dz, dt, n_steps)
+    ud = dev(cloudy, u0)
+    out = cloudy.DeviceArray.zeros(*u0.shape)
+    cloudy.solve_rainshaft_ssprk33(par, ud, n_steps, out=out)
+    got = out.to_numpy()
+    assert np.array_equal(ud.to_numpy(), u0)             # out-of-place call leaves the input alone
+    ref = np.abs(want).max(axis=1, keepdims=True) + 1e-300
+    err = np.abs(got - want) / ref
+    print(f"rainshaft {case}: {n_steps} SSPRK33 steps, max |hip-oracle| / max|plane| = {err.max():.2e}")
+    assert err.max() < 1e-9
+    assert got.min() >= 0.0
+    # rain reached the cells below the initial slab; mass only leaves through the bottom
+    assert got[1, :5].sum() > 0.0 and got[1::3, :nz].sum() <= u0[1::3, :nz].sum() * (1 + 1e-12)
+    # the same steps driven from the host through make_rainshaft_rhs agree with the fused launch
+    rhs = cloudy.make_rainshaft_rhs()
+    u = u0[:, :2 * nz].copy()
+    for _ in range(3):
+        f = lambda x: rhs(dev(cloudy, np.maximum(x, 0.0, out=x)), par, 0.0).to_numpy()  # noqa: E731
+        up = u
+        u = up + dt * f(up)
+        u = (3.0 * up + u + dt * f(u)) / 4.0
+        u = (up + 2.0 * u + 2.0 * dt * f(u)) / 3.0
+    np.maximum(u, 0.0, out=u)
+    o3 = cloudy.DeviceArray.zeros(u.shape[0], 2 * nz)
+    cloudy.solve_rainshaft_ssprk33(par, dev(cloudy, u0[:, :2 * nz].copy()), 3, out=o3)
+    assert np.allclose(o3.to_numpy(), u, rtol=1e-12, atol=1e-13 * np.abs(u).max())
+    # in place, zero steps, and the nz limit
+    cloudy.solve_rainshaft_ssprk33(par, ud, 0)
+    assert np.array_equal(ud.to_numpy(), u0)
+    par.nz = 260
+    with pytest.raises(cloudy.CloudyError) as e:
+        cloudy.solve_rainshaft_ssprk33(par, cloudy.DeviceArray.zeros(u0.shape[0], 520), 1)
+    assert e.value.code == cloudy._lib.EUNSUPPORTED
