@@ -430,6 +430,50 @@ def main():
                 "value": n5 * world / (ms5 * 1e-3), "unit": "cell-RHS/s", "launch_ms_wall": ms5,
             }
         del m5, cs5, sf5
+        # the rainshaft drivers' time integration fused into one launch (cloudy_rainshaft_ssprk33_steps), fp64:
+        # (i) throughput on 5e5 independent columns of 20 cells, (ii) latency of the reference example itself
+        # (rainshaft_gamma_mixture.jl: ONE column of 20 cells, 1000 SSPRK33 steps of dt = 1 s)
+        nz, ncol, nst = 20, 500_000, 2
+        wlr = make_workload("cfg3b", nz * ncol, seed=SEED + 1000 * rank)
+        planr = wlr["coal_data"].plan(wlr["dist_types"], vel=vel)
+        ur = pkg.DeviceArray.from_numpy(wlr["mom"])
+        outr = pkg.DeviceArray.zeros(nmom, nz * ncol)
+        L = pkg.lib()
+
+        def _col_steps(n_columns, n_steps, dt):
+            pkg._lib.check(L.cloudy_rainshaft_ssprk33_steps(planr.handle, nz, n_columns, nz * ncol, ur.ptr, outr.ptr,
+                                                            150.0, dt, n_steps, None))
+            pkg._lib.check(L.cloudy_stream_synchronize(None))
+
+        _col_steps(ncol, nst, 1e-3)
+        t0 = time.perf_counter()
+        _col_steps(ncol, nst, 1e-3)
+        msr = 1e3 * (time.perf_counter() - t0)
+        variants["rainshaft_ssprk33_columns"] = {
+            "workload": f"cloudy_rainshaft_ssprk33_steps: {ncol} columns x {nz} cells/GPU, cfg3b tensors and thresholds "
+                        f"+ sedimentation vel={vel}, {nst} SSPRK33 steps (3 RHS evaluations each) in one launch, fp64",
+            "value": 3 * nst * nz * ncol * world / (msr * 1e-3), "unit": "cell-RHS/s", "ms_per_call": msr,
+        }
+        z = (np.arange(nz) + 0.5) * 150.0
+        at = ((z >= 0.5 * z.max() - 75.0) & (z < 0.75 * z.max() - 75.0)).astype(float)
+        kg = np.array([[2.220446049250313e-16 / 1e6, 5.0], [5.0, 0.0]])   # CoalescenceTensor(LinearKernelFunction(5), 1)
+        cd1 = pkg.CoalescenceData(pkg.CoalescenceTensor(kg), (3, 3), (2e-10, float("inf")), NORMS)
+        plan1 = cd1.plan([1, 1], vel=vel)
+        u1 = pkg.DeviceArray.from_numpy(np.outer([1e7, 1e-3, 2e-13, 0.0, 0.0, 0.0], at))
+        o1 = pkg.DeviceArray.zeros(6, nz)
+        for rep in range(2):
+            t0 = time.perf_counter()
+            pkg._lib.check(L.cloudy_rainshaft_ssprk33_steps(plan1.handle, nz, 1, nz, u1.ptr, o1.ptr, 150.0, 1.0, 1000,
+                                                            None))
+            pkg._lib.check(L.cloudy_stream_synchronize(None))
+            ms1 = 1e3 * (time.perf_counter() - t0)
+        variants["rainshaft_reference_example"] = {
+            "workload": "rainshaft_gamma_mixture.jl end to end: 1 column x 20 cells, two Gamma modes, Golovin b = 5, "
+                        "thr (2e-10, Inf), vel ((50, 1/6),), 1000 SSPRK33 steps of dt = 1 s in one launch",
+            "value": ms1, "unit": "ms per solve", "higher_is_better": False,
+            "column_mass_left": float(o1.to_numpy()[[1, 4]].sum() / 5e-3),
+        }
+        del ur, outr
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -51,6 +51,11 @@ struct LaunchReq {
     double dz = 0.0;  // OP_RAINSHAFT_SSPRK33
 };
 
+// the fused integrators (cloudy_ssprk33_steps, cloudy_rainshaft_ssprk33_steps) live in their own units
+// (int_n<N>_p<P>.hip), compiled with machine LICM off: see launch_int_impl.hpp
+template <int N, int P>
+hipError_t launch_int(const HostPlan &h, const LaunchReq &r);
+
 // one per instantiation unit (inst_n<N>_p<P>.hip), so that the kernel families compile in parallel
 hipError_t launch_n1_p1(const HostPlan &h, const LaunchReq &r);
 hipError_t launch_n1_p2(const HostPlan &h, const LaunchReq &r);

@@ -1,0 +1,5 @@
+// instantiation unit: the fused integrators of the N = 1 modes, P = 5 (tensor order 4) family
+#include "launch_int_impl.hpp"
+namespace cloudy {
+template hipError_t launch_int<1, 5>(const HostPlan &h, const LaunchReq &r);
+}  // namespace cloudy

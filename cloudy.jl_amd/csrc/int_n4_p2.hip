@@ -1,0 +1,5 @@
+// instantiation unit: the fused integrators of the N = 4 modes, P = 2 (tensor order 1) family
+#include "launch_int_impl.hpp"
+namespace cloudy {
+template hipError_t launch_int<4, 2>(const HostPlan &h, const LaunchReq &r);
+}  // namespace cloudy

@@ -1074,6 +1074,12 @@ __global__ void __launch_bounds__(kBlock)
     }
 }
 
+#ifdef CLOUDY_ABLATE_BARRIER
+#define CLOUDY_STAGE_BARRIER() ((void)0)
+#else
+#define CLOUDY_STAGE_BARRIER() __syncthreads()
+#endif
+
 struct SediArgs {
     int32_t n_vel, pad;
     double vel[4][2];  // already rescaled by norms[1]^vel[k][1] (rainshaft_helpers.jl:74-76)
@@ -1089,13 +1095,12 @@ __device__ __forceinline__ void sedi_flux_parcel(const int32_t (&dist_type)[N], 
         const int dtp = dist_type[m];
         const bool gam = (dtp == DIST_GAMMA || dtp == DIST_EXP);
         const double lnth = (dtp == DIST_LOGNORMAL) ? th[m] : log(th[m]);
-        const double lgk = gam ? lgamma(kk[m]) : 0.0;
         double s[3] = {0.0, 0.0, 0.0};
         for (int v = 0; v < S.n_vel; ++v) {
             const double qv = S.vel[v][1];
             if (gam) {
-                // M_qv from the log-gamma difference once, the higher orders by M_{q+1} = M_q theta (k + q)
-                double mom = nn[m] * (qv == 0.0 ? 1.0 : exp(fma(qv, lnth, lgamma(qv + kk[m]) - lgk)));
+                // M_qv from the log-gamma ratio once, the higher orders by M_{q+1} = M_q theta (k + q)
+                double mom = nn[m] * (qv == 0.0 ? 1.0 : exp(fma(qv, lnth, log_gamma_ratio(kk[m], qv))));
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     s[j] = fma(-S.vel[v][0], mom, s[j]);
@@ -1146,10 +1151,61 @@ __global__ void __launch_bounds__(kBlock)
                              size_t n_columns, size_t ld, const TIO *u_in, TIO *u_out, double dt, double dz,
                              int n_steps) {
     __shared__ double sh_flux[N * 3][kBlock];
+    constexpr bool kStash = (MODE != MODE_ALLINF) && (N <= 2);  // larger N: the LDS footprint would cost more occupancy than it buys
+    __shared__ double sh_keep[kStash ? 3 * N * 3 : 1][kBlock];
     const KArgs<N, P> &A = *Ag;
     const int t = threadIdx.x;
     const int cpb = kBlock / nz;  // whole columns per workgroup
-    const int cl = t / nz, iz = t - cl * nz;
+    int pos = t;                  // cell slot of the workgroup this lane integrates: column pos / nz, level pos % nz
+    if (MODE != MODE_ALLINF) {
+        // regime sort of the workgroup's cells on the initial state (see coal_rhs_sorted_kernel): lanes of a wave get
+        // cells of similar x_t / theta, so their Simpson passes take the same branches; the flux exchange below is
+        // indexed by cell slot, not by lane, so any permutation works.
+        __shared__ __attribute__((aligned(16))) unsigned int sh_key[kBlock];
+        __shared__ unsigned short sh_perm[kBlock];
+        unsigned int key = 0xFFFFFFFFu;
+        {
+            const int c0 = t / nz;
+            const size_t col0 = (size_t)blockIdx.x * cpb + c0;
+            if (c0 < cpb && col0 < n_columns) {
+                double nn[N], th[N], kk[N];
+                load_parcel<N, P, TIO>(A, col0 * (size_t)nz + (t - c0 * nz), ld, u_in, nn, th, kk);
+                int f = 0;
+#pragma unroll
+                for (int m = N - 2; m >= 0; --m)
+                    if (A.finite[m]) f = m;
+                double nf = nn[0], thf = th[0], kf = kk[0], xtf = A.thr[0];
+#pragma unroll
+                for (int m = 1; m < N; ++m)
+                    if (m == f) {
+                        nf = nn[m];
+                        thf = th[m];
+                        kf = kk[m];
+                        xtf = A.thr[m];
+                    }
+                const float r = (float)((xtf / thf) / (kf + double(P + 2)));
+                key = 0xFFFFFF00u;  // empty cells after the occupied ones, before the idle slots
+                if (nf > 0.0 && r == r) key = __float_as_uint(fmaxf(r, 0.0f));  // <= 0x7F800000
+            }
+        }
+        key = (key & 0xFFFFFF00u) | (unsigned int)t;
+        sh_key[t] = key;
+        __syncthreads();
+        int rank = 0;
+        const uint4 *sh_key4 = reinterpret_cast<const uint4 *>(sh_key);
+#pragma unroll 8
+        for (int s2 = 0; s2 < kBlock / 4; ++s2) {
+            const uint4 k4 = sh_key4[s2];
+            rank += (k4.x < key) + (k4.y < key) + (k4.z < key) + (k4.w < key);
+        }
+        sh_perm[rank] = (unsigned short)t;
+        __syncthreads();
+        // The per-stage barrier makes a workgroup as slow as its most expensive wave.  Odd workgroups hand the sorted
+        // cells to their waves in reverse order, so that a SIMD holding waves of two workgroups does not get the two
+        // expensive ends.
+        pos = sh_perm[(blockIdx.x & 1) ? (kBlock - 1 - t) : t];
+    }
+    const int cl = pos / nz, iz = pos - cl * nz;
     const size_t col = (size_t)blockIdx.x * cpb + cl;
     const bool active = (cl < cpb) && (col < n_columns);
     const size_t i = col * (size_t)nz + iz;
@@ -1163,14 +1219,18 @@ __global__ void __launch_bounds__(kBlock)
     for (int step = 0; step < n_steps; ++step) {
 #pragma unroll 1
         for (int stage = 0; stage < 3; ++stage) {
-            size_t opaque_zero = 0;  // see ssprk33_kernel: keeps the tensor s_loads inside the stage
+            // The plan constants are re-derived through opaque zero offsets (see ssprk33_kernel), twice per stage: the
+            // closure inversion and the sedimentation flux see the norms and the velocity block, and only after the
+            // flux exchange are the tensors loaded for the coalescence integrals -- otherwise all of them are live in
+            // SGPRs at once and spill into VGPR lanes.
+            size_t opaque_zero = 0;
             asm volatile("" : "+s"(opaque_zero));
             const KArgs<N, P> &As = *(Ag + opaque_zero);
             const SediArgs &S = *reinterpret_cast<const SediArgs *>(Ag + opaque_zero + 1);
-            double f[N][3], fl[N][3];
+            double f[N][3], nn[N], th[N], kk[N];
+            bool all_small = true;
             if (active) {
-                double nn[N], th[N], kk[N], acc[N][3];
-                bool all_small = true;
+                double fl[N][3];
 #pragma unroll
                 for (int m = 0; m < N; ++m) {
 #pragma unroll
@@ -1181,36 +1241,68 @@ __global__ void __launch_bounds__(kBlock)
                     all_small = all_small && (m0 < kEps) && (m1 < kEps) && (As.np[m] != 3 || m2 < kEps);
                     invert_closure(As.dist_type[m], m0, m1, m2, As.kmin, As.kmax, nn[m], th[m], kk[m]);
                 }
-                coal_ints_parcel<N, P, MODE>(As, nodes, nn, th, kk, acc);
                 sedi_flux_parcel<N>(As.dist_type, S, nn, th, kk, fl);
 #pragma unroll
                 for (int m = 0; m < N; ++m)
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
-                        const bool live = q < As.np[m];
-                        f[m][q] = (live && !all_small) ? acc[m][q] * As.out_scale[3 * m + q] : 0.0;  // :67-72
-                        fl[m][q] = live ? fl[m][q] * As.out_scale[3 * m + q] : 0.0;
-                        sh_flux[3 * m + q][t] = fl[m][q];
+                        f[m][q] = (q < As.np[m]) ? fl[m][q] * As.out_scale[3 * m + q] : 0.0;
+                        sh_flux[3 * m + q][pos] = f[m][q];
                     }
             }
-            __syncthreads();
+            CLOUDY_STAGE_BARRIER();
             if (active) {
                 const bool top = (iz == nz - 1);  // zero flux above the top cell (:80-81)
 #pragma unroll
                 for (int m = 0; m < N; ++m)
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
-                        const double f_up = top ? 0.0 : sh_flux[3 * m + q][t + 1];
-                        f[m][q] += -(f_up - fl[m][q]) / dz;  // :83-85
+                        const double f_up = top ? 0.0 : sh_flux[3 * m + q][pos + 1];
+                        f[m][q] = -(f_up - f[m][q]) / dz;  // :83-85
                     }
-                if (stage == 0) {
+                // With a finite threshold the Simpson pass needs the registers: the stage input, the step input and the
+                // flux divergence wait in the lane's own LDS slots meanwhile (36 fewer VGPRs at N = 2).
+                if (kStash) {
 #pragma unroll
                     for (int m = 0; m < N; ++m)
 #pragma unroll
                         for (int q = 0; q < 3; ++q) {
-                            up[m][q] = u[m][q];
-                            u[m][q] = up[m][q] + dt * f[m][q];
+                            sh_keep[0 * N * 3 + 3 * m + q][t] = u[m][q];
+                            if (stage == 0) sh_keep[1 * N * 3 + 3 * m + q][t] = u[m][q];  // uprev (clamped)
+                            sh_keep[2 * N * 3 + 3 * m + q][t] = f[m][q];
                         }
+                }
+                size_t opaque_zero2 = 0;
+                asm volatile("" : "+s"(opaque_zero2));
+                const KArgs<N, P> &Ac = *(Ag + opaque_zero2);
+                double acc[N][3];
+                coal_ints_parcel<N, P, MODE>(Ac, nodes, nn, th, kk, acc);
+                if (kStash) {
+                    asm volatile("" ::: "memory");  // reload, do not forward the stored registers
+#pragma unroll
+                    for (int m = 0; m < N; ++m)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            u[m][q] = sh_keep[0 * N * 3 + 3 * m + q][t];
+                            up[m][q] = sh_keep[1 * N * 3 + 3 * m + q][t];
+                            f[m][q] = sh_keep[2 * N * 3 + 3 * m + q][t];
+                        }
+                } else if (stage == 0) {
+#pragma unroll
+                    for (int m = 0; m < N; ++m)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) up[m][q] = u[m][q];
+                }
+#pragma unroll
+                for (int m = 0; m < N; ++m)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)  // coal_source .+ sedi_source (:88), empty cells skip coalescence (:67-72)
+                        f[m][q] = ((q < Ac.np[m] && !all_small) ? acc[m][q] * Ac.out_scale[3 * m + q] : 0.0) + f[m][q];
+                if (stage == 0) {
+#pragma unroll
+                    for (int m = 0; m < N; ++m)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) u[m][q] = up[m][q] + dt * f[m][q];
                 } else if (stage == 1) {
 #pragma unroll
                     for (int m = 0; m < N; ++m)
@@ -1224,7 +1316,7 @@ __global__ void __launch_bounds__(kBlock)
                             u[m][q] = div_by_const(up[m][q] + 2.0 * u[m][q] + 2.0 * dt * f[m][q], 3.0, 1.0 / 3.0);
                 }
             }
-            __syncthreads();
+            CLOUDY_STAGE_BARRIER();
         }
     }
     if (active) {
@@ -1257,14 +1349,13 @@ __global__ void __launch_bounds__(kBlock)
             const int dtp = A.dist_type[m];
             const bool gam = (dtp == DIST_GAMMA || dtp == DIST_EXP);
             const double lnth = (dtp == DIST_LOGNORMAL) ? th[m] : log(th[m]);
-            const double lgk = gam ? lgamma(kk[m]) : 0.0;
             out[(size_t)off * ld + i] = (TIO)0.0;
-            // M_{1/3} from the log-gamma difference, M_{4/3} = M_{1/3} theta (k + 1/3) for the Gamma family
+            // M_{1/3} from the log-gamma ratio, M_{4/3} = M_{1/3} theta (k + 1/3) for the Gamma family
             double mom = 0.0;
             for (int j = 1; j < A.np[m]; ++j) {
                 const double q = double(j) - 2.0 / 3.0;
                 if (gam)
-                    mom = (j == 1) ? nn[m] * exp(fma(q, lnth, lgamma(q + kk[m]) - lgk))
+                    mom = (j == 1) ? nn[m] * exp(fma(q, lnth, log_gamma_ratio(kk[m], q)))
                                    : mom * (th[m] * (kk[m] + (q - 1.0)));
                 else
                     mom = nn[m] * exp((dtp == DIST_MONO) ? q * lnth : fma(q, lnth, 0.5 * q * q * (kk[m] * kk[m])));

@@ -98,37 +98,6 @@ hipError_t launch_io(const HostPlan &h, const LaunchReq &r, const KArgs<N, P> &A
         hipLaunchKernelGGL((cond_evap_kernel<N, P, TIO>), dim3(grid_for(r.n, false)), dim3(kBlock), 0, r.stream, A,
                            r.coef, r.s_scalar, r.s_dev, r.n, r.ld, in, out);
         break;
-    case OP_SSPRK33: {
-        const unsigned g = grid_for(r.n, heavy);
-        if (!h.kargs_dev) return hipErrorNotInitialized;  // uploaded by OP_PREPARE at plan creation
-        const KArgs<N, P> *Ad = static_cast<const KArgs<N, P> *>(h.kargs_dev);
-        if (h.mode == MODE_ALLINF)
-            hipLaunchKernelGGL((ssprk33_kernel<N, P, MODE_ALLINF, TIO>), dim3(g), dim3(kBlock), 0, r.stream, Ad,
-                               h.nodes_dev, r.n, r.ld, in, out, r.dt, r.n_steps);
-        else if (h.mode == MODE_FIXED)
-            hipLaunchKernelGGL((ssprk33_kernel<N, P, MODE_FIXED, TIO>), dim3(g), dim3(kBlock), 0, r.stream, Ad,
-                               h.nodes_dev, r.n, r.ld, in, out, r.dt, r.n_steps);
-        else
-            hipLaunchKernelGGL((ssprk33_kernel<N, P, MODE_MOVING, TIO>), dim3(g), dim3(kBlock), 0, r.stream, Ad,
-                               h.nodes_dev, r.n, r.ld, in, out, r.dt, r.n_steps);
-        break;
-    }
-    case OP_RAINSHAFT_SSPRK33: {
-        if (!h.kargs_dev) return hipErrorNotInitialized;
-        if (r.nz < 1 || r.nz > (size_t)kBlock) return hipErrorInvalidValue;
-        const KArgs<N, P> *Ad = static_cast<const KArgs<N, P> *>(h.kargs_dev);
-        const size_t cpb = kBlock / r.nz, n_columns = r.n / r.nz;
-        const unsigned g = (unsigned)((n_columns + cpb - 1) / cpb);
-        if (h.mode == MODE_ALLINF)
-            hipLaunchKernelGGL((rainshaft_ssprk33_kernel<N, P, MODE_ALLINF, TIO>), dim3(g), dim3(kBlock), 0, r.stream,
-                               Ad, h.nodes_dev, (int)r.nz, n_columns, r.ld, in, out, r.dt, r.dz, r.n_steps);
-        else if (h.mode == MODE_FIXED)
-            hipLaunchKernelGGL((rainshaft_ssprk33_kernel<N, P, MODE_FIXED, TIO>), dim3(g), dim3(kBlock), 0, r.stream,
-                               Ad, h.nodes_dev, (int)r.nz, n_columns, r.ld, in, out, r.dt, r.dz, r.n_steps);
-        else
-            return hipErrorInvalidValue;  // make_rainshaft_rhs is FixedThreshold only (rainshaft_helpers.jl:70)
-        break;
-    }
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -159,12 +128,13 @@ hipError_t launch_np(const HostPlan &h, const LaunchReq &r) {
         *static_cast<void **>(r.out) = dev;
         return hipSuccess;
     }
+    case OP_SSPRK33:
+    case OP_RAINSHAFT_SSPRK33:
+        return launch_int<N, P>(h, r);  // int_n<N>_p<P>.hip
     case OP_COAL:
     case OP_SEDI:
     case OP_COND:
     case OP_NQ:
-    case OP_SSPRK33:
-    case OP_RAINSHAFT_SSPRK33:
         // get_coal_ints on (n, theta, k) planes is an fp64 interface for every plan
         if (h.dtype != CLOUDY_F64 && r.input_kind == IN_MOMENTS) return launch_io<N, P, float>(h, r, A);
         return launch_io<N, P, double>(h, r, A);
