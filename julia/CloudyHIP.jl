@@ -101,6 +101,20 @@ function solve_ssprk33!(u, plan, dt, n_steps; stream = C_NULL)
     return u
 end
 
+"""
+    solve_rainshaft_ssprk33!(u, plan, nz, dz, dt, n_steps; stream = C_NULL)
+
+`solve(ODEProblem(make_rainshaft_rhs(AnalyticalCoalStyle()), m, tspan, p), SSPRK33(), dt = p.dt)` of
+test/examples/Analytical/rainshaft_gamma_mixture.jl:59-60 for `size(u, 1) ÷ nz` independent columns of `nz <= 256`
+cells stacked along the first axis (the reference's `m[nz, nmom]` layout for one column), final state only.
+"""
+function solve_rainshaft_ssprk33!(u, plan, nz, dz, dt, n_steps; stream = C_NULL)
+    check(ccall((:cloudy_rainshaft_ssprk33_steps, lib), Cint,
+                (Ptr{Cvoid}, Csize_t, Csize_t, Csize_t, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cdouble, Cint, Ptr{Cvoid}),
+                plan, nz, size(u, 1) ÷ nz, stride(u, 2), pointer(u), pointer(u), dz, dt, n_steps, stream))
+    return u
+end
+
 # host-array convenience (copies over PCIe each call; for validation, not for production stepping)
 function rhs_host!(dm::Matrix{Float64}, m::Matrix{Float64}, plan)
     check(ccall((:cloudy_coal_rhs_host, lib), Cint, (Ptr{Cvoid}, Csize_t, Csize_t, Ptr{Float64}, Ptr{Float64}),
