@@ -15,7 +15,7 @@ class Plan:
     """Owner of a cloudy_plan handle (include/cloudy_hip.h): one immutable constant block per configuration."""
 
     def __init__(self, dist_types, kernel_c, dist_thresholds, norms, threshold_style, k_range=(EPS, 10.0),
-                 n_bins_per_log_unit=15, vel=(), kernel_is_normalized=False, device=-1, dtype=0):
+                 n_bins_per_log_unit=15, vel=(), kernel_is_normalized=False, device=-1, dtype=0, specialize=0):
         L = _lib.lib()
         d = _lib.PlanDesc()
         L.cloudy_plan_desc_init(C.byref(d))
@@ -46,12 +46,18 @@ class Plan:
         d.device = int(device)
         d.dtype = int(dtype)  # CLOUDY_F64 = 0; CLOUDY_F32 = 1: float planes in HBM, fp64 arithmetic in registers
         self.dtype = int(dtype)
+        # plan-time compiled kernels for all-Inf thresholds: 0 = when available, 1 = required, -1 = off
+        d.specialize = int(specialize)
         h = C.c_void_p()
         _lib.check(L.cloudy_plan_create(C.byref(d), C.byref(h)))
         self.handle = h
         self.N = N
         self.P = int(d.tensor_p)
         self.nmom = L.cloudy_plan_nmom(h)
+        self.specialized = bool(L.cloudy_plan_specialized(h))
+
+    def jit_log(self):
+        return _lib.lib().cloudy_plan_jit_log(self.handle).decode("utf-8", "replace")
 
     def get(self):
         """(N_mom_max, N_2d_ints, thresholds, normalised kernels [N,N,P,P], mom_norms) as the library holds them."""
@@ -119,16 +125,18 @@ class CoalescenceData:
             self.dist_thresholds = self.dist_thresholds_in
         self._plans = {}
 
-    def plan(self, dist_types, k_range=(EPS, 10.0), vel=(), dtype=0):
-        """The device plan for this data and the closure types of `pdists` (built once, cached)."""
+    def plan(self, dist_types, k_range=(EPS, 10.0), vel=(), dtype=0, specialize=0):
+        """The device plan for this data and the closure types of `pdists` (built once, cached).  `specialize`:
+        plan-time compiled kernels for all-Inf thresholds (0 = when available, 1 = required, -1 = off)."""
         dist_types = tuple(int(t) for t in dist_types)
         for t, npm in zip(dist_types, self.NProgMoms):
             if {0: 2, 1: 3, 2: 2, 3: 3}.get(t) != npm:
                 raise ValueError("NProgMoms does not match nparams of the distributions")
-        key = (dist_types, tuple(k_range), tuple(map(tuple, np.asarray(vel, dtype=float).reshape(-1, 2))), int(dtype))
+        key = (dist_types, tuple(k_range), tuple(map(tuple, np.asarray(vel, dtype=float).reshape(-1, 2))), int(dtype),
+               int(specialize))
         if key not in self._plans:
             self._plans[key] = Plan(dist_types, self.kernel_c, self.dist_thresholds_in, self.norms, self.ts,
-                                    k_range=k_range, vel=vel, dtype=dtype)
+                                    k_range=k_range, vel=vel, dtype=dtype, specialize=specialize)
         return self._plans[key]
 
 

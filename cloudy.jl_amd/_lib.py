@@ -39,6 +39,7 @@ class PlanDesc(C.Structure):
         ("n_vel", C.c_int32),
         ("vel", C.c_double * (MAX_VEL * 2)),
         ("device", C.c_int32),
+        ("specialize", C.c_int32),
     ]
 
 
@@ -48,6 +49,8 @@ SYMBOLS = {
     "cloudy_plan_desc_init": (None, [C.POINTER(PlanDesc)]),
     "cloudy_plan_create": (_i, [C.POINTER(PlanDesc), C.POINTER(_vp)]),
     "cloudy_plan_destroy": (None, [_vp]),
+    "cloudy_plan_specialized": (_i, [_vp]),
+    "cloudy_plan_jit_log": (C.c_char_p, [_vp]),
     "cloudy_plan_nmom": (_i, [_vp]),
     "cloudy_plan_nparams": (_i, [_vp]),
     "cloudy_plan_get": (_i, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _dp, _dp, _dp]),

@@ -12,7 +12,10 @@
 #include <new>
 #include <vector>
 
+#include <string>
+
 #include "host_plan.hpp"
+#include "jit.hpp"
 #include "kernels.hpp"
 #include "reduce_kernels.hpp"
 
@@ -20,6 +23,9 @@ using namespace cloudy;
 
 struct cloudy_plan {
     HostPlan h;
+    bool jit_on = false;   // plan-time specialised kernels (jit.hpp) serve cloudy_coal_rhs / cloudy_ssprk33_steps
+    JitKernels jit;
+    std::string jit_log;   // why not, when jit_on is false
 };
 
 namespace {
@@ -65,8 +71,40 @@ int check_batch(const cloudy_plan *plan, size_t n, size_t ld, const void *a, con
     return CLOUDY_OK;
 }
 
+// cloudy_coal_rhs / cloudy_ssprk33_steps of a specialised plan: same grids and the same two-parcels-per-lane
+// alignment rule as launch_io() in launch_impl.hpp.
+hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
+    const HostPlan &h = plan->h;
+    size_t n = r.n, ld = r.ld;
+    const void *in = r.in;
+    void *out = r.out;
+    const unsigned g1 = (unsigned)((n + kBlock - 1) / kBlock);
+    if (r.op == OP_SSPRK33) {
+        double dt = r.dt;
+        int n_steps = r.n_steps;
+        void *args[] = {&n, &ld, &in, &out, &dt, &n_steps};
+        return hipModuleLaunchKernel(plan->jit.ssprk33, g1, 1, 1, kBlock, 1, 1, 0, r.stream, args, nullptr);
+    }
+    const size_t esz = h.dtype != CLOUDY_F64 ? sizeof(float) : sizeof(double);
+    const uintptr_t amask = 2 * esz - 1;
+    const bool aligned2 =
+        ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & amask) == 0 && (ld % 2 == 0);
+    void *args[] = {&n, &ld, &in, &out};
+    if (aligned2 && !h.force_ppl1) {
+        const unsigned g2 = (unsigned)(((n + 1) / 2 + kBlock - 1) / kBlock);
+        return hipModuleLaunchKernel(plan->jit.allinf2, g2, 1, 1, kBlock, 1, 1, 0, r.stream, args, nullptr);
+    }
+    return hipModuleLaunchKernel(plan->jit.ppl1, g1, 1, 1, kBlock, 1, 1, 0, r.stream, args, nullptr);
+}
+
 int run(const cloudy_plan *plan, const LaunchReq &r) {
     if (r.n == 0) return CLOUDY_OK;
+    if (plan->jit_on && r.input_kind == IN_MOMENTS && r.physical_out && !r.rainshaft &&
+        (r.op == OP_COAL || r.op == OP_SSPRK33)) {
+        hipError_t e = launch_jit(plan, r);
+        if (e != hipSuccess) return fail_hip(e, "specialised kernel launch");
+        return CLOUDY_OK;
+    }
     hipError_t e = dispatch(plan->h, r);
     if (e != hipSuccess) return fail_hip(e, "kernel launch");
     return CLOUDY_OK;
@@ -298,9 +336,35 @@ int cloudy_plan_create(const cloudy_plan_desc *d, cloudy_plan **out) {
             return fail_hip(e, "constant block upload");
         }
     }
+    // plan-time specialisation of the all-Inf kernels (jit.hpp): 0 = when available, 1 = required, -1 = off
+    const char *env = std::getenv("CLOUDY_HIP_JIT");
+    const bool env_off = env && env[0] == '0';
+    if (h.mode == MODE_ALLINF && d->specialize >= 0 && !(env_off && d->specialize == 0)) {
+        p->jit_on = jit_get(h, p->jit, p->jit_log);
+        if (!p->jit_on && d->specialize > 0) {
+            int rc = fail(CLOUDY_EUNSUPPORTED, "plan-time specialisation failed: %.400s", p->jit_log.c_str());
+            cloudy_plan_destroy(p);
+            return rc;
+        }
+    } else {
+        p->jit_log = h.mode != MODE_ALLINF ? "only plans whose thresholds are all Inf are specialised"
+                                           : "switched off (desc.specialize < 0 or CLOUDY_HIP_JIT=0)";
+        if (d->specialize > 0) {
+            int rc = fail(CLOUDY_EUNSUPPORTED, "plan-time specialisation required but %s", p->jit_log.c_str());
+            cloudy_plan_destroy(p);
+            return rc;
+        }
+    }
     *out = p;
     return CLOUDY_OK;
 }
+
+int cloudy_plan_specialized(const cloudy_plan *plan) {
+    if (!plan) return fail(CLOUDY_EINVAL, "plan is NULL");
+    return plan->jit_on ? 1 : 0;
+}
+
+const char *cloudy_plan_jit_log(const cloudy_plan *plan) { return plan ? plan->jit_log.c_str() : "plan is NULL"; }
 
 void cloudy_plan_destroy(cloudy_plan *plan) {
     if (!plan) return;

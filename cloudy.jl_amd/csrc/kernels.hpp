@@ -524,8 +524,16 @@ __device__ __forceinline__ void contract_promoted(const double (&ckk)[P][P], con
     T0 *= 0.5;
 }
 
+// Plan-time specialisation (jit.hpp): when the plan constants are compile-time values (SPEC), terms whose tensor
+// coefficient is exactly zero are dropped -- fma(0, M, v) == v for finite M, so results are bit-identical -- and the
+// remaining coefficients become literals.  In the ahead-of-time kernels (SPEC = false) the test is constant-true.
+template <bool SPEC>
+__device__ __forceinline__ constexpr bool nzc(double c) {
+    return SPEC ? c != 0.0 : true;
+}
+
 // get_coal_ints for one parcel: acc[k][m], normalised units.
-template <int N, int P, int MODE, bool FAST = false>
+template <int N, int P, int MODE, bool FAST = false, bool SPEC = false>
 __device__ __forceinline__ void coal_ints_parcel(const KArgs<N, P> &A, const double *__restrict__ nodes,
                                                  const double (&nn)[N], const double (&th)[N], const double (&kk)[N],
                                                  double (&acc)[N][3]) {
@@ -611,10 +619,11 @@ __device__ __forceinline__ void coal_ints_parcel(const KArgs<N, P> &A, const dou
                 for (int b = 0; b < P; ++b) {
                     double v1 = 0.0, v2 = 0.0;
 #pragma unroll
-                    for (int a = 0; a < P; ++a) {
-                        v1 = fma(A.c[j][k][a][b], Mm[j][a + 1], v1);
-                        v2 = fma(A.c[j][k][a][b], Mm[j][a + 2], v2);
-                    }
+                    for (int a = 0; a < P; ++a)
+                        if (nzc<SPEC>(A.c[j][k][a][b])) {
+                            v1 = fma(A.c[j][k][a][b], Mm[j][a + 1], v1);
+                            v2 = fma(A.c[j][k][a][b], Mm[j][a + 2], v2);
+                        }
                     s1 = fma(v1, Mm[k][b], s1);
                     s2a = fma(v1, Mm[k][b + 1], s2a);
                     s2b = fma(v2, Mm[k][b], s2b);
@@ -627,7 +636,8 @@ __device__ __forceinline__ void coal_ints_parcel(const KArgs<N, P> &A, const dou
                 for (int b = 0; b < P; ++b) {
                     double v = 0.0;
 #pragma unroll
-                    for (int a = 0; a < P; ++a) v = fma(A.c[j][k][a][b], Mm[j][a], v);
+                    for (int a = 0; a < P; ++a)
+                        if (nzc<SPEC>(A.c[j][k][a][b])) v = fma(A.c[j][k][a][b], Mm[j][a], v);
                     r0 = fma(v, Mm[k][b], r0);
                     r1 = fma(v, Mm[k][b + 1], r1);
                     r2 = fma(v, Mm[k][b + 2], r2);
@@ -641,10 +651,11 @@ __device__ __forceinline__ void coal_ints_parcel(const KArgs<N, P> &A, const dou
                 for (int b = 0; b < P; ++b) {
                     double v = 0.0, v1 = 0.0;
 #pragma unroll
-                    for (int a = 0; a < P; ++a) {
-                        v = fma(A.c[k][k][a][b], Mm[k][a], v);
-                        v1 = fma(A.c[k][k][a][b], Mm[k][a + 1], v1);
-                    }
+                    for (int a = 0; a < P; ++a)
+                        if (nzc<SPEC>(A.c[k][k][a][b])) {
+                            v = fma(A.c[k][k][a][b], Mm[k][a], v);
+                            v1 = fma(A.c[k][k][a][b], Mm[k][a + 1], v1);
+                        }
                     r0 = fma(v, Mm[k][b], r0);
                     s2 = fma(v1, Mm[k][b + 1], s2);
                 }
@@ -696,17 +707,16 @@ __device__ __forceinline__ bool load_parcel(const KArgs<N, P> &A, size_t i, size
     return all_small;
 }
 
-template <int N, int P, int MODE, typename TIO>
-__global__ void __launch_bounds__(kBlock)
-    coal_rhs_kernel(const KArgs<N, P> A, const double *__restrict__ nodes, size_t n, size_t ld,
-                    const TIO *__restrict__ in, TIO *__restrict__ out) {
+template <int N, int P, int MODE, typename TIO, bool SPEC = false>
+__device__ __forceinline__ void coal_rhs_body(const KArgs<N, P> &A, const double *__restrict__ nodes, size_t n, size_t ld,
+                                              const TIO *__restrict__ in, TIO *__restrict__ out) {
     // one parcel per lane, no grid-stride loop: a parcel loop would let LICM hoist every libm polynomial
     // constant of the body into registers for the whole kernel (measured: 256 VGPRs + spills vs ~100).
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) {
         double nn[N], th[N], kk[N], acc[N][3];
         const bool all_small = load_parcel<N, P, TIO>(A, i, ld, in, nn, th, kk);
-        coal_ints_parcel<N, P, MODE>(A, nodes, nn, th, kk, acc);
+        coal_ints_parcel<N, P, MODE, false, SPEC>(A, nodes, nn, th, kk, acc);
         const bool skip = A.rainshaft && all_small;  // rainshaft_helpers.jl:67-68
 #pragma unroll
         for (int k = 0; k < N; ++k) {
@@ -718,14 +728,20 @@ __global__ void __launch_bounds__(kBlock)
     }
 }
 
+template <int N, int P, int MODE, typename TIO>
+__global__ void __launch_bounds__(kBlock)
+    coal_rhs_kernel(const KArgs<N, P> A, const double *__restrict__ nodes, size_t n, size_t ld,
+                    const TIO *__restrict__ in, TIO *__restrict__ out) {
+    coal_rhs_body<N, P, MODE, TIO>(A, nodes, n, ld, in, out);
+}
+
 // ALLINF with two parcels per lane: every plane is read and written as one 16-byte access per lane (1 KiB per
 // wave instruction).  Requires 16-byte aligned planes: base pointers 16-B aligned and ld even (checked by the
 // host, which otherwise launches the one-parcel kernel).  The two parcels are independent instruction streams,
 // which also gives the scheduler ILP across the division sequences of the closure inversion.
-template <int N, int P, typename TIO>
-__global__ void __launch_bounds__(kBlock)
-    coal_rhs_allinf2_kernel(const KArgs<N, P> A, size_t n, size_t ld, const TIO *__restrict__ in,
-                            TIO *__restrict__ out) {
+template <int N, int P, typename TIO, bool SPEC = false>
+__device__ __forceinline__ void coal_rhs_allinf2_body(const KArgs<N, P> &A, size_t n, size_t ld,
+                                                      const TIO *__restrict__ in, TIO *__restrict__ out) {
     const size_t i = ((size_t)blockIdx.x * kBlock + threadIdx.x) * 2;
     if (i >= n) return;
     const bool pair = (i + 1 < n);
@@ -754,7 +770,8 @@ __global__ void __launch_bounds__(kBlock)
         }
     }
 #pragma unroll
-    for (int e = 0; e < 2; ++e) coal_ints_parcel<N, P, MODE_ALLINF>(A, nullptr, nn[e], th[e], kk[e], acc[e]);
+    for (int e = 0; e < 2; ++e)
+        coal_ints_parcel<N, P, MODE_ALLINF, false, SPEC>(A, nullptr, nn[e], th[e], kk[e], acc[e]);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         const int off = A.off[k];
@@ -769,6 +786,13 @@ __global__ void __launch_bounds__(kBlock)
                 *dst = (TIO)(acc[0][k][m] * s);
         }
     }
+}
+
+template <int N, int P, typename TIO>
+__global__ void __launch_bounds__(kBlock)
+    coal_rhs_allinf2_kernel(const KArgs<N, P> A, size_t n, size_t ld, const TIO *__restrict__ in,
+                            TIO *__restrict__ out) {
+    coal_rhs_allinf2_body<N, P, TIO>(A, n, ld, in, out);
 }
 
 // Threshold modes (FIXED / MOVING): the cost of a parcel is dominated by the incomplete-gamma evaluations of its
@@ -869,7 +893,7 @@ __global__ void __launch_bounds__(kBlock)
 // 3 RHS evaluations per step, each a full pass over the state in OrdinaryDiffEq).  Here a lane keeps its parcel's
 // moments in registers across all stages and steps: HBM traffic is one read and one write of the state per CALL
 // (n_steps steps), and there are no per-stage launches.
-template <int N, int P, int MODE>
+template <int N, int P, int MODE, bool SPEC = false>
 __device__ __forceinline__ void rhs_physical(const KArgs<N, P> &A, const double *__restrict__ nodes,
                                              const double (&u)[N][3], double (&f)[N][3]) {
     double nn[N], th[N], kk[N], acc[N][3];
@@ -880,7 +904,7 @@ __device__ __forceinline__ void rhs_physical(const KArgs<N, P> &A, const double 
         const double m2 = div_by_const(u[m][2], A.norm[3 * m + 2], A.inv_norm[3 * m + 2]);
         invert_closure(A.dist_type[m], m0, m1, m2, A.kmin, A.kmax, nn[m], th[m], kk[m]);
     }
-    coal_ints_parcel<N, P, MODE>(A, nodes, nn, th, kk, acc);
+    coal_ints_parcel<N, P, MODE, false, SPEC>(A, nodes, nn, th, kk, acc);
 #pragma unroll
     for (int m = 0; m < N; ++m) {
         f[m][0] = acc[m][0] * A.out_scale[3 * m + 0];
@@ -889,10 +913,9 @@ __device__ __forceinline__ void rhs_physical(const KArgs<N, P> &A, const double 
     }
 }
 
-template <int N, int P, int MODE, typename TIO>
-__global__ void __launch_bounds__(kBlock)
-    ssprk33_kernel(const KArgs<N, P> *__restrict__ Ag, const double *__restrict__ nodes, size_t n, size_t ld,
-                   const TIO *u_in, TIO *u_out, double dt, int n_steps) {
+template <int N, int P, int MODE, typename TIO, bool SPEC = false>
+__device__ __forceinline__ void ssprk33_body(const KArgs<N, P> *__restrict__ Ag, const double *__restrict__ nodes, size_t n,
+                                             size_t ld, const TIO *u_in, TIO *u_out, double dt, int n_steps) {
     // The plan constants come through a device pointer that is re-derived once per stage through an opaque zero offset: with by-value kernel arguments LICM hoists every scalar load of the tensors out of the step/stage
     // loops and then spills ~170 SGPRs into VGPR lanes (348 v_readlane per pass measured); re-deriving the pointer
     // keeps those s_loads inside the stage, where they hit the scalar cache.
@@ -957,9 +980,9 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll 1
         for (int stage = 0; stage < 3; ++stage) {
             size_t opaque_zero = 0;  // launder an OFFSET, not the pointer: the pointer keeps its global address space
-            asm volatile("" : "+s"(opaque_zero));
+            if (!SPEC) asm volatile("" : "+s"(opaque_zero));  // (compile-time plan constants need no loads at all)
             const KArgs<N, P> *Ap = Ag + opaque_zero;
-            rhs_physical<N, P, MODE>(*Ap, nodes, u, f);
+            rhs_physical<N, P, MODE, SPEC>(*Ap, nodes, u, f);
             // OrdinaryDiffEq SSPRK33: u = uprev + dt k;  u = (3 uprev + u + dt k)/4;  u = (uprev + 2u + 2dt k)/3
             // (wave-uniform branch on the stage OUTSIDE the element loops: selects per element would triple the work)
             if (stage == 0) {
@@ -989,6 +1012,13 @@ __global__ void __launch_bounds__(kBlock)
         u_out[(size_t)(off + 1) * ld + i] = (TIO)u[m][1];
         if (A.np[m] == 3) u_out[(size_t)(off + 2) * ld + i] = (TIO)u[m][2];
     }
+}
+
+template <int N, int P, int MODE, typename TIO>
+__global__ void __launch_bounds__(kBlock)
+    ssprk33_kernel(const KArgs<N, P> *__restrict__ Ag, const double *__restrict__ nodes, size_t n, size_t ld,
+                   const TIO *u_in, TIO *u_out, double dt, int n_steps) {
+    ssprk33_body<N, P, MODE, TIO>(Ag, nodes, n, ld, u_in, u_out, dt, n_steps);
 }
 
 // ---- diagnostics / the callers either side of the operator ---------------------------------------

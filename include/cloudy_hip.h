@@ -110,6 +110,10 @@ typedef struct cloudy_plan_desc {
     int32_t n_vel;                           /* 0 = no sedimentation term */
     double vel[CLOUDY_MAX_VEL][2];           /* p.vel: terminal velocity sum_k vel[k][0] * x^vel[k][1], physical units */
     int32_t device;                          /* HIP device ordinal, -1 = current */
+    int32_t specialize;                      /* plan-time compilation (hiprtc) of the all-Inf-threshold kernels with the
+                                                plan as compile-time constants: 0 = when available (default; the
+                                                environment variable CLOUDY_HIP_JIT=0 turns it off), 1 = required
+                                                (plan creation fails otherwise), -1 = off */
 } cloudy_plan_desc;
 
 /* fills defaults: k_range = (eps, 10), n_bins_per_log_unit = 15, norms = (1, 1), thresholds = +Inf,
@@ -118,6 +122,10 @@ void cloudy_plan_desc_init(cloudy_plan_desc *desc);
 
 int cloudy_plan_create(const cloudy_plan_desc *desc, cloudy_plan **out);
 void cloudy_plan_destroy(cloudy_plan *plan);
+/* 1 if cloudy_coal_rhs / cloudy_ssprk33_steps of this plan run kernels compiled for it at plan creation, else 0 with
+ * the reason (or the compiler log) in cloudy_plan_jit_log.  Either way the results are the same bits. */
+int cloudy_plan_specialized(const cloudy_plan *plan);
+const char *cloudy_plan_jit_log(const cloudy_plan *plan);
 int cloudy_plan_nmom(const cloudy_plan *plan);      /* sum(NProgMoms) */
 int cloudy_plan_nparams(const cloudy_plan *plan);   /* 3 * N planes of (n, theta, k) */
 /* copies of the derived CoalescenceData fields (Coalescence.jl:69-84), for tests and hosts */

@@ -888,3 +888,83 @@ def test_rainshaft_column_integrator_ssprk33(gpu_cloudy, oracle, case):
     with pytest.raises(cloudy.CloudyError) as e:
         cloudy.solve_rainshaft_ssprk33(par, cloudy.DeviceArray.zeros(u0.shape[0], 520), 1)
     assert e.value.code == cloudy._lib.EUNSUPPORTED
+
+
+def _rhs_with_plan(cloudy, plan, mom, dtype=np.float64):
+    m = cloudy.DeviceArray.from_numpy(mom.astype(dtype))
+    dm = cloudy.DeviceArray.zeros(mom.shape[0], mom.shape[1], dtype)
+    cloudy._lib.check(cloudy.lib().cloudy_coal_rhs(plan.handle, mom.shape[1], mom.shape[1], m.ptr, dm.ptr, None))
+    return dm.to_numpy()
+
+
+def test_plan_time_specialised_kernels_are_bit_identical(gpu_cloudy, oracle):
+    """Plans whose thresholds are all Inf get kernels compiled for them at plan creation (hiprtc; jit.hpp) with the
+    tensors, norms and closure types as compile-time constants: zero coefficients drop out.  Same bits as the
+    ahead-of-time kernels -- for the headline workload, float planes, the one-parcel fallback and the fused SSPRK33."""
+    cloudy = gpu_cloudy
+    L = cloudy.lib()
+    n = 100_003
+    wl = bench.make_workload("cfg3a", n, seed=23)
+    cd, dts = wl["coal_data"], wl["dist_types"]
+    spec, gen = cd.plan(dts, specialize=1), cd.plan(dts, specialize=-1)
+    assert spec.specialized and not gen.specialized and "off" in gen.jit_log()
+    fin = np.all(np.isfinite(_rhs_with_plan(cloudy, gen, wl["mom"])), axis=0)
+    assert fin.mean() > 0.98
+    a, b = _rhs_with_plan(cloudy, spec, wl["mom"]), _rhs_with_plan(cloudy, gen, wl["mom"])
+    assert np.array_equal(a[:, fin], b[:, fin])
+    want, scale = oracle.rhs_coal_batch(bench.oracle_params("cfg3a"), wl["mom"], with_scale=True)
+    assert_close_scaled(a, want, scale, TOL_POLY, "specialised cfg3a")
+    # float planes
+    s32, g32 = cd.plan(dts, dtype=1, specialize=1), cd.plan(dts, dtype=1, specialize=-1)
+    a32 = _rhs_with_plan(cloudy, s32, wl["mom"], np.float32)
+    b32 = _rhs_with_plan(cloudy, g32, wl["mom"], np.float32)
+    f32 = np.all(np.isfinite(b32), axis=0)
+    assert s32.specialized and np.array_equal(a32[:, f32], b32[:, f32])
+    # odd leading dimension: the one-parcel-per-lane kernel of the specialised module
+    ld = n + 1 + (n % 2)
+    buf = np.zeros((6, ld))
+    buf[:, :n] = wl["mom"]
+    m, dm = dev(cloudy, buf), dev(cloudy, np.zeros((6, ld)))
+    assert ld % 2 == 1 and L.cloudy_coal_rhs(spec.handle, n, ld, m.ptr, dm.ptr, None) == 0
+    assert np.array_equal(dm.to_numpy()[:, :n][:, fin], b[:, fin])
+    # fused SSPRK33
+    reg = np.flatnonzero(fin)[:50_000]
+    u0 = np.ascontiguousarray(wl["mom"][:, reg])
+    outs = []
+    for plan in (spec, gen):
+        u, o = dev(cloudy, u0), cloudy.DeviceArray.zeros(6, u0.shape[1])
+        cloudy._lib.check(L.cloudy_ssprk33_steps(plan.handle, u0.shape[1], u0.shape[1], u.ptr, o.ptr, 1e-3, 3, None))
+        outs.append(o.to_numpy())
+    ok = np.all(np.isfinite(outs[1]), axis=0)
+    assert ok.mean() > 0.9 and np.array_equal(outs[0][:, ok], outs[1][:, ok])
+    # a second plan with the same constants shares the compiled module (instant); thresholds are never specialised
+    assert cloudy.Plan(dts, cd.kernel_c, cd.dist_thresholds_in, cd.norms, 0, specialize=1).specialized
+    thr = bench.make_workload("cfg3b", 16)["coal_data"].plan(dts)
+    assert not thr.specialized and "all Inf" in thr.jit_log()
+    with pytest.raises(cloudy.CloudyError):
+        bench.make_workload("cfg3b", 16)["coal_data"].plan(dts, specialize=1).close()
+
+
+@pytest.mark.parametrize("N,P", [(1, 1), (1, 2), (2, 2), (3, 3), (4, 2), (2, 5), (4, 5)])
+def test_specialised_kernels_across_families(gpu_cloudy, oracle, N, P):
+    """Random sparse symmetric tensors, mixed Exponential / Gamma modes: specialised == ahead-of-time, bit for bit,
+    and both within tolerance of the oracle."""
+    cloudy = gpu_cloudy
+    rng = np.random.default_rng(100 * N + P)
+    kc = np.zeros((N, N, P, P))
+    for j in range(N):
+        for k in range(j, N):
+            c = rng.uniform(0.1, 1.0, (P, P)) * (rng.random((P, P)) < 0.45)
+            c = np.triu(c) + np.triu(c, 1).T
+            kc[j, k] = kc[k, j] = c * 1e-3 * (1e9 ** np.add.outer(np.arange(P), np.arange(P)))
+    dist_types = [int(t) for t in rng.integers(0, 2, N)]
+    par, op, _ = make_case(cloudy, oracle, dist_types, kc, (INF,) * N, bench.NORMS)
+    n = 20_001
+    mom = mixed_moments(dist_types, n, seed=N * 10 + P)
+    spec = par.coal_data.plan(dist_types, specialize=1)
+    gen = par.coal_data.plan(dist_types, specialize=-1)
+    a, b = _rhs_with_plan(cloudy, spec, mom), _rhs_with_plan(cloudy, gen, mom)
+    fin = np.all(np.isfinite(b), axis=0)
+    assert spec.specialized and fin.mean() > 0.95 and np.array_equal(a[:, fin], b[:, fin])
+    want, scale = oracle.rhs_coal_batch(op, mom, with_scale=True)
+    assert_close_scaled(a, want, scale, TOL_POLY, f"specialised N={N} P={P}")

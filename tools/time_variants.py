@@ -20,8 +20,13 @@ for rnd in range(a.rounds):
                             "--warmup", "3", "--parcels", str(a.parcels)], env=env, capture_output=True, text=True)
         try:
             j = json.loads(p.stdout.strip().splitlines()[-1])
-            res.setdefault(lib, []).append((j["roofline"]["kernel_ms"], j["variants"]["cfg3b"]["kernel_ms"]))
+            v = j["variants"]
+            res.setdefault(lib, []).append((j["roofline"]["kernel_ms"], v["cfg3b"]["kernel_ms"], v["cfg4"]["kernel_ms"],
+                                            v["cfg3b_f32_fast"]["kernel_ms"], v["cfg2"]["kernel_ms"],
+                                            v["cfg3a_fused_ssprk33"]["ms_per_call"], v["cfg3a_f32_planes"]["kernel_ms"]))
         except Exception as e:
             print(lib, "FAILED", p.stderr[-400:])
 for lib, v in res.items():
-    print(f"{os.path.basename(lib):40s} cfg3a kernel_ms {min(x[0] for x in v):.4f}  cfg3b kernel_ms {min(x[1] for x in v):.3f}   all={v}")
+    print(f"{os.path.basename(lib):40s} cfg3a {min(x[0] for x in v):.4f}  cfg3b {min(x[1] for x in v):.3f}  cfg4 {min(x[2] for x in v):.2f}  "
+          f"cfg3b_f32_fast {min(x[3] for x in v):.3f}  cfg2 {min(x[4] for x in v):.4f}  fused_ssprk33 {min(x[5] for x in v):.3f}  "
+          f"cfg3a_f32_planes {min(x[6] for x in v):.4f} ms")
