@@ -620,7 +620,7 @@ __device__ __forceinline__ void coal_ints_parcel(const KArgs<N, P> &A, const dou
                     double v1 = 0.0, v2 = 0.0;
 #pragma unroll
                     for (int a = 0; a < P; ++a)
-                        if (nzc<SPEC>(A.c[j][k][a][b])) {
+                        if (!SPEC || A.c[j][k][a][b] != 0.0) {
                             v1 = fma(A.c[j][k][a][b], Mm[j][a + 1], v1);
                             v2 = fma(A.c[j][k][a][b], Mm[j][a + 2], v2);
                         }
@@ -637,7 +637,7 @@ __device__ __forceinline__ void coal_ints_parcel(const KArgs<N, P> &A, const dou
                     double v = 0.0;
 #pragma unroll
                     for (int a = 0; a < P; ++a)
-                        if (nzc<SPEC>(A.c[j][k][a][b])) v = fma(A.c[j][k][a][b], Mm[j][a], v);
+                        if (!SPEC || A.c[j][k][a][b] != 0.0) v = fma(A.c[j][k][a][b], Mm[j][a], v);
                     r0 = fma(v, Mm[k][b], r0);
                     r1 = fma(v, Mm[k][b + 1], r1);
                     r2 = fma(v, Mm[k][b + 2], r2);
@@ -652,7 +652,7 @@ __device__ __forceinline__ void coal_ints_parcel(const KArgs<N, P> &A, const dou
                     double v = 0.0, v1 = 0.0;
 #pragma unroll
                     for (int a = 0; a < P; ++a)
-                        if (nzc<SPEC>(A.c[k][k][a][b])) {
+                        if (!SPEC || A.c[k][k][a][b] != 0.0) {
                             v = fma(A.c[k][k][a][b], Mm[k][a], v);
                             v1 = fma(A.c[k][k][a][b], Mm[k][a + 1], v1);
                         }
@@ -707,32 +707,26 @@ __device__ __forceinline__ bool load_parcel(const KArgs<N, P> &A, size_t i, size
     return all_small;
 }
 
+// The body of the one-parcel kernel is a source fragment included twice: in the ahead-of-time kernel, where the plan
+// constants are the by-value kernel argument, and in coal_rhs_body for the plan-time compiled kernels (jit.hpp), where
+// they are a constexpr object.  (A shared inline function taking `const KArgs &` would do -- but binding a reference
+// to a by-value kernel argument makes clang copy the whole struct out of the kernarg segment at kernel entry: all of
+// it live in SGPRs at once, 185-270 spilled-SGPR reloads in the hot path, +35 % VALU instructions measured.)
 template <int N, int P, int MODE, typename TIO, bool SPEC = false>
 __device__ __forceinline__ void coal_rhs_body(const KArgs<N, P> &A, const double *__restrict__ nodes, size_t n, size_t ld,
                                               const TIO *__restrict__ in, TIO *__restrict__ out) {
-    // one parcel per lane, no grid-stride loop: a parcel loop would let LICM hoist every libm polynomial
-    // constant of the body into registers for the whole kernel (measured: 256 VGPRs + spills vs ~100).
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) {
-        double nn[N], th[N], kk[N], acc[N][3];
-        const bool all_small = load_parcel<N, P, TIO>(A, i, ld, in, nn, th, kk);
-        coal_ints_parcel<N, P, MODE, false, SPEC>(A, nodes, nn, th, kk, acc);
-        const bool skip = A.rainshaft && all_small;  // rainshaft_helpers.jl:67-68
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-            const int off = A.off[k];
-            st_stream(out + (size_t)(off + 0) * ld + i, skip ? 0.0 : acc[k][0] * A.out_scale[3 * k + 0]);
-            st_stream(out + (size_t)(off + 1) * ld + i, skip ? 0.0 : acc[k][1] * A.out_scale[3 * k + 1]);
-            if (A.np[k] == 3) st_stream(out + (size_t)(off + 2) * ld + i, skip ? 0.0 : acc[k][2] * A.out_scale[3 * k + 2]);
-        }
-    }
+#define CLOUDY_SPEC SPEC
+#include "coal_rhs_body.inc"
+#undef CLOUDY_SPEC
 }
 
 template <int N, int P, int MODE, typename TIO>
 __global__ void __launch_bounds__(kBlock)
     coal_rhs_kernel(const KArgs<N, P> A, const double *__restrict__ nodes, size_t n, size_t ld,
                     const TIO *__restrict__ in, TIO *__restrict__ out) {
-    coal_rhs_body<N, P, MODE, TIO>(A, nodes, n, ld, in, out);
+#define CLOUDY_SPEC false
+#include "coal_rhs_body.inc"
+#undef CLOUDY_SPEC
 }
 
 // ALLINF with two parcels per lane: every plane is read and written as one 16-byte access per lane (1 KiB per
@@ -742,57 +736,18 @@ __global__ void __launch_bounds__(kBlock)
 template <int N, int P, typename TIO, bool SPEC = false>
 __device__ __forceinline__ void coal_rhs_allinf2_body(const KArgs<N, P> &A, size_t n, size_t ld,
                                                       const TIO *__restrict__ in, TIO *__restrict__ out) {
-    const size_t i = ((size_t)blockIdx.x * kBlock + threadIdx.x) * 2;
-    if (i >= n) return;
-    const bool pair = (i + 1 < n);
-    double nn[2][N], th[2][N], kk[2][N], acc[2][N][3];
-#pragma unroll
-    for (int m = 0; m < N; ++m) {
-        const int off = A.off[m];
-        const bool three = A.np[m] == 3;
-        dvec2 v0, v1, v2 = {0.0, 0.0};
-        if (pair) {
-            v0 = ld_stream2(in + (size_t)(off + 0) * ld + i);
-            v1 = ld_stream2(in + (size_t)(off + 1) * ld + i);
-            if (three) v2 = ld_stream2(in + (size_t)(off + 2) * ld + i);
-        } else {
-            v0 = dvec2{(double)in[(size_t)(off + 0) * ld + i], 0.0};
-            v1 = dvec2{(double)in[(size_t)(off + 1) * ld + i], 0.0};
-            if (three) v2 = dvec2{(double)in[(size_t)(off + 2) * ld + i], 0.0};
-        }
-        const double m0[2] = {v0.x, v0.y}, m1[2] = {v1.x, v1.y}, m2[2] = {v2.x, v2.y};
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const double a0 = div_by_const(m0[e], A.norm[3 * m + 0], A.inv_norm[3 * m + 0]);
-            const double a1 = div_by_const(m1[e], A.norm[3 * m + 1], A.inv_norm[3 * m + 1]);
-            const double a2 = div_by_const(m2[e], A.norm[3 * m + 2], A.inv_norm[3 * m + 2]);
-            invert_closure(A.dist_type[m], a0, a1, a2, A.kmin, A.kmax, nn[e][m], th[e][m], kk[e][m]);
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 2; ++e)
-        coal_ints_parcel<N, P, MODE_ALLINF, false, SPEC>(A, nullptr, nn[e], th[e], kk[e], acc[e]);
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        const int off = A.off[k];
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            if (m == 2 && A.np[k] != 3) continue;
-            const double s = A.out_scale[3 * k + m];
-            TIO *dst = out + (size_t)(off + m) * ld + i;
-            if (pair)
-                st_stream2(dst, acc[0][k][m] * s, acc[1][k][m] * s);
-            else
-                *dst = (TIO)(acc[0][k][m] * s);
-        }
-    }
+#define CLOUDY_SPEC SPEC
+#include "coal_rhs_allinf2_body.inc"
+#undef CLOUDY_SPEC
 }
 
 template <int N, int P, typename TIO>
 __global__ void __launch_bounds__(kBlock)
     coal_rhs_allinf2_kernel(const KArgs<N, P> A, size_t n, size_t ld, const TIO *__restrict__ in,
                             TIO *__restrict__ out) {
-    coal_rhs_allinf2_body<N, P, TIO>(A, n, ld, in, out);
+#define CLOUDY_SPEC false
+#include "coal_rhs_allinf2_body.inc"
+#undef CLOUDY_SPEC
 }
 
 // Threshold modes (FIXED / MOVING): the cost of a parcel is dominated by the incomplete-gamma evaluations of its

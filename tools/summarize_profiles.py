@@ -24,9 +24,9 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
     for f in newest(os.path.join(src, f"{tag}_{d}", "*", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if "cloudy::" not in k:
+            if "cloudy" not in k:
                 continue
-            short = k.split("cloudy::")[1].split("(")[0]
+            short = k.split("cloudy::")[1].split("(")[0] if "cloudy::" in k else k.split("(")[0]  # cloudy_jit_* are extern "C"
             table.setdefault((short, int(r["Grid_Size"])), {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
 rows = []
 for (k, grid), cs in sorted(table.items()):
@@ -48,7 +48,9 @@ print(json.dumps(traffic, indent=1))
 # flop count per parcel of the threshold kernel, both at the bench's 1e7-parcel workloads
 latest = {"tag": tag, "n_parcels": 10_000_000}
 for row in rows:
-    if row["kernel"].startswith("coal_rhs_allinf2_kernel<2, 3, double>") and "FETCH_SIZE" in row and "WRITE_SIZE" in row:
+    if (row["kernel"].startswith(("cloudy_jit_allinf2_n2p3_f64", "coal_rhs_allinf2_kernel<2, 3, double>"))
+            and row["grid_size"] >= 5_000_000 and "FETCH_SIZE" in row and "WRITE_SIZE" in row
+            and not ("cfg3a_kernel" in latest and latest["cfg3a_kernel"].startswith("cloudy_jit"))):
         latest["cfg3a_hbm_bytes_per_launch"] = 2 * row["FETCH_SIZE"] * 1024 + row["WRITE_SIZE"] * 1024
         latest["cfg3a_kernel"] = row["kernel"]
     if row["kernel"].startswith("coal_rhs_sorted_kernel<2, 3, 1, double") and "SQ_INSTS_VALU_FMA_F64" in row:
