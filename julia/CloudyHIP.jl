@@ -28,6 +28,7 @@ mutable struct PlanDesc
     n_vel::Int32
     vel::NTuple{2 * MAX_VEL,Float64}
     device::Int32
+    specialize::Int32               # plan-time compiled kernels for all-Inf thresholds: 0 auto, 1 required, -1 off
 end
 
 check(rc) = rc == 0 ? nothing : error("libcloudy_hip: ", unsafe_string(ccall((:cloudy_last_error, lib), Cstring, ())))
@@ -52,7 +53,7 @@ function plan(pdists, kernels, NProgMoms, thresholds, norms, ts = FixedThreshold
     # row-major [N][N][P][P] with c[a][b] multiplying x^a y^b
     c = Float64[kernels[j][k].c[a, b] for b in 1:P, a in 1:P, k in 1:N, j in 1:N]
     d = Ref(PlanDesc(0, 0, pad((), MAX_MODES, Int32(0)), 0, 0, 0, C_NULL, pad((), MAX_MODES, Inf), 0,
-                     (1.0, 1.0), (eps(Float64), 10.0), 15, 0, 0, pad((), 2MAX_VEL, 0.0), -1))
+                     (1.0, 1.0), (eps(Float64), 10.0), 15, 0, 0, pad((), 2MAX_VEL, 0.0), -1, 0))
     ccall((:cloudy_plan_desc_init, lib), Cvoid, (Ref{PlanDesc},), d)
     d[].n_modes = N
     d[].dist_type = pad(map(dist_code, pdists), MAX_MODES, Int32(0))
