@@ -15,8 +15,8 @@
 #include <string>
 
 #include "host_plan.hpp"
-#include "jit.hpp"
 #include "kernels.hpp"
+#include "jit.hpp"
 #include "reduce_kernels.hpp"
 
 using namespace cloudy;
@@ -85,6 +85,11 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
         void *args[] = {&n, &ld, &in, &out, &dt, &n_steps};
         return hipModuleLaunchKernel(plan->jit.ssprk33, g1, 1, 1, kBlock, 1, 1, 0, r.stream, args, nullptr);
     }
+    if (h.mode != MODE_ALLINF) {
+        const double *nodes = h.nodes_dev;
+        void *args[] = {&nodes, &n, &ld, &in, &out};
+        return hipModuleLaunchKernel(plan->jit.sorted, g1, 1, 1, kBlock, 1, 1, 0, r.stream, args, nullptr);
+    }
     const size_t esz = h.dtype != CLOUDY_F64 ? sizeof(float) : sizeof(double);
     const uintptr_t amask = 2 * esz - 1;
     const bool aligned2 =
@@ -100,7 +105,7 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
 int run(const cloudy_plan *plan, const LaunchReq &r) {
     if (r.n == 0) return CLOUDY_OK;
     if (plan->jit_on && r.input_kind == IN_MOMENTS && r.physical_out && !r.rainshaft &&
-        (r.op == OP_COAL || r.op == OP_SSPRK33)) {
+        (r.op == OP_COAL || (r.op == OP_SSPRK33 && plan->h.mode == MODE_ALLINF))) {
         hipError_t e = launch_jit(plan, r);
         if (e != hipSuccess) return fail_hip(e, "specialised kernel launch");
         return CLOUDY_OK;
@@ -336,10 +341,11 @@ int cloudy_plan_create(const cloudy_plan_desc *d, cloudy_plan **out) {
             return fail_hip(e, "constant block upload");
         }
     }
-    // plan-time specialisation of the all-Inf kernels (jit.hpp): 0 = when available, 1 = required, -1 = off
+    // plan-time specialisation (jit.hpp): 0 = when available, 1 = required, -1 = off
     const char *env = std::getenv("CLOUDY_HIP_JIT");
     const bool env_off = env && env[0] == '0';
-    if (h.mode == MODE_ALLINF && d->specialize >= 0 && !(env_off && d->specialize == 0)) {
+    // every (threshold mode, plane type) combination of cloudy_coal_rhs has a specialised kernel
+    if (d->specialize >= 0 && !(env_off && d->specialize == 0)) {
         p->jit_on = jit_get(h, p->jit, p->jit_log);
         if (!p->jit_on && d->specialize > 0) {
             int rc = fail(CLOUDY_EUNSUPPORTED, "plan-time specialisation failed: %.400s", p->jit_log.c_str());
@@ -347,13 +353,7 @@ int cloudy_plan_create(const cloudy_plan_desc *d, cloudy_plan **out) {
             return rc;
         }
     } else {
-        p->jit_log = h.mode != MODE_ALLINF ? "only plans whose thresholds are all Inf are specialised"
-                                           : "switched off (desc.specialize < 0 or CLOUDY_HIP_JIT=0)";
-        if (d->specialize > 0) {
-            int rc = fail(CLOUDY_EUNSUPPORTED, "plan-time specialisation required but %s", p->jit_log.c_str());
-            cloudy_plan_destroy(p);
-            return rc;
-        }
+        p->jit_log = "switched off (desc.specialize < 0 or CLOUDY_HIP_JIT=0)";
     }
     *out = p;
     return CLOUDY_OK;

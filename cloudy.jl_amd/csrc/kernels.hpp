@@ -756,91 +756,21 @@ __global__ void __launch_bounds__(kBlock)
 // any of them takes, so the 256 parcels of a workgroup are first ranked by r (counting sort in LDS) and each
 // lane then processes the parcel of its rank: waves become regime-homogeneous.  Parcels stay inside their
 // workgroup's 256-parcel window (2 KB per plane), so stores remain line-coalesced.
+template <int N, int P, int MODE, typename TIO, bool FAST = false, bool SPEC = false>
+__device__ __forceinline__ void coal_rhs_sorted_body(const KArgs<N, P> &A, const double *__restrict__ nodes, size_t n,
+                                                     size_t ld, const TIO *__restrict__ in, TIO *__restrict__ out) {
+#define CLOUDY_SPEC SPEC
+#include "coal_rhs_sorted_body.inc"
+#undef CLOUDY_SPEC
+}
+
 template <int N, int P, int MODE, typename TIO, bool FAST = false>
 __global__ void __launch_bounds__(kBlock)
     coal_rhs_sorted_kernel(const KArgs<N, P> A, const double *__restrict__ nodes, size_t n, size_t ld,
                            const TIO *__restrict__ in, TIO *__restrict__ out) {
-    __shared__ double sh_par[3 * N][kBlock];
-    __shared__ __attribute__((aligned(16))) unsigned int sh_key[kBlock];
-    __shared__ unsigned short sh_perm[kBlock];
-    __shared__ unsigned char sh_small[kBlock];
-    const int t = threadIdx.x;
-    const size_t base = (size_t)blockIdx.x * kBlock;
-    {
-        const size_t i0 = base + t;
-        double nn[N], th[N], kk[N];
-        bool all_small = true;
-        unsigned int key = 0xFFFFFFFFu;  // out-of-range or empty parcels rank last
-        if (i0 < n) {
-            all_small = load_parcel<N, P, TIO>(A, i0, ld, in, nn, th, kk);
-            int f = 0;  // first mode that carries a threshold (wave-uniform)
-            if (MODE == MODE_FIXED) {
-#pragma unroll
-                for (int m = N - 2; m >= 0; --m)
-                    if (A.finite[m]) f = m;
-            }
-            double nf = nn[0], thf = th[0], kf = kk[0], xtf = A.thr[0];
-#pragma unroll
-            for (int m = 1; m < N; ++m)
-                if (m == f) {
-                    nf = nn[m];
-                    thf = th[m];
-                    kf = kk[m];
-                    xtf = A.thr[m];
-                }
-            // MOVING: x_t / theta = P^-1(k; p) is a monotone function of k alone -> rank by k
-            const float r = (MODE == MODE_FIXED) ? (float)((xtf / thf) / (kf + double(P + 2))) : (float)kf;
-            if (nf > 0.0 && r == r) key = __float_as_uint(fmaxf(r, 0.0f));
-        } else {
-#pragma unroll
-            for (int m = 0; m < N; ++m) {
-                nn[m] = 0.0;
-                th[m] = 1.0;
-                kk[m] = 1.0;
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < N; ++m) {
-            sh_par[3 * m + 0][t] = nn[m];
-            sh_par[3 * m + 1][t] = th[m];
-            sh_par[3 * m + 2][t] = kk[m];
-        }
-        key = (key & 0xFFFFFF00u) | (unsigned int)t;  // unique keys (thread id in the 8 low mantissa bits): no tie-break
-        sh_key[t] = key;
-        sh_small[t] = all_small ? 1 : 0;
-        __syncthreads();
-        int rank = 0;
-        const uint4 *sh_key4 = reinterpret_cast<const uint4 *>(sh_key);
-#pragma unroll 8
-        for (int s2 = 0; s2 < kBlock / 4; ++s2) {
-            const uint4 k4 = sh_key4[s2];  // wave-uniform address: one broadcast ds_read_b128 per four keys
-            rank += (k4.x < key) + (k4.y < key) + (k4.z < key) + (k4.w < key);
-        }
-        sh_perm[rank] = (unsigned short)t;
-        __syncthreads();
-    }
-    const int src = sh_perm[t];
-    const size_t i = base + src;
-    if (i < n) {
-        double nn[N], th[N], kk[N], acc[N][3];
-#pragma unroll
-        for (int m = 0; m < N; ++m) {
-            nn[m] = sh_par[3 * m + 0][src];
-            th[m] = sh_par[3 * m + 1][src];
-            kk[m] = sh_par[3 * m + 2][src];
-        }
-        coal_ints_parcel<N, P, MODE, FAST>(A, nodes, nn, th, kk, acc);
-        const bool skip = A.rainshaft && sh_small[src];
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-            const int off = A.off[k];
-            // plain (cached) stores: lanes write in permuted order inside the workgroup's 2-KB window, so the L2
-            // must merge them into full lines (nontemporal 8-B stores measured 3.3x write amplification here)
-            out[(size_t)(off + 0) * ld + i] = (TIO)(skip ? 0.0 : acc[k][0] * A.out_scale[3 * k + 0]);
-            out[(size_t)(off + 1) * ld + i] = (TIO)(skip ? 0.0 : acc[k][1] * A.out_scale[3 * k + 1]);
-            if (A.np[k] == 3) out[(size_t)(off + 2) * ld + i] = (TIO)(skip ? 0.0 : acc[k][2] * A.out_scale[3 * k + 2]);
-        }
-    }
+#define CLOUDY_SPEC false
+#include "coal_rhs_sorted_body.inc"
+#undef CLOUDY_SPEC
 }
 
 // ---- on-device explicit time stepping -------------------------------------------------------

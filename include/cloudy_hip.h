@@ -110,8 +110,9 @@ typedef struct cloudy_plan_desc {
     int32_t n_vel;                           /* 0 = no sedimentation term */
     double vel[CLOUDY_MAX_VEL][2];           /* p.vel: terminal velocity sum_k vel[k][0] * x^vel[k][1], physical units */
     int32_t device;                          /* HIP device ordinal, -1 = current */
-    int32_t specialize;                      /* plan-time compilation (hiprtc) of the all-Inf-threshold kernels with the
-                                                plan as compile-time constants: 0 = when available (default; the
+    int32_t specialize;                      /* plan-time compilation (hiprtc) of the cloudy_coal_rhs kernel (and, for
+                                                all-Inf thresholds, the cloudy_ssprk33_steps kernel) with the plan as
+                                                compile-time constants: 0 = when available (default; the
                                                 environment variable CLOUDY_HIP_JIT=0 turns it off), 1 = required
                                                 (plan creation fails otherwise), -1 = off */
 } cloudy_plan_desc;

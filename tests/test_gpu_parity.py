@@ -937,12 +937,34 @@ def test_plan_time_specialised_kernels_are_bit_identical(gpu_cloudy, oracle):
         outs.append(o.to_numpy())
     ok = np.all(np.isfinite(outs[1]), axis=0)
     assert ok.mean() > 0.9 and np.array_equal(outs[0][:, ok], outs[1][:, ok])
-    # a second plan with the same constants shares the compiled module (instant); thresholds are never specialised
+    # a second plan with the same constants shares the compiled module (instant)
     assert cloudy.Plan(dts, cd.kernel_c, cd.dist_thresholds_in, cd.norms, 0, specialize=1).specialized
-    thr = bench.make_workload("cfg3b", 16)["coal_data"].plan(dts)
-    assert not thr.specialized and "all Inf" in thr.jit_log()
-    with pytest.raises(cloudy.CloudyError):
-        bench.make_workload("cfg3b", 16)["coal_data"].plan(dts, specialize=1).close()
+
+
+@pytest.mark.parametrize("name,moving,dtype", [("cfg3b", False, 0), ("cfg3b", False, 2), ("cfg3b", True, 0),
+                                               ("cfg4", False, 0)])
+def test_specialised_threshold_kernels_are_bit_identical(gpu_cloudy, oracle, name, moving, dtype):
+    """Plans with a threshold get the regime-sorted kernel compiled for them too (tensors, norms, threshold and node
+    counts as constants; the node table stays in memory): same bits as the ahead-of-time kernel."""
+    cloudy = gpu_cloudy
+    n = 20_011
+    wl = bench.make_workload(name, n, seed=29)
+    dts = wl["dist_types"]
+    if moving:
+        N = len(dts)
+        kc = wl["kernel_c"]
+        kernels = tuple(tuple(cloudy.CoalescenceTensor(kc[j, k]) for k in range(N)) for j in range(N))
+        cd = cloudy.CoalescenceData(kernels, wl["NProgMoms"], (0.9,) * (N - 1) + (1.0,), bench.NORMS,
+                                    cloudy.MovingThreshold())
+    else:
+        cd = wl["coal_data"]
+    spec, gen = cd.plan(dts, dtype=dtype, specialize=1), cd.plan(dts, dtype=dtype, specialize=-1)
+    assert spec.specialized and not gen.specialized
+    tio = np.float64 if dtype == 0 else np.float32
+    a, b = _rhs_with_plan(cloudy, spec, wl["mom"], tio), _rhs_with_plan(cloudy, gen, wl["mom"], tio)
+    fin = np.all(np.isfinite(b), axis=0)
+    assert fin.mean() > 0.95 and np.array_equal(a[:, fin], b[:, fin])
+    assert np.array_equal(np.isnan(a), np.isnan(b))
 
 
 @pytest.mark.parametrize("N,P", [(1, 1), (1, 2), (2, 2), (3, 3), (4, 2), (2, 5), (4, 5)])
