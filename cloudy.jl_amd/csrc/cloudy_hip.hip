@@ -12,6 +12,7 @@
 #include <new>
 #include <vector>
 
+#include <mutex>
 #include <string>
 
 #include "host_plan.hpp"
@@ -26,6 +27,10 @@ struct cloudy_plan {
     bool jit_on = false;   // plan-time specialised kernels (jit.hpp) serve cloudy_coal_rhs / cloudy_ssprk33_steps
     JitKernels jit;
     std::string jit_log;   // why not, when jit_on is false
+    // thresholded plans compile their fused integrator on the first cloudy_ssprk33_steps call
+    mutable std::once_flag int_once;
+    mutable hipFunction_t int_ssprk33 = nullptr;
+    mutable std::string int_log;
 };
 
 namespace {
@@ -82,6 +87,11 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
     if (r.op == OP_SSPRK33) {
         double dt = r.dt;
         int n_steps = r.n_steps;
+        if (h.mode != MODE_ALLINF) {
+            const double *nodes = h.nodes_dev;
+            void *args[] = {&nodes, &n, &ld, &in, &out, &dt, &n_steps};
+            return hipModuleLaunchKernel(plan->int_ssprk33, g1, 1, 1, kBlock, 1, 1, 0, r.stream, args, nullptr);
+        }
         void *args[] = {&n, &ld, &in, &out, &dt, &n_steps};
         return hipModuleLaunchKernel(plan->jit.ssprk33, g1, 1, 1, kBlock, 1, 1, 0, r.stream, args, nullptr);
     }
@@ -104,8 +114,14 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
 
 int run(const cloudy_plan *plan, const LaunchReq &r) {
     if (r.n == 0) return CLOUDY_OK;
-    if (plan->jit_on && r.input_kind == IN_MOMENTS && r.physical_out && !r.rainshaft &&
-        (r.op == OP_COAL || (r.op == OP_SSPRK33 && plan->h.mode == MODE_ALLINF))) {
+    bool use_jit = plan->jit_on && r.input_kind == IN_MOMENTS && r.physical_out && !r.rainshaft &&
+                   (r.op == OP_COAL || r.op == OP_SSPRK33);
+    if (use_jit && r.op == OP_SSPRK33 && plan->h.mode != MODE_ALLINF) {
+        std::call_once(plan->int_once,
+                       [&] { (void)jit_get_integrator(plan->h, plan->int_ssprk33, plan->int_log); });
+        use_jit = plan->int_ssprk33 != nullptr;  // otherwise the ahead-of-time integrator
+    }
+    if (use_jit) {
         hipError_t e = launch_jit(plan, r);
         if (e != hipSuccess) return fail_hip(e, "specialised kernel launch");
         return CLOUDY_OK;
