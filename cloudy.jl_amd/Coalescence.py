@@ -14,8 +14,10 @@ EPS = float(np.finfo(np.float64).eps)
 class Plan:
     """Owner of a cloudy_plan handle (include/cloudy_hip.h): one immutable constant block per configuration."""
 
-    def __init__(self, dist_types, kernel_c, dist_thresholds, norms, threshold_style, k_range=(EPS, 10.0),
-                 n_bins_per_log_unit=15, vel=(), kernel_is_normalized=False, device=-1, dtype=0, specialize=0):
+    @staticmethod
+    def make_desc(dist_types, kernel_c, dist_thresholds, norms, threshold_style, k_range=(EPS, 10.0),
+                  n_bins_per_log_unit=15, vel=(), kernel_is_normalized=False, device=-1, dtype=0, specialize=0):
+        """The cloudy_plan_desc of a configuration and the array its kernel_c pointer refers to (keep it alive)."""
         L = _lib.lib()
         d = _lib.PlanDesc()
         L.cloudy_plan_desc_init(C.byref(d))
@@ -29,7 +31,6 @@ class Plan:
         d.tensor_p = kc.shape[-1]
         d.kernel_layout = 1 if kc.ndim == 4 else 0
         d.kernel_is_normalized = int(bool(kernel_is_normalized))
-        self._kc = kc  # keep alive during create
         d.kernel_c = kc.ctypes.data_as(C.POINTER(C.c_double))
         for i, t in enumerate(dist_thresholds):
             d.dist_thresholds[i] = float(t)
@@ -45,9 +46,17 @@ class Plan:
             d.vel[2 * i], d.vel[2 * i + 1] = v[i, 0], v[i, 1]
         d.device = int(device)
         d.dtype = int(dtype)  # CLOUDY_F64 = 0; CLOUDY_F32 = 1: float planes in HBM, fp64 arithmetic in registers
-        self.dtype = int(dtype)
-        # plan-time compiled kernels for all-Inf thresholds: 0 = when available, 1 = required, -1 = off
+        # plan-time compiled kernels: 0 = when available, 1 = required, -1 = off
         d.specialize = int(specialize)
+        return d, kc
+
+    def __init__(self, dist_types, kernel_c, dist_thresholds, norms, threshold_style, k_range=(EPS, 10.0),
+                 n_bins_per_log_unit=15, vel=(), kernel_is_normalized=False, device=-1, dtype=0, specialize=0):
+        L = _lib.lib()
+        d, self._kc = Plan.make_desc(dist_types, kernel_c, dist_thresholds, norms, threshold_style, k_range,
+                                     n_bins_per_log_unit, vel, kernel_is_normalized, device, dtype, specialize)
+        N = len(dist_types)
+        self.dtype = int(dtype)
         h = C.c_void_p()
         _lib.check(L.cloudy_plan_create(C.byref(d), C.byref(h)))
         self.handle = h

@@ -51,6 +51,7 @@ SYMBOLS = {
     "cloudy_plan_destroy": (None, [_vp]),
     "cloudy_plan_specialized": (_i, [_vp]),
     "cloudy_plan_jit_log": (C.c_char_p, [_vp]),
+    "cloudy_jit_selfcheck": (_i, [C.POINTER(PlanDesc), C.c_char_p]),
     "cloudy_plan_nmom": (_i, [_vp]),
     "cloudy_plan_nparams": (_i, [_vp]),
     "cloudy_plan_get": (_i, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _dp, _dp, _dp]),

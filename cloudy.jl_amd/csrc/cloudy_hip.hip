@@ -151,7 +151,13 @@ void cloudy_plan_desc_init(cloudy_plan_desc *d) {
     d->device = -1;
 }
 
-int cloudy_plan_create(const cloudy_plan_desc *d, cloudy_plan **out) {
+}  // extern "C"
+
+namespace {
+
+// Host half of cloudy_plan_create: validation and every derived constant (no device involved).  On success *out owns
+// a plan without device resources and `nodes` holds the Simpson node tables.
+int build_host_plan(const cloudy_plan_desc *d, cloudy_plan **out, std::vector<double> &nodes) {
     if (!d || !out) return fail(CLOUDY_EINVAL, "desc/out is NULL");
     *out = nullptr;
     if (d->struct_size != sizeof(cloudy_plan_desc))
@@ -237,7 +243,7 @@ int cloudy_plan_create(const cloudy_plan_desc *d, cloudy_plan **out) {
 
     // Simpson node tables for FixedThreshold (ParticleDistributions.jl:604-610): the grid depends only on
     // the (normalised) threshold, so it is built once here, in fp64, exactly as the reference builds it.
-    std::vector<double> nodes;
+    nodes.clear();
     bool any_finite = false;
     if (d->threshold_style == CLOUDY_FIXED_THRESHOLD) {
         for (int i = 0; i < N - 1; ++i) {
@@ -308,6 +314,22 @@ int cloudy_plan_create(const cloudy_plan_desc *d, cloudy_plan **out) {
         h.vel_n[v][0] = d->vel[v][0] * std::pow(d->norms[1], d->vel[v][1]);
         h.vel_n[v][1] = d->vel[v][1];
     }
+    h.n_nodes = (int)(nodes.size() / kNodeStride);
+    *out = p;
+    return CLOUDY_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cloudy_plan_create(const cloudy_plan_desc *d, cloudy_plan **out) {
+    cloudy_plan *p = nullptr;
+    std::vector<double> nodes;
+    int rc0 = build_host_plan(d, &p, nodes);
+    if (out) *out = nullptr;
+    if (rc0 != CLOUDY_OK) return rc0;
+    HostPlan &h = p->h;
 
     // device-side constants
     int ndev = 0;
@@ -334,7 +356,6 @@ int cloudy_plan_create(const cloudy_plan_desc *d, cloudy_plan **out) {
         const char *e = std::getenv("CLOUDY_HIP_PPL1");
         h.force_ppl1 = (e && e[0] == '1') ? 1 : 0;
     }
-    h.n_nodes = (int)(nodes.size() / kNodeStride);
     if (h.n_nodes > 0) {
         e = hipMalloc((void **)&h.nodes_dev, nodes.size() * sizeof(double));
         if (e == hipSuccess)
@@ -381,6 +402,21 @@ int cloudy_plan_specialized(const cloudy_plan *plan) {
 }
 
 const char *cloudy_plan_jit_log(const cloudy_plan *plan) { return plan ? plan->jit_log.c_str() : "plan is NULL"; }
+
+int cloudy_jit_selfcheck(const cloudy_plan_desc *d, const char *arch) {
+    cloudy_plan *p = nullptr;
+    std::vector<double> nodes;
+    int rc = build_host_plan(d, &p, nodes);
+    if (rc != CLOUDY_OK) return rc;
+    std::string log;
+    std::vector<char> code;
+    const std::string a = (arch && *arch) ? arch : "gfx950";
+    bool ok = jit_compile(jit_source(p->h, 0), a, p->h.mode == MODE_ALLINF, code, log);
+    if (ok && p->h.mode != MODE_ALLINF) ok = jit_compile(jit_source(p->h, 1), a, true, code, log);
+    delete p;
+    if (!ok) return fail(CLOUDY_EUNSUPPORTED, "plan-time compilation failed: %.440s", log.c_str());
+    return CLOUDY_OK;
+}
 
 void cloudy_plan_destroy(cloudy_plan *plan) {
     if (!plan) return;

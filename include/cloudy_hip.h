@@ -127,6 +127,10 @@ void cloudy_plan_destroy(cloudy_plan *plan);
  * the reason (or the compiler log) in cloudy_plan_jit_log.  Either way the results are the same bits. */
 int cloudy_plan_specialized(const cloudy_plan *plan);
 const char *cloudy_plan_jit_log(const cloudy_plan *plan);
+/* Build check without a GPU: validates `desc`, generates the plan's specialised translation unit(s) and compiles them
+ * with hiprtc for `arch` (NULL = "gfx950"); nothing is loaded or launched.  CLOUDY_OK, or CLOUDY_EUNSUPPORTED with the
+ * compiler log in cloudy_last_error(). */
+int cloudy_jit_selfcheck(const cloudy_plan_desc *desc, const char *arch);
 int cloudy_plan_nmom(const cloudy_plan *plan);      /* sum(NProgMoms) */
 int cloudy_plan_nparams(const cloudy_plan *plan);   /* 3 * N planes of (n, theta, k) */
 /* copies of the derived CoalescenceData fields (Coalescence.jl:69-84), for tests and hosts */

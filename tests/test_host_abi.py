@@ -218,3 +218,42 @@ def test_polyfit_reference_kats(cloudy):
     h = cloudy.CoalescenceTensor(cloudy.HydrodynamicKernelFunction(1e2 * np.pi), 4, 1e-6)
     assert h.c.shape == (5, 5) and np.array_equal(h.c, h.c.T)
     assert h.c[0, 0] == np.finfo(np.float64).eps / 1e6
+
+
+@pytest.mark.parametrize("case", ["cfg2", "cfg3a", "cfg3a_f32", "cfg3b", "cfg3b_f32fast", "cfg3_moving", "cfg4",
+                                  "n4p5_mixed"])
+def test_plan_time_translation_units_compile_without_a_gpu(cloudy, case):
+    """cloudy_jit_selfcheck: the kernel sources embedded in libcloudy_hip.so plus the generated constexpr plan compile
+    with hiprtc for gfx950 here, on the CPU -- the build check of the plan-time specialisation (jit.hpp).  Thresholded
+    plans compile two units (single-pass kernel; fused integrator)."""
+    import bench
+
+    L = cloudy.lib()
+    moving, dtype = 0, 0
+    if case == "n4p5_mixed":
+        rng = np.random.default_rng(7)
+        N, P = 4, 5
+        kc = np.zeros((N, N, P, P))
+        for j in range(N):
+            for k in range(j, N):
+                c = rng.uniform(0.1, 1.0, (P, P)) * (rng.random((P, P)) < 0.5)
+                kc[j, k] = kc[k, j] = np.triu(c) + np.triu(c, 1).T
+        dist_types, thr, dtype = [0, 1, 2, 1], (1e-9, 1e-8, 1e-7, INF), 1
+    else:
+        name = {"cfg3a_f32": "cfg3a", "cfg3b_f32fast": "cfg3b", "cfg3_moving": "cfg3b"}.get(case, case)
+        spec = bench.workload_spec(name)
+        kc, dist_types, thr = bench.kernel_matrix(spec), [1] * spec["n_modes"], spec["thresholds"]
+        dtype = {"cfg3a_f32": 1, "cfg3b_f32fast": 2}.get(case, 0)
+        if case == "cfg3_moving":
+            moving, thr = 1, (0.9, 1.0)
+    d, keep = cloudy.Plan.make_desc(dist_types, kc, thr, bench.NORMS, moving, dtype=dtype)
+    rc = L.cloudy_jit_selfcheck(C.byref(d), b"gfx950")
+    assert rc == 0, L.cloudy_last_error().decode()
+    assert keep is not None
+
+
+def test_jit_selfcheck_reports_descriptor_errors(cloudy):
+    L = cloudy.lib()
+    d, keep = cloudy.Plan.make_desc([1], [[1.0, 2.0], [3.0, 4.0]], (INF,), (1.0, 1.0), 0)
+    assert L.cloudy_jit_selfcheck(C.byref(d), None) == cloudy._lib.ENOTSYMMETRIC
+    assert b"not symmetric" in L.cloudy_last_error()
