@@ -28,8 +28,8 @@ struct cloudy_plan {
     JitKernels jit;
     std::string jit_log;   // why not, when jit_on is false
     // thresholded plans compile their fused integrator on the first cloudy_ssprk33_steps call
-    mutable std::once_flag int_once;
-    mutable hipFunction_t int_ssprk33 = nullptr;
+    mutable std::once_flag int_once, rs_once;
+    mutable hipFunction_t int_ssprk33 = nullptr, rs_coal = nullptr;
     mutable std::string int_log;
 };
 
@@ -98,7 +98,12 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
     if (h.mode != MODE_ALLINF) {
         const double *nodes = h.nodes_dev;
         void *args[] = {&nodes, &n, &ld, &in, &out};
-        return hipModuleLaunchKernel(plan->jit.sorted, g1, 1, 1, kBlock, 1, 1, 0, r.stream, args, nullptr);
+        return hipModuleLaunchKernel(r.rainshaft ? plan->rs_coal : plan->jit.sorted, g1, 1, 1, kBlock, 1, 1, 0, r.stream,
+                                     args, nullptr);
+    }
+    if (r.rainshaft) {
+        void *args[] = {&n, &ld, &in, &out};
+        return hipModuleLaunchKernel(plan->rs_coal, g1, 1, 1, kBlock, 1, 1, 0, r.stream, args, nullptr);
     }
     const size_t esz = h.dtype != CLOUDY_F64 ? sizeof(float) : sizeof(double);
     const uintptr_t amask = 2 * esz - 1;
@@ -114,8 +119,12 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
 
 int run(const cloudy_plan *plan, const LaunchReq &r) {
     if (r.n == 0) return CLOUDY_OK;
-    bool use_jit = plan->jit_on && r.input_kind == IN_MOMENTS && r.physical_out && !r.rainshaft &&
-                   (r.op == OP_COAL || r.op == OP_SSPRK33);
+    bool use_jit = plan->jit_on && r.input_kind == IN_MOMENTS && r.physical_out &&
+                   (r.op == OP_COAL || (r.op == OP_SSPRK33 && !r.rainshaft));
+    if (use_jit && r.op == OP_COAL && r.rainshaft) {
+        std::call_once(plan->rs_once, [&] { (void)jit_get_rainshaft(plan->h, plan->rs_coal, plan->int_log); });
+        use_jit = plan->rs_coal != nullptr;
+    }
     if (use_jit && r.op == OP_SSPRK33 && plan->h.mode != MODE_ALLINF) {
         std::call_once(plan->int_once,
                        [&] { (void)jit_get_integrator(plan->h, plan->int_ssprk33, plan->int_log); });
@@ -413,6 +422,7 @@ int cloudy_jit_selfcheck(const cloudy_plan_desc *d, const char *arch) {
     const std::string a = (arch && *arch) ? arch : "gfx950";
     bool ok = jit_compile(jit_source(p->h, 0), a, p->h.mode == MODE_ALLINF, code, log);
     if (ok && p->h.mode != MODE_ALLINF) ok = jit_compile(jit_source(p->h, 1), a, true, code, log);
+    if (ok) ok = jit_compile(jit_source(p->h, 2), a, false, code, log);  // rainshaft cell body
     delete p;
     if (!ok) return fail(CLOUDY_EUNSUPPORTED, "plan-time compilation failed: %.440s", log.c_str());
     return CLOUDY_OK;

@@ -965,6 +965,18 @@ def test_specialised_threshold_kernels_are_bit_identical(gpu_cloudy, oracle, nam
     fin = np.all(np.isfinite(b), axis=0)
     assert fin.mean() > 0.95 and np.array_equal(a[:, fin], b[:, fin])
     assert np.array_equal(np.isnan(a), np.isnan(b))
+    # the rainshaft cell body (clamp + empty-cell rule) has its own specialised kernel, compiled on first use
+    if not moving:
+        vel = ((50.0, 1.0 / 6),)
+        sv, gv = cd.plan(dts, vel=vel, dtype=dtype, specialize=1), cd.plan(dts, vel=vel, dtype=dtype, specialize=-1)
+        mneg = wl["mom"].astype(tio).copy()
+        mneg[:, ::97] *= -1.0                      # negative moments are clamped to zero
+        mneg[:, 5::101] = 0.0                      # empty cells skip coalescence
+        res = [cloudy.rainshaft_sources(pl, cloudy.DeviceArray.from_numpy(mneg)) for pl in (sv, gv)]
+        for x, y in zip(res[0], res[1]):
+            x, y = x.to_numpy(), y.to_numpy()
+            f2 = np.isfinite(y)
+            assert np.array_equal(x[f2], y[f2])
     # the fused integrator of a thresholded plan is compiled on its first call
     reg = np.flatnonzero(fin)[:4096]
     u0 = np.ascontiguousarray(wl["mom"][:, reg]).astype(tio)
