@@ -524,6 +524,47 @@ __device__ __forceinline__ void contract_promoted(const double (&ckk)[P][P], con
     T0 *= 0.5;
 }
 
+
+// Regime ranking of a workgroup's 256 parcels by a non-negative float key (the threshold kernels sort their lanes so
+// that waves become regime-homogeneous): a counting sort on 255 logarithmic buckets -- eight per binade over
+// [2^-8, 2^23.75], i.e. the key to ~9 % -- with one LDS atomic per lane and a workgroup prefix sum, instead of
+// comparing every key with every other (1030 VALU instructions per lane, 6 % of the cfg3b kernel; measured equal
+// quality of the resulting waves).  Invalid / empty parcels (valid = false) rank last.  The order inside a bucket is
+// whatever order the atomics were served in: any permutation gives the same results, parcels are independent.
+// sh_cnt: kBlock counters; returns through sh_perm the lane -> slot map: slot `rank` is processed by lane sh_perm[rank].
+__device__ __forceinline__ void regime_rank(bool valid, float key, unsigned int *sh_cnt, unsigned short *sh_perm) {
+    const int t = threadIdx.x;
+    int bucket = kBlock - 1;
+    if (valid) {
+        const int code = (int)(__float_as_uint(fmaxf(key, 0.0f)) >> 20) - (127 - 8) * 8;
+        bucket = code < 0 ? 0 : (code > kBlock - 2 ? kBlock - 2 : code);
+    }
+    sh_cnt[t] = 0u;
+    __syncthreads();
+    const unsigned int pos = atomicAdd(&sh_cnt[bucket], 1u);
+    __syncthreads();
+    // exclusive prefix sum of the 256 counters: inclusive scan inside each wave, wave totals through LDS
+    const unsigned int c = sh_cnt[t];
+    unsigned int incl = c;
+    const int lane = t & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned int up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+    }
+    __shared__ unsigned int sh_wave_tot[kBlock / 64];
+    if (lane == 63) sh_wave_tot[t >> 6] = incl;
+    __syncthreads();
+    unsigned int offs = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w)
+        if (w < (t >> 6)) offs += sh_wave_tot[w];
+    sh_cnt[t] = offs + incl - c;  // exclusive prefix of bucket t
+    __syncthreads();
+    sh_perm[sh_cnt[bucket] + pos] = (unsigned short)t;
+    __syncthreads();
+}
+
 // Plan-time specialisation (jit.hpp): when the plan constants are compile-time values (SPEC), terms whose tensor
 // coefficient is exactly zero are dropped -- fma(0, M, v) == v for finite M, so results are bit-identical -- and the
 // remaining coefficients become literals.  In the ahead-of-time kernels (SPEC = false) the test is constant-true.
@@ -808,10 +849,11 @@ __device__ __forceinline__ void ssprk33_body(const KArgs<N, P> *__restrict__ Ag,
     size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (MODE != MODE_ALLINF) {
         // regime sort of the workgroup's parcels on the initial state (see coal_rhs_sorted_kernel)
-        __shared__ __attribute__((aligned(16))) unsigned int sh_key[kBlock];
+        __shared__ unsigned int sh_cnt[kBlock];
         __shared__ unsigned short sh_perm[kBlock];
         const int t = threadIdx.x;
-        unsigned int key = 0xFFFFFFFFu;
+        bool valid = false;
+        float rkey = 0.0f;
         if (i < n) {
             double nn[N], th[N], kk[N];
             load_parcel<N, P, TIO>(A, i, ld, u_in, nn, th, kk);
@@ -831,20 +873,10 @@ __device__ __forceinline__ void ssprk33_body(const KArgs<N, P> *__restrict__ Ag,
                     xtf = A.thr[m];
                 }
             const float r = (MODE == MODE_FIXED) ? (float)((xtf / thf) / (kf + double(P + 2))) : (float)kf;
-            if (nf > 0.0 && r == r) key = __float_as_uint(fmaxf(r, 0.0f));
+            valid = nf > 0.0 && r == r;
+            rkey = r;
         }
-        key = (key & 0xFFFFFF00u) | (unsigned int)t;
-        sh_key[t] = key;
-        __syncthreads();
-        int rank = 0;
-        const uint4 *sh_key4 = reinterpret_cast<const uint4 *>(sh_key);
-#pragma unroll 8
-        for (int s2 = 0; s2 < kBlock / 4; ++s2) {
-            const uint4 k4 = sh_key4[s2];
-            rank += (k4.x < key) + (k4.y < key) + (k4.z < key) + (k4.w < key);
-        }
-        sh_perm[rank] = (unsigned short)t;
-        __syncthreads();
+        regime_rank(valid, rkey, sh_cnt, sh_perm);
         i = (size_t)blockIdx.x * kBlock + sh_perm[t];
     }
     if (i >= n) return;
@@ -1076,9 +1108,10 @@ __global__ void __launch_bounds__(kBlock)
         // regime sort of the workgroup's cells on the initial state (see coal_rhs_sorted_kernel): lanes of a wave get
         // cells of similar x_t / theta, so their Simpson passes take the same branches; the flux exchange below is
         // indexed by cell slot, not by lane, so any permutation works.
-        __shared__ __attribute__((aligned(16))) unsigned int sh_key[kBlock];
+        __shared__ unsigned int sh_cnt[kBlock];
         __shared__ unsigned short sh_perm[kBlock];
-        unsigned int key = 0xFFFFFFFFu;
+        bool valid = false;
+        float rkey = 0.0f;
         {
             const int c0 = t / nz;
             const size_t col0 = (size_t)blockIdx.x * cpb + c0;
@@ -1099,22 +1132,11 @@ __global__ void __launch_bounds__(kBlock)
                         xtf = A.thr[m];
                     }
                 const float r = (float)((xtf / thf) / (kf + double(P + 2)));
-                key = 0xFFFFFF00u;  // empty cells after the occupied ones, before the idle slots
-                if (nf > 0.0 && r == r) key = __float_as_uint(fmaxf(r, 0.0f));  // <= 0x7F800000
+                valid = nf > 0.0 && r == r;  // (empty cells and idle slots rank last)
+                rkey = r;
             }
         }
-        key = (key & 0xFFFFFF00u) | (unsigned int)t;
-        sh_key[t] = key;
-        __syncthreads();
-        int rank = 0;
-        const uint4 *sh_key4 = reinterpret_cast<const uint4 *>(sh_key);
-#pragma unroll 8
-        for (int s2 = 0; s2 < kBlock / 4; ++s2) {
-            const uint4 k4 = sh_key4[s2];
-            rank += (k4.x < key) + (k4.y < key) + (k4.z < key) + (k4.w < key);
-        }
-        sh_perm[rank] = (unsigned short)t;
-        __syncthreads();
+        regime_rank(valid, rkey, sh_cnt, sh_perm);
         // The per-stage barrier makes a workgroup as slow as its most expensive wave.  Odd workgroups hand the sorted
         // cells to their waves in reverse order, so that a SIMD holding waves of two workgroups does not get the two
         // expensive ends.
