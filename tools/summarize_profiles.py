@@ -53,7 +53,9 @@ for row in rows:
             and not ("cfg3a_kernel" in latest and latest["cfg3a_kernel"].startswith("cloudy_jit"))):
         latest["cfg3a_hbm_bytes_per_launch"] = 2 * row["FETCH_SIZE"] * 1024 + row["WRITE_SIZE"] * 1024
         latest["cfg3a_kernel"] = row["kernel"]
-    if row["kernel"].startswith("coal_rhs_sorted_kernel<2, 3, 1, double") and "SQ_INSTS_VALU_FMA_F64" in row:
+    if (row["kernel"].startswith(("cloudy_jit_sorted_n2p3_f64", "coal_rhs_sorted_kernel<2, 3, 1, double"))
+            and row["grid_size"] >= 10_000_000 and "SQ_INSTS_VALU_FMA_F64" in row
+            and not ("cfg3b_kernel" in latest and latest["cfg3b_kernel"].startswith("cloudy_jit"))):
         util = row["SQ_THREAD_CYCLES_VALU"] / (row["SQ_ACTIVE_INST_VALU"] * 64.0)
         flops = (2 * row["SQ_INSTS_VALU_FMA_F64"] + row["SQ_INSTS_VALU_MUL_F64"] + row["SQ_INSTS_VALU_ADD_F64"]) * 64.0 * util
         latest["cfg3b_fp64_flops_per_launch"] = flops
