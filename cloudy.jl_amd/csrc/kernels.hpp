@@ -335,7 +335,7 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double n, 
         const double E0 = exp(fma(a_top, nd.lxmx - lnth, -z) - lg_top);
         double Pz[M];
         Pz[M - 1] = inc_gamma_p_from_E(a_top, z, E0, nullptr);
-        const double invz = 1.0 / z;
+        const double invz = recip_fast(z);
         double E = E0, a = a_top;
 #pragma unroll
         for (int p2 = M - 2; p2 >= 0; --p2) {
