@@ -329,9 +329,10 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double n, 
 #pragma unroll 1
     for (; j < nb; ++j) {
         const SimpsonNode nd = grid.node(j, true);
-        const double t = nd.x * inv_th, z = nd.xmx * inv_th;
-        if (!(z > 0.0)) continue;  // P(a, z <= 0) = 0
-        const double h0 = nd.wdx * exp(fma(k, nd.lx - lnth, -t));
+        const double t = nd.x * inv_th, zr = nd.xmx * inv_th;
+        const bool zpos = zr > 0.0;  // P(a, z <= 0) = 0: such a node (never on the reference grid) contributes nothing
+        const double z = zpos ? zr : 1.0;
+        const double h0 = zpos ? nd.wdx * exp(fma(k, nd.lx - lnth, -t)) : 0.0;
         const double E0 = exp(fma(a_top, nd.lxmx - lnth, -z) - lg_top);
         double Pz[M];
         Pz[M - 1] = inc_gamma_p_from_E(a_top, z, E0, nullptr);
