@@ -806,8 +806,14 @@ __device__ __forceinline__ void coal_rhs_sorted_body(const KArgs<N, P> &A, const
 #undef CLOUDY_SPEC
 }
 
+// Occupancy target of the threshold kernels: the Simpson pass is a long chain of dependent fp64 operations, and going
+// from 2 to 3-4 resident waves per SIMD is worth more than the few spilled registers it costs the P = 5 families
+// (cfg4, N = 3, P = 5: 184 VGPRs / occupancy 2 -> 128 VGPRs + 18 spilled / occupancy 4: 17.5 -> 14.3 ms).
+#ifndef CLOUDY_SORTED_WAVES
+#define CLOUDY_SORTED_WAVES 4
+#endif
 template <int N, int P, int MODE, typename TIO, bool FAST = false>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CLOUDY_SORTED_WAVES)))
     coal_rhs_sorted_kernel(const KArgs<N, P> A, const double *__restrict__ nodes, size_t n, size_t ld,
                            const TIO *__restrict__ in, TIO *__restrict__ out) {
 #define CLOUDY_SPEC false
@@ -933,7 +939,7 @@ __device__ __forceinline__ void ssprk33_body(const KArgs<N, P> *__restrict__ Ag,
 }
 
 template <int N, int P, int MODE, typename TIO>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CLOUDY_SORTED_WAVES)))
     ssprk33_kernel(const KArgs<N, P> *__restrict__ Ag, const double *__restrict__ nodes, size_t n, size_t ld,
                    const TIO *u_in, TIO *u_out, double dt, int n_steps) {
     ssprk33_body<N, P, MODE, TIO>(Ag, nodes, n, ld, u_in, u_out, dt, n_steps);
