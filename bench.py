@@ -91,6 +91,9 @@ def workload_spec(name):
     if name == "cfg4":   # BASELINE configs[3] in the reference's formulation: 3 Gamma modes, hydrodynamic kernel as an
         # order-4 fitted tensor (box_gamma_mixture_hydro.jl:22-23), thresholds of box_gamma_mixture_3modes.jl:29
         return dict(n_modes=3, kernel="hydro", thresholds=(1e-9, 1e-7, INF), default_parcels=12_500_000)
+    if name == "moving4":  # box_gamma_mix_moving.jl:13-30: 4 Gamma modes, Golovin b = 5, MovingThreshold percentiles 0.99
+        return dict(n_modes=4, kernel="golovin", thresholds=(0.99, 0.99, 0.99, 1.0), moving=True,
+                    default_parcels=2_500_000)
     raise ValueError(f"unknown workload {name}")
 
 
@@ -129,7 +132,8 @@ def make_workload(name, n_parcels, seed=SEED):
     kc = kernel_matrix(spec)
     kernels = tuple(tuple(pkg.CoalescenceTensor(kc[j, k]) for k in range(N)) for j in range(N))
     NProgMoms = (3,) * N
-    coal_data = pkg.CoalescenceData(kernels, NProgMoms, spec["thresholds"], NORMS)
+    ts = pkg.MovingThreshold() if spec.get("moving") else pkg.FixedThreshold()
+    coal_data = pkg.CoalescenceData(kernels, NProgMoms, spec["thresholds"], NORMS, ts)
     pdists = tuple(pkg.GammaPrimitiveParticleDistribution(1.0, 1.0, 1.0) for _ in range(N))
     par = pkg.ODEParameters(pdists, coal_data, NProgMoms, NORMS)
     return dict(name=name, spec=spec, mom=synth_moments(N, n_parcels, seed), coal_data=coal_data,
@@ -141,7 +145,8 @@ def oracle_params(name):
     from oracle import cloudy_oracle as O
 
     spec = workload_spec(name)
-    return O.make_params([O.GAMMA] * spec["n_modes"], kernel_matrix(spec), spec["thresholds"], norms=NORMS)
+    return O.make_params([O.GAMMA] * spec["n_modes"], kernel_matrix(spec), spec["thresholds"], norms=NORMS,
+                         threshold_style=O.MOVING_THRESHOLD if spec.get("moving") else O.FIXED_THRESHOLD)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -403,19 +408,20 @@ def main():
 
     if not args.no_variants and args.workload == "cfg3a":
         # the other BASELINE configurations, a few launches each
-        for vname, vn in (("cfg2", 1_000_000), ("cfg4", 12_500_000)):
+        for vname, vn in (("cfg2", 1_000_000), ("cfg4", 12_500_000), ("moving4", 2_500_000)):
             wlv = make_workload(vname, vn, seed=SEED + 1000 * rank)
             planv = wlv["coal_data"].plan(wlv["dist_types"])
             mv = pkg.DeviceArray.from_numpy(wlv["mom"])
             dmv = pkg.DeviceArray.zeros(planv.nmom, vn)
             reps = 200 if vname == "cfg2" else 3
-            for _ in range(3 if vname == "cfg4" else 200):
+            for _ in range(200 if vname == "cfg2" else 3):
                 pkg._lib.check(pkg.lib().cloudy_coal_rhs(planv.handle, vn, vn, mv.ptr, dmv.ptr, None))
             msv = _event_ms(pkg, planv, mv, dmv, reps)
             spv = workload_spec(vname)
             variants[vname] = {
                 "workload": f"{vname}: {vn} parcels/GPU, {spv['n_modes']} Gamma mode(s), kernel {spv['kernel']}, "
-                            f"thresholds {spv['thresholds']}, {planv.nmom} moments, fp64",
+                            f"{'MovingThreshold percentiles' if spv.get('moving') else 'thresholds'} "
+                            f"{spv['thresholds']}, {planv.nmom} moments, fp64",
                 "value": vn * world / (msv * 1e-3), "unit": "parcel-RHS/s", "kernel_ms": msv,
                 "hbm_GBs": 2 * planv.nmom * 8 * vn / (msv * 1e-3) / 1e9,
             }

@@ -574,83 +574,80 @@ __device__ __forceinline__ constexpr bool nzc(double c) {
     return SPEC ? c != 0.0 : true;
 }
 
-// get_coal_ints for one parcel: acc[k][m], normalised units.
-template <int N, int P, int MODE, bool FAST = false, bool SPEC = false>
-__device__ __forceinline__ void coal_ints_parcel(const KArgs<N, P> &A, const double *__restrict__ nodes,
-                                                 const double (&nn)[N], const double (&th)[N], const double (&kk)[N],
-                                                 double (&acc)[N][3]) {
+// The promoted part of the self collisions of ONE mode k (Coalescence.jl:200-244, 353-455): with
+// F = get_finite_2d_integrals and D = M_p M_q - F, returns T_m = 1/2 sum c^{kk}_ab C(m,c) D[a+c][b+m-c], the amount
+// that order m loses from mode k to mode k+1 (lost altogether for k = N-1).  Zero unless the mode carries a threshold
+// or one of its moments is below 2^-26 (the only way M_p M_q < eps can fire, Coalescence.jl:213).
+// `has_pass`: whether this mode runs a Simpson pass (FIXED: finite threshold; MOVING: every mode but the last).
+template <int N, int P, int MODE>
+__device__ __forceinline__ bool mode_has_pass(const KArgs<N, P> &A, int k) {
+    if (MODE == MODE_FIXED) return k < N - 1 && A.finite[k];
+    if (MODE == MODE_MOVING) return k < N - 1;
+    return false;
+}
+
+template <int N, int P, int MODE, bool FAST = false>
+__device__ __forceinline__ void promoted_mode(const KArgs<N, P> &A, const double *__restrict__ nodes, int k, double n,
+                                              double th, double kk, const double (&Mk)[P + 2], double &T0, double &T1,
+                                              double &T2) {
     constexpr int M = P + 2;
     constexpr int T = M * (M + 1) / 2;
-    double Mm[N][M];
+    T0 = T1 = T2 = 0.0;
+    bool thresholded = false;
+    double msh[T];
 #pragma unroll
-    for (int i = 0; i < N; ++i) moment_row<M>(A.dist_type[i], nn[i], th[i], kk[i], A.n_mom_max, Mm[i]);
+    for (int t = 0; t < T; ++t) msh[t] = 0.0;
+    if (MODE == MODE_FIXED) {
+        if (k < N - 1 && A.finite[k]) {  // wave-uniform
+            thresholded = true;
+            if (A.dist_type[k] == DIST_MONO) {
+                // moment_source_helper, ParticleDistributions.jl:557-564: n^2 theta^(p1+p2) if theta < x_t/2, else 0
+                const bool below = th < 0.5 * A.thr[k];
 #pragma unroll
-    for (int k = 0; k < N; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.0;
-
-    // ---- promoted part of the self collisions: moves T_m from mode k to mode k+1 (lost for k = N-1)
+                for (int p1 = 0; p1 < M; ++p1)
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-        bool thresholded = false;
-        double msh[T];
-#pragma unroll
-        for (int t = 0; t < T; ++t) msh[t] = 0.0;
-        if (MODE == MODE_FIXED) {
-            if (k < N - 1 && A.finite[k]) {  // wave-uniform
-                thresholded = true;
-                if (A.dist_type[k] == DIST_MONO) {
-                    // moment_source_helper, ParticleDistributions.jl:557-564: n^2 theta^(p1+p2) if theta < x_t/2, else 0
-                    const bool below = th[k] < 0.5 * A.thr[k];
-#pragma unroll
-                    for (int p1 = 0; p1 < M; ++p1)
-#pragma unroll
-                        for (int p2 = p1; p2 < M; ++p2) msh[tri<M>(p1, p2)] = below ? Mm[k][p1] * Mm[k][p2] : 0.0;
-                } else if (nn[k] > 0.0) {
-                    const FixedGrid grid{nodes + (size_t)A.node_off[k] * kNodeStride, A.n_bins[k]};
-                    if (FAST)
-                        msh_grid_f32<P>(grid, A.thr[k], nn[k], th[k], kk[k], A.dist_type[k] == DIST_GAMMA, Mm[k], msh);
-                    else
-                        msh_grid<P>(grid, A.thr[k], nn[k], th[k], kk[k], A.dist_type[k] == DIST_GAMMA, Mm[k], msh);
-                }
-            }
-        } else if (MODE == MODE_MOVING) {
-            if (k < N - 1) {
-                const bool is_gamma = A.dist_type[k] == DIST_GAMMA;
-                const double xt = moving_threshold(is_gamma, th[k], kk[k], A.thr[k]);
-                thresholded = !(xt == INFINITY);
-                if (thresholded && nn[k] > 0.0) {
-                    if (FAST)
-                        msh_grid_f32<P>(MovingGrid(xt, A.nbpl), xt, nn[k], th[k], kk[k], is_gamma, Mm[k], msh);
-                    else
-                        msh_grid<P>(MovingGrid(xt, A.nbpl), xt, nn[k], th[k], kk[k], is_gamma, Mm[k], msh);
-                }
+                    for (int p2 = p1; p2 < M; ++p2) msh[tri<M>(p1, p2)] = below ? Mk[p1] * Mk[p2] : 0.0;
+            } else if (n > 0.0) {
+                const FixedGrid grid{nodes + (size_t)A.node_off[k] * kNodeStride, A.n_bins[k]};
+                if (FAST)
+                    msh_grid_f32<P>(grid, A.thr[k], n, th, kk, A.dist_type[k] == DIST_GAMMA, Mk, msh);
+                else
+                    msh_grid<P>(grid, A.thr[k], n, th, kk, A.dist_type[k] == DIST_GAMMA, Mk, msh);
             }
         }
-        // without a threshold D is non-zero only where M_p M_q < eps: impossible when every moment >= 2^-26
-        double mn = Mm[k][0];
-#pragma unroll
-        for (int q = 1; q < M; ++q)
-            if (q < A.n_mom_max) mn = fmin(mn, Mm[k][q]);
-        const bool need = (nn[k] > 0.0) && (thresholded || mn < kSqrtEps);
-        if (need) {
-            double F[T], D[T];
-            finite_2d_and_promoted<P>(Mm[k], thresholded, msh, F, D);
-            double T0, T1, T2;
-            contract_promoted<P>(A.c[k][k], D, T0, T1, T2);
-            acc[k][0] -= T0;
-            acc[k][1] -= T1;
-            acc[k][2] -= T2;
-            if (k + 1 < N) {
-                acc[k + 1][0] += T0;
-                acc[k + 1][1] += T1;
-                acc[k + 1][2] += T2;
+    } else if (MODE == MODE_MOVING) {
+        if (k < N - 1) {
+            const bool is_gamma = A.dist_type[k] == DIST_GAMMA;
+            const double xt = moving_threshold(is_gamma, th, kk, A.thr[k]);
+            thresholded = !(xt == INFINITY);
+            if (thresholded && n > 0.0) {
+                if (FAST)
+                    msh_grid_f32<P>(MovingGrid(xt, A.nbpl), xt, n, th, kk, is_gamma, Mk, msh);
+                else
+                    msh_grid<P>(MovingGrid(xt, A.nbpl), xt, n, th, kk, is_gamma, Mk, msh);
             }
         }
     }
+    // without a threshold D is non-zero only where M_p M_q < eps: impossible when every moment >= 2^-26
+    double mn = Mk[0];
+#pragma unroll
+    for (int q = 1; q < M; ++q)
+        if (q < A.n_mom_max) mn = fmin(mn, Mk[q]);
+    const bool need = (n > 0.0) && (thresholded || mn < kSqrtEps);
+    if (need) {
+        double F[T], D[T];
+        finite_2d_and_promoted<P>(Mk, thresholded, msh, F, D);
+        contract_promoted<P>(A.c[k][k], D, T0, T1, T2);
+    }
+}
+
+// ---- pair terms: Q - R for j < k, -R for j > k, S_1(full products) - R for j == k, with the
+//      products common to Q and R (and to S_1 and R) cancelled analytically:
+//      Q_0 = R_0;  Q_1 = R_1 + sum v1_b Mk_b;  Q_2 = R_2 + 2 sum v1_b Mk_{b+1} + sum v2_b Mk_b
+//      with v_s[b] = sum_a c_ab Mj_{a+s}.   Adds to acc.
+template <int N, int P, bool SPEC>
+__device__ __forceinline__ void pair_terms(const KArgs<N, P> &A, const double (&Mm)[N][P + 2], double (&acc)[N][3]) {
 #ifndef CLOUDY_ABLATE_PAIR
-    // ---- pair terms: Q - R for j < k, -R for j > k, S_1(full products) - R for j == k, with the
-    //      products common to Q and R (and to S_1 and R) cancelled analytically:
-    //      Q_0 = R_0;  Q_1 = R_1 + sum v1_b Mk_b;  Q_2 = R_2 + 2 sum v1_b Mk_{b+1} + sum v2_b Mk_b
-    //      with v_s[b] = sum_a c_ab Mj_{a+s}.
 #pragma unroll
     for (int k = 0; k < N; ++k) {
 #pragma unroll
@@ -708,6 +705,34 @@ __device__ __forceinline__ void coal_ints_parcel(const KArgs<N, P> &A, const dou
     }
 
 #endif
+}
+
+// get_coal_ints for one parcel: acc[k][m], normalised units.
+template <int N, int P, int MODE, bool FAST = false, bool SPEC = false>
+__device__ __forceinline__ void coal_ints_parcel(const KArgs<N, P> &A, const double *__restrict__ nodes,
+                                                 const double (&nn)[N], const double (&th)[N], const double (&kk)[N],
+                                                 double (&acc)[N][3]) {
+    constexpr int M = P + 2;
+    double Mm[N][M];
+#pragma unroll
+    for (int i = 0; i < N; ++i) moment_row<M>(A.dist_type[i], nn[i], th[i], kk[i], A.n_mom_max, Mm[i]);
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.0;
+    // ---- promoted part of the self collisions: moves T_m from mode k to mode k+1 (lost for k = N-1)
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double T0, T1, T2;
+        promoted_mode<N, P, MODE, FAST>(A, nodes, k, nn[k], th[k], kk[k], Mm[k], T0, T1, T2);
+        acc[k][0] -= T0;
+        acc[k][1] -= T1;
+        acc[k][2] -= T2;
+        if (k + 1 < N) {
+            acc[k + 1][0] += T0;
+            acc[k + 1][1] += T1;
+            acc[k + 1][2] += T2;
+        }
+    }
+    pair_terms<N, P, SPEC>(A, Mm, acc);
 }
 
 // load one parcel (moments -> normalise -> invert, or parameters as given)

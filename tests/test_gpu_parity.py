@@ -106,12 +106,13 @@ def test_closed_forms_constant_and_golovin(gpu_cloudy, oracle):
 
 
 @pytest.mark.parametrize("name,n,tol", [("cfg2", 200_000, TOL_POLY), ("cfg3a", 200_000, TOL_POLY),
-                                        ("cfg3b", 20_000, TOL_QUAD)])
+                                        ("cfg3b", 20_000, TOL_QUAD), ("cfg4", 4_000, TOL_QUAD),
+                                        ("moving4", 4_000, TOL_QUAD)])
 def test_bench_workloads_vs_oracle(gpu_cloudy, oracle, name, n, tol):
     """The bench's synthetic Gamma-mixture batches (incl. ~1 % degenerate parcels) at oracle-sized n."""
     cloudy = gpu_cloudy
     wl = bench.make_workload(name, n, seed=99)
-    d = run_rhs(cloudy, wl["par"], wl["mom"])
+    d = run_rhs(cloudy, wl["par"], wl["mom"], cloudy.MovingThreshold() if wl["spec"].get("moving") else None)
     want, scale = oracle.rhs_coal_batch(bench.oracle_params(name), wl["mom"], with_scale=True)
     worst = assert_close_scaled(d, want, scale, tol, name)
     print(f"{name}: max |hip-oracle|/scale = {worst:.2e}")
@@ -987,7 +988,11 @@ def test_specialised_threshold_kernels_are_bit_identical(gpu_cloudy, oracle, nam
                                                             None))
         outs.append(o.to_numpy())
     ok = np.all(np.isfinite(outs[1]), axis=0)
-    assert ok.mean() > 0.5 and np.array_equal(outs[0][:, ok], outs[1][:, ok])  # (the explicit scheme blows up on some)
+    # (the explicit scheme blows up on some parcels.)  Same arithmetic, but -ffp-contract=fast may fuse multiply-adds
+    # differently in the two compilations of the stage loop: agreement to rounding, not bit for bit
+    assert ok.mean() > 0.5
+    ref = np.abs(outs[1][:, ok]).max(axis=1, keepdims=True)
+    assert np.all(np.abs(outs[0][:, ok] - outs[1][:, ok]) <= 1e-12 * ref)
 
 
 @pytest.mark.parametrize("N,P", [(1, 1), (1, 2), (2, 2), (3, 3), (4, 2), (2, 5), (4, 5)])
