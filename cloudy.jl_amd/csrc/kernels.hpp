@@ -192,6 +192,11 @@ struct FixedGrid {
     __device__ __forceinline__ double upow(int j, int q) const { return nd[kNodeStride * j + 5 + q]; }
     __device__ __forceinline__ int n_bins() const { return nb; }
     __device__ __forceinline__ double node_x(int j) const { return nd[kNodeStride * j]; }
+    // running-abscissa interface shared with MovingGrid (a table needs none)
+    __device__ __forceinline__ double first_x() const { return 0.0; }
+    __device__ __forceinline__ double next_x(double, int) const { return 0.0; }
+    __device__ __forceinline__ double node_x(int j, double) const { return nd[kNodeStride * j]; }
+    __device__ __forceinline__ SimpsonNode node(int j, double, bool late) const { return node(j, late); }
     __device__ __forceinline__ SimpsonNode node(int j, bool /*late*/) const {
         return SimpsonNode{nd[kNodeStride * j + 0], nd[kNodeStride * j + 1], nd[kNodeStride * j + 2],
                            nd[kNodeStride * j + 3], nd[kNodeStride * j + 4]};
@@ -199,7 +204,7 @@ struct FixedGrid {
 };
 // MovingThreshold: the threshold, hence the grid, is per parcel (computed with the reference's expressions).
 struct MovingGrid {
-    double xt, x_min, dx;
+    double xt, x_min, dx, ratio;
     int nb;
     static constexpr bool kHasPowers = false;
     __device__ __forceinline__ double upow(int, int) const { return 0.0; }
@@ -208,13 +213,22 @@ struct MovingGrid {
         nb = (int)floor(double(nbpl) * log10(xt_ / x_lb));
         x_min = log(x_lb);
         dx = (log(xt_) - x_min) / double(nb);
+        ratio = exp(dx);
     }
     __device__ __forceinline__ int n_bins() const { return nb; }
     __device__ __forceinline__ double node_x(int j) const { return exp(x_min + double(j) * dx); }
-    __device__ __forceinline__ SimpsonNode node(int j, bool late) const {
+    // The nodes are visited in order, so x_j = exp(x_min + j dx) (ParticleDistributions.jl:566) is carried along as
+    // x_{j-1} e^{dx} and re-anchored with a true exp() every 16th node: at most 15 roundings of drift (< 2e-15), one
+    // multiplication instead of ~31 instructions for the others.
+    __device__ __forceinline__ double first_x() const { return exp(x_min); }
+    __device__ __forceinline__ double next_x(double x_run, int j_next) const {
+        return (j_next & 15) == 0 ? exp(x_min + double(j_next) * dx) : x_run * ratio;
+    }
+    __device__ __forceinline__ double node_x(int, double x_run) const { return x_run; }
+    __device__ __forceinline__ SimpsonNode node(int j, double x_run, bool late) const {
         SimpsonNode s;
         s.lx = x_min + double(j) * dx;  // logx(x_min, j+1, dx)
-        s.x = exp(s.lx);
+        s.x = x_run;
         s.xmx = xt - s.x;
         s.lxmx = late ? log(s.xmx) : 0.0;
         s.wdx = simpson_weight(j + 1, nb) * dx;
@@ -260,6 +274,7 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double n, 
     //   b_n = c_n z0^n:  b_{n+1} = ((z0 - a + 1 + n) b_n - z0 b_{n-1}) / (n + 1)
     const double x_early = fmin(th, 0.2 * xt / fmax(a_top - 1.0, 2.0));
     int j = 0;
+    double xr = grid.first_x();  // running abscissa (MovingGrid); a table (FixedGrid) ignores it
 #ifndef CLOUDY_NO_EARLY_NODES
     {
         double U[NS];
@@ -268,8 +283,9 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double n, 
         const double inv_xt = 1.0 / xt;
 #pragma unroll 1
         for (; j < nb; ++j) {
-            if (!(grid.node_x(j) <= x_early)) break;
-            const SimpsonNode nd = grid.node(j, false);
+            if (!(grid.node_x(j, xr) <= x_early)) break;
+            const SimpsonNode nd = grid.node(j, xr, false);
+            xr = grid.next_x(xr, j + 1);
             const double t = nd.x * inv_th;
             double e = nd.wdx * exp(fma(k, nd.lx - lnth, -t));
             if (Grid::kHasPowers) {
@@ -328,7 +344,8 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double n, 
 #endif
 #pragma unroll 1
     for (; j < nb; ++j) {
-        const SimpsonNode nd = grid.node(j, true);
+        const SimpsonNode nd = grid.node(j, xr, true);
+        xr = grid.next_x(xr, j + 1);
         const double t = nd.x * inv_th, zr = nd.xmx * inv_th;
         const bool zpos = zr > 0.0;  // P(a, z <= 0) = 0: such a node (never on the reference grid) contributes nothing
         const double z = zpos ? zr : 1.0;
@@ -383,6 +400,7 @@ __device__ __forceinline__ void msh_grid_f32(const Grid &grid, double xt, double
     for (int t = 0; t < T; ++t) acc[t] = 0.0f;
     const double x_early = fmin(2.0 * th, 0.4 * xt / fmax(a_top - 1.0, 2.0));
     int j = 0;
+    double xr = grid.first_x();
     {
         // power sums in u = x / x_t (<= 1: no single-precision range problems even for theta ~ 1e15 of clamped
         // closures); the expansion is then in b_n = c_n z0^n:  b_{n+1} = ((z0 - a + 1 + n) b_n - z0 b_{n-1}) / (n+1),
@@ -393,8 +411,9 @@ __device__ __forceinline__ void msh_grid_f32(const Grid &grid, double xt, double
         const double inv_xt = 1.0 / xt;
 #pragma unroll 1
         for (; j < nb; ++j) {
-            if (!(grid.node_x(j) <= x_early)) break;
-            const SimpsonNode nd = grid.node(j, false);
+            if (!(grid.node_x(j, xr) <= x_early)) break;
+            const SimpsonNode nd = grid.node(j, xr, false);
+            xr = grid.next_x(xr, j + 1);
             const double td = nd.x * inv_th;
             const float u = (float)(nd.x * inv_xt);
             float e = (float)nd.wdx * __expf((float)fma(k, nd.lx - lnth, -td));
@@ -440,7 +459,8 @@ __device__ __forceinline__ void msh_grid_f32(const Grid &grid, double xt, double
     }
 #pragma unroll 1
     for (; j < nb; ++j) {
-        const SimpsonNode nd = grid.node(j, true);
+        const SimpsonNode nd = grid.node(j, xr, true);
+        xr = grid.next_x(xr, j + 1);
         const double td = nd.x * inv_th, zd = nd.xmx * inv_th;
         if (!(zd > 0.0)) continue;
         const float z = (float)zd, xf = (float)nd.x;
