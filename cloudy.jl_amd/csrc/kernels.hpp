@@ -553,13 +553,16 @@ __device__ __forceinline__ void contract_promoted(const double (&ckk)[P][P], con
 // quality of the resulting waves).  Invalid / empty parcels (valid = false) rank last.  The order inside a bucket is
 // whatever order the atomics were served in: any permutation gives the same results, parcels are independent.
 // sh_cnt: kBlock counters; returns through sh_perm the lane -> slot map: slot `rank` is processed by lane sh_perm[rank].
-__device__ __forceinline__ void regime_rank(bool valid, float key, unsigned int *sh_cnt, unsigned short *sh_perm) {
+// `bucket_if_valid` in [0, 254]: regime_bucket(key).
+__device__ __forceinline__ int regime_bucket(float key) {
+    const int code = (int)(__float_as_uint(fmaxf(key, 0.0f)) >> 20) - (127 - 8) * 8;
+    return code < 0 ? 0 : (code > kBlock - 2 ? kBlock - 2 : code);
+}
+
+__device__ __forceinline__ void regime_rank(bool valid, int bucket_if_valid, unsigned int *sh_cnt,
+                                            unsigned short *sh_perm) {
     const int t = threadIdx.x;
-    int bucket = kBlock - 1;
-    if (valid) {
-        const int code = (int)(__float_as_uint(fmaxf(key, 0.0f)) >> 20) - (127 - 8) * 8;
-        bucket = code < 0 ? 0 : (code > kBlock - 2 ? kBlock - 2 : code);
-    }
+    const int bucket = valid ? bucket_if_valid : kBlock - 1;
     sh_cnt[t] = 0u;
     __syncthreads();
     const unsigned int pos = atomicAdd(&sh_cnt[bucket], 1u);
@@ -928,7 +931,7 @@ __device__ __forceinline__ void ssprk33_body(const KArgs<N, P> *__restrict__ Ag,
             valid = nf > 0.0 && r == r;
             rkey = r;
         }
-        regime_rank(valid, rkey, sh_cnt, sh_perm);
+        regime_rank(valid, regime_bucket(rkey), sh_cnt, sh_perm);
         i = (size_t)blockIdx.x * kBlock + sh_perm[t];
     }
     if (i >= n) return;
@@ -1188,7 +1191,7 @@ __global__ void __launch_bounds__(kBlock)
                 rkey = r;
             }
         }
-        regime_rank(valid, rkey, sh_cnt, sh_perm);
+        regime_rank(valid, regime_bucket(rkey), sh_cnt, sh_perm);
         // The per-stage barrier makes a workgroup as slow as its most expensive wave.  Odd workgroups hand the sorted
         // cells to their waves in reverse order, so that a SIMD holding waves of two workgroups does not get the two
         // expensive ends.
