@@ -293,6 +293,7 @@ def main():
     ap.add_argument("--no-variants", action="store_true")
     args = ap.parse_args()
 
+    t_start = time.perf_counter()
     rank, world, local_rank, dist, torch = _dist_setup(args.gpus)
     import __graft_entry__ as ge
 
@@ -304,6 +305,7 @@ def main():
     spec = workload_spec(args.workload)
     n_local = args.parcels or spec["default_parcels"]
     res = _run_workload(pkg, args.workload, n_local, args.steps, args.warmup, rank, dist, torch)
+    t_headline = time.perf_counter()
     nmom = res["nmom"]
     bytes_per_eval = 2 * nmom * 8  # read nmom moments + write nmom tendencies, fp64
     total = n_local * world
@@ -499,6 +501,7 @@ def main():
         }
         del ur, outr
 
+    t_variants = time.perf_counter()
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = _cpu_baseline(args.workload)
@@ -533,6 +536,11 @@ def main():
             "mass_rate_residual": abs(res["mass_rate_sum"]) / max(res["mass_rate_gross"], 1e-300),
             "mass_residual_per_parcel_max": res["mass_per_parcel"],
             "variants": variants,
+            # where this process spent its wall time: the timed region is steps x ms_per_step; the rest is set-up
+            # (imports, synthetic data, plan creation incl. ~1 s of hiprtc, warm-up, diagnostics), the other
+            # workloads under "variants", and the CPU baseline
+            "process_wall_s": {"setup_and_headline": t_headline - t_start, "timed_region": res["wall"],
+                               "variants": t_variants - t_headline, "cpu_baseline": time.perf_counter() - t_variants},
         }
         print(json.dumps(out))
     if dist is not None:
