@@ -1018,3 +1018,19 @@ def test_specialised_kernels_across_families(gpu_cloudy, oracle, N, P):
     assert spec.specialized and fin.mean() > 0.95 and np.array_equal(a[:, fin], b[:, fin])
     want, scale = oracle.rhs_coal_batch(op, mom, with_scale=True)
     assert_close_scaled(a, want, scale, TOL_POLY, f"specialised N={N} P={P}")
+
+
+def test_code_object_cache_on_disk(gpu_cloudy, tmp_path, monkeypatch):
+    """Compiled plan kernels are kept between processes (CLOUDY_HIP_CACHE_DIR): a new plan writes its code object
+    there, and an empty value switches the cache off."""
+    cloudy = gpu_cloudy
+    d = tmp_path / "cc"
+    monkeypatch.setenv("CLOUDY_HIP_CACHE_DIR", str(d))
+    kc = [[0.0, 3.25], [3.25, 0.0]]                      # constants no other test uses: not yet in the process cache
+    plan = cloudy.Plan([1], kc, (INF,), (1e6, 1e-9), 0, specialize=1)
+    files = list(d.glob("*.co"))
+    assert plan.specialized and len(files) == 1 and files[0].stat().st_size > 1000
+    assert files[0].read_bytes()[:4] == b"\x7fELF"
+    monkeypatch.setenv("CLOUDY_HIP_CACHE_DIR", "")
+    plan2 = cloudy.Plan([1], [[0.0, 3.5], [3.5, 0.0]], (INF,), (1e6, 1e-9), 0, specialize=1)
+    assert plan2.specialized and len(list(d.glob("*.co"))) == 1
