@@ -8,6 +8,7 @@ known-answer values, and closed forms.  Tolerances (stated here, from BASELINE.j
 `scale` is the sum of |Q|, |R|, |S| terms of an output as reported by the oracle: a tendency is a small difference
 of large terms (e.g. the net mass tendency of a mode), so rounding is measured against the terms."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -15,6 +16,8 @@ import pytest
 import bench
 
 pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 EPS = float(np.finfo(np.float64).eps)
 INF = float("inf")
@@ -1034,3 +1037,18 @@ def test_code_object_cache_on_disk(gpu_cloudy, tmp_path, monkeypatch):
     monkeypatch.setenv("CLOUDY_HIP_CACHE_DIR", "")
     plan2 = cloudy.Plan([1], [[0.0, 3.5], [3.5, 0.0]], (INF,), (1e6, 1e-9), 0, specialize=1)
     assert plan2.specialized and len(list(d.glob("*.co"))) == 1
+
+
+def test_more_than_2_to_32_elements_per_array(gpu_cloudy):
+    """Sizing for 288 GB: 8e8 parcels x 6 planes = 4.8e9 elements per array (38 GB in, 38 GB out) in one launch; the
+    batch repeats a 2^20-parcel tile, so every tile of the output must equal the first (tools/big_batch_check.py)."""
+    import subprocess
+    import sys
+
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "big_batch_check.py"), "800000000"],
+                       capture_output=True, text=True, timeout=600)
+    if p.returncode != 0 and ("-4" in p.stderr or "out of memory" in p.stderr.lower()):
+        pytest.skip("not enough free device memory for the 77 GB check")
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "mismatching tiles: 0" in p.stdout
+    print(p.stdout.strip())
