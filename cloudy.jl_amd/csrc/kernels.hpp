@@ -590,7 +590,7 @@ __device__ __forceinline__ void regime_rank(bool valid, int bucket_if_valid, uns
 }
 
 // Plan-time specialisation (jit.hpp): when the plan constants are compile-time values (SPEC), terms whose tensor
-// coefficient is exactly zero are dropped -- fma(0, M, v) == v for finite M, so results are bit-identical -- and the
+// coefficient is exactly zero are dropped -- fma(0, M, v) == v for finite M, the arithmetic is unchanged -- and the
 // remaining coefficients become literals.  In the ahead-of-time kernels (SPEC = false) the test is constant-true.
 template <bool SPEC>
 __device__ __forceinline__ constexpr bool nzc(double c) {

@@ -124,7 +124,8 @@ void cloudy_plan_desc_init(cloudy_plan_desc *desc);
 int cloudy_plan_create(const cloudy_plan_desc *desc, cloudy_plan **out);
 void cloudy_plan_destroy(cloudy_plan *plan);
 /* 1 if cloudy_coal_rhs / cloudy_ssprk33_steps of this plan run kernels compiled for it at plan creation, else 0 with
- * the reason (or the compiler log) in cloudy_plan_jit_log.  Either way the results are the same bits. */
+ * the reason (or the compiler log) in cloudy_plan_jit_log.  Either way the arithmetic is the same (results agree to
+ * rounding, bit for bit in most configurations). */
 int cloudy_plan_specialized(const cloudy_plan *plan);
 const char *cloudy_plan_jit_log(const cloudy_plan *plan);
 /* Build check without a GPU: validates `desc`, generates the plan's specialised translation unit(s) and compiles them

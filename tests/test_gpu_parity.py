@@ -1052,3 +1052,19 @@ def test_more_than_2_to_32_elements_per_array(gpu_cloudy):
     assert p.returncode == 0, p.stdout + p.stderr
     assert "mismatching tiles: 0" in p.stdout
     print(p.stdout.strip())
+
+
+@pytest.mark.parametrize("seed", [7, 11])
+def test_randomised_plan_sweep(gpu_cloudy, oracle, seed):
+    """tools/fuzz_parity.py: random plans (N, P, closure families, fixed / moving thresholds, sparse symmetric tensors,
+    plane types) -- plan-time compiled and ahead-of-time kernels against the oracle and against each other."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_parity as F
+
+    rng = np.random.default_rng(seed)
+    for c in range(10):
+        cfg = F.random_config(rng)
+        worst, dj = F.check_config(gpu_cloudy, cfg, 300, 5000 + 100 * seed + c)
+        assert dj <= 1e-6

@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on the GPU: random plans (N, P, closure families, fixed / moving thresholds, sparse symmetric
+tensors, plane types) -- HIP (plan-time compiled and ahead-of-time kernels) against the CPU oracle on small batches.
+usage: python tools/fuzz_parity.py [--configs 40] [--seed 1] [--parcels 400]"""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import bench
+from __graft_entry__ import load_package
+from oracle import cloudy_oracle as O
+
+INF = float("inf")
+
+
+def random_config(rng):
+    N = int(rng.integers(1, 5))
+    P = int(rng.integers(1, 6))
+    moving = bool(rng.random() < 0.25) and N > 1
+    dist = []
+    for i in range(N):
+        allowed = [0, 1] if moving and i < N - 1 else [0, 1, 1, 1, 2, 3]
+        dist.append(int(rng.choice(allowed)))
+    if moving:
+        thr = tuple(float(rng.choice([0.5, 0.9, 0.97, 0.99])) for _ in range(N - 1)) + (1.0,)
+    else:
+        thr = []
+        for i in range(N):
+            finite = i < N - 1 and dist[i] != 3 and rng.random() < 0.6
+            thr.append(float(10.0 ** rng.uniform(-11.0, -6.5)) if finite else INF)
+        thr = tuple(thr)
+    kc = np.zeros((N, N, P, P))
+    for j in range(N):
+        for k in range(j, N):
+            c = rng.uniform(0.1, 1.0, (P, P)) * (rng.random((P, P)) < 0.5)
+            c = np.triu(c) + np.triu(c, 1).T
+            kc[j, k] = kc[k, j] = c * 1e-3 * (1e9 ** np.add.outer(np.arange(P), np.arange(P)))
+    dtype = int(rng.choice([0, 0, 0, 1]))
+    return dict(N=N, P=P, moving=moving, dist=dist, thr=thr, kc=kc, dtype=dtype)
+
+
+def moments_for(dist, n, seed):
+    full = bench.synth_moments(len(dist), n, seed)
+    rows = []
+    for i, t in enumerate(dist):
+        rows += [full[3 * i], full[3 * i + 1]] + ([full[3 * i + 2]] if t in (1, 3) else [])
+    return np.ascontiguousarray(np.stack(rows))
+
+
+def run(pkg, plan, mom, tio):
+    m = pkg.DeviceArray.from_numpy(mom.astype(tio))
+    dm = pkg.DeviceArray.zeros(mom.shape[0], mom.shape[1], tio)
+    pkg._lib.check(pkg.lib().cloudy_coal_rhs(plan.handle, mom.shape[1], mom.shape[1], m.ptr, dm.ptr, None))
+    return dm.to_numpy().astype(np.float64)
+
+
+def check_config(pkg, cfg, n, seed):
+    """-> (worst |hip - oracle| / scale, worst |jit - aot| / scale); raises AssertionError on a parity failure"""
+    N = cfg["N"]
+    kernels = tuple(tuple(pkg.CoalescenceTensor(cfg["kc"][j, k]) for k in range(N)) for j in range(N))
+    npm = tuple({0: 2, 1: 3, 2: 2, 3: 3}[t] for t in cfg["dist"])
+    ts = pkg.MovingThreshold() if cfg["moving"] else pkg.FixedThreshold()
+    cd = pkg.CoalescenceData(kernels, npm, cfg["thr"], bench.NORMS, ts)
+    op = O.make_params(cfg["dist"], cfg["kc"], cfg["thr"], norms=bench.NORMS,
+                       threshold_style=O.MOVING_THRESHOLD if cfg["moving"] else O.FIXED_THRESHOLD)
+    mom = moments_for(cfg["dist"], n, seed)
+    tio = np.float64 if cfg["dtype"] == 0 else np.float32
+    mom_in = mom.astype(tio).astype(np.float64)
+    jit = cd.plan(cfg["dist"], dtype=cfg["dtype"], specialize=1)
+    aot = cd.plan(cfg["dist"], dtype=cfg["dtype"], specialize=-1)
+    a, b = run(pkg, jit, mom_in, tio), run(pkg, aot, mom_in, tio)
+    want, scale = O.rhs_coal_batch(op, mom_in, with_scale=True)
+    with np.errstate(over="ignore"):
+        fin = np.isfinite(want) & np.isfinite(want.astype(tio))
+    quad = cfg["moving"] or any(np.isfinite(cfg["thr"]))
+    tol = 1e-8 if quad else 1e-12
+    if cfg["dtype"] == 0:
+        bound = tol * scale
+    else:
+        bound = 6.0e-8 * np.abs(want) + tol * scale + 1.5e-45
+    with np.errstate(invalid="ignore"):
+        err = np.abs(a - want)
+    # (float planes: where the allowed error exceeds FLT_MAX -- clamped closures with terms of 1e90 that cancel --
+    # the rounding residual of the fp64 arithmetic overflows the float output; any value is within tolerance there)
+    bad = fin & ~(err <= bound) & (bound < 3.0e38)
+    err = np.where(bound < 3.0e38, err, 0.0)
+    assert not bad.any(), f"{bad.sum()} entries beyond tolerance, worst {np.max(err[fin] / np.maximum(scale[fin], 1e-300)):.3e}"
+    # plan-time compiled vs ahead-of-time kernels: same arithmetic; -ffp-contract=fast may fuse a multiply-add differently
+    # in the two compilations, so agreement is to rounding (bit-identical in most families)
+    both = np.isfinite(a) & np.isfinite(b)
+    dj = float(np.max(np.abs(a - b)[both] / np.maximum(scale[both], 1e-300))) if both.any() else 0.0
+    assert dj <= (1e-14 if cfg["dtype"] == 0 else 1e-6), f"plan-time compiled and ahead-of-time kernels differ by {dj:.2e} of scale"
+    worst = float(np.max(err[fin] / np.maximum(scale[fin], 1e-300))) if fin.any() else 0.0
+    return worst, dj
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--parcels", type=int, default=400)
+    a = ap.parse_args()
+    pkg = load_package()
+    rng = np.random.default_rng(a.seed)
+    t0 = time.time()
+    fails = 0
+    for c in range(a.configs):
+        cfg = random_config(rng)
+        tag = (f"#{c} N={cfg['N']} P={cfg['P']} dist={cfg['dist']} {'moving' if cfg['moving'] else 'fixed'} "
+               f"thr={tuple(f'{t:.2g}' for t in cfg['thr'])} dtype={cfg['dtype']}")
+        try:
+            worst, dj = check_config(pkg, cfg, a.parcels, 1000 + c)
+            print(f"ok   {tag}: max |hip-oracle|/scale {worst:.2e}, |jit-aot|/scale {dj:.1e}")
+        except AssertionError as e:
+            fails += 1
+            print(f"FAIL {tag}: {e}")
+    print(f"{a.configs} configurations, {fails} failures, {time.time() - t0:.0f} s")
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
