@@ -1,10 +1,11 @@
 // kernels.hpp -- gfx950 kernels for the batched collision-coalescence moment tendency.
 //
-// One wavefront lane owns one parcel.  State is moment-major SoA (plane q at base + q*ld), so a
-// wave's load of one moment is one contiguous 512-byte request.  All parcel-independent constants
-// (normalised kernel tensors, norms, thresholds, Simpson nodes) are wave-uniform: they arrive as
-// kernel arguments / uniform-address loads and live in SGPRs, the CDNA home for broadcast data
-// (no LDS traffic, no per-lane registers).
+// One wavefront lane owns one parcel (two in the all-Inf kernel).  State is moment-major SoA (plane q at
+// base + q*ld), so a wave's load of one moment is one contiguous 512-byte (1-KiB) request.  All parcel-independent
+// constants (normalised kernel tensors, norms, thresholds, Simpson nodes) are wave-uniform: compile-time constants
+// when the kernel is compiled for its plan (jit.hpp), otherwise kernel arguments / uniform-address loads that live
+// in SGPRs, the CDNA home for broadcast data (no LDS traffic, no per-lane registers).  LDS carries what crosses
+// lanes: the regime ranking and parcel exchange of the threshold kernels, the flux exchange of the rainshaft column.
 //
 // The per-parcel chain fused here (reference file:line, CliMA/Cloudy.jl v0.6.0):
 //   normalise            test/examples/utils/box_model_helpers.jl:30-31
@@ -842,10 +843,10 @@ __global__ void __launch_bounds__(kBlock)
 
 // Threshold modes (FIXED / MOVING): the cost of a parcel is dominated by the incomplete-gamma evaluations of its
 // Simpson nodes, and which algorithm a node takes (power series for z <= a+1, continued fraction above; P == 1
-// far above) is decided by r = (x_t/theta) / (a_top + 1) of the parcel.  Lanes of one wave execute every branch
-// any of them takes, so the 256 parcels of a workgroup are first ranked by r (counting sort in LDS) and each
-// lane then processes the parcel of its rank: waves become regime-homogeneous.  Parcels stay inside their
-// workgroup's 256-parcel window (2 KB per plane), so stores remain line-coalesced.
+// far above) is decided by r = (x_t/theta) / (a_top + 1) of the parcel and mode.  Lanes of one wave execute every
+// branch any of them takes, so for each thresholded mode the 256 parcels of a workgroup are ranked by that mode's r
+// (regime_rank) and each lane integrates the mode of the parcel of its rank: waves become regime-homogeneous.  The
+// three phases are described in coal_rhs_sorted_body.inc.
 template <int N, int P, int MODE, typename TIO, bool FAST = false, bool SPEC = false>
 __device__ __forceinline__ void coal_rhs_sorted_body(const KArgs<N, P> &A, const double *__restrict__ nodes, size_t n,
                                                      size_t ld, const TIO *__restrict__ in, TIO *__restrict__ out) {

@@ -4,7 +4,7 @@
 // out of them into registers for the life of the kernel -- 256 VGPRs, occupancy 1 and spills, against 108-170 VGPRs
 // without (measured on MI355X: cloudy_ssprk33_steps on the cfg3b batch 1.12 -> 0.53 ms per RHS evaluation per 1e6
 // parcels, the rainshaft column integrator 1.53 -> 0.78).  The single-pass kernels of inst_n<N>_p<P>.hip keep LICM:
-// their Simpson node loops gain from the hoisting (cfg3b 4.85 ms with, 4.96 ms without).
+// their Simpson node loops gain from the hoisting (cfg3b, at the time: 4.85 ms with, 4.96 ms without).
 #pragma once
 #include "launch_impl.hpp"
 
