@@ -13,7 +13,7 @@ from oracle import cloudy_oracle as O
 INF = float("inf")
 
 
-def random_config(rng):
+def random_config(rng, wild=False):
     N = int(rng.integers(1, 5))
     P = int(rng.integers(1, 6))
     moving = bool(rng.random() < 0.25) and N > 1
@@ -36,7 +36,12 @@ def random_config(rng):
             c = np.triu(c) + np.triu(c, 1).T
             kc[j, k] = kc[k, j] = c * 1e-3 * (1e9 ** np.add.outer(np.arange(P), np.arange(P)))
     dtype = int(rng.choice([0, 0, 0, 1]))
-    return dict(N=N, P=P, moving=moving, dist=dist, thr=thr, kc=kc, dtype=dtype)
+    norms, k_range = bench.NORMS, (float(np.finfo(np.float64).eps), 10.0)
+    if wild:  # other unit systems and clamp ranges: the eps rules, the Simpson grids (x_t / m0) and the k clamp move
+        norms = (float(10.0 ** rng.uniform(3, 9)), float(10.0 ** rng.uniform(-12, -7)))
+        k_range = (float(rng.choice([np.finfo(np.float64).eps, 1e-3, 0.1])), float(rng.choice([5.0, 10.0, 25.0])))
+        dtype = 0
+    return dict(N=N, P=P, moving=moving, dist=dist, thr=thr, kc=kc, dtype=dtype, norms=norms, k_range=k_range)
 
 
 def moments_for(dist, n, seed):
@@ -60,14 +65,15 @@ def check_config(pkg, cfg, n, seed):
     kernels = tuple(tuple(pkg.CoalescenceTensor(cfg["kc"][j, k]) for k in range(N)) for j in range(N))
     npm = tuple({0: 2, 1: 3, 2: 2, 3: 3}[t] for t in cfg["dist"])
     ts = pkg.MovingThreshold() if cfg["moving"] else pkg.FixedThreshold()
-    cd = pkg.CoalescenceData(kernels, npm, cfg["thr"], bench.NORMS, ts)
-    op = O.make_params(cfg["dist"], cfg["kc"], cfg["thr"], norms=bench.NORMS,
+    norms, k_range = cfg.get("norms", bench.NORMS), cfg.get("k_range", (float(np.finfo(np.float64).eps), 10.0))
+    cd = pkg.CoalescenceData(kernels, npm, cfg["thr"], norms, ts)
+    op = O.make_params(cfg["dist"], cfg["kc"], cfg["thr"], norms=norms, k_range=k_range,
                        threshold_style=O.MOVING_THRESHOLD if cfg["moving"] else O.FIXED_THRESHOLD)
     mom = moments_for(cfg["dist"], n, seed)
     tio = np.float64 if cfg["dtype"] == 0 else np.float32
     mom_in = mom.astype(tio).astype(np.float64)
-    jit = cd.plan(cfg["dist"], dtype=cfg["dtype"], specialize=1)
-    aot = cd.plan(cfg["dist"], dtype=cfg["dtype"], specialize=-1)
+    jit = cd.plan(cfg["dist"], k_range=k_range, dtype=cfg["dtype"], specialize=1)
+    aot = cd.plan(cfg["dist"], k_range=k_range, dtype=cfg["dtype"], specialize=-1)
     a, b = run(pkg, jit, mom_in, tio), run(pkg, aot, mom_in, tio)
     want, scale = O.rhs_coal_batch(op, mom_in, with_scale=True)
     with np.errstate(over="ignore"):
@@ -99,15 +105,17 @@ def main():
     ap.add_argument("--configs", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--parcels", type=int, default=400)
+    ap.add_argument("--wild", action="store_true", help="also randomise norms and the k clamp range")
     a = ap.parse_args()
     pkg = load_package()
     rng = np.random.default_rng(a.seed)
     t0 = time.time()
     fails = 0
     for c in range(a.configs):
-        cfg = random_config(rng)
+        cfg = random_config(rng, a.wild)
         tag = (f"#{c} N={cfg['N']} P={cfg['P']} dist={cfg['dist']} {'moving' if cfg['moving'] else 'fixed'} "
-               f"thr={tuple(f'{t:.2g}' for t in cfg['thr'])} dtype={cfg['dtype']}")
+               f"thr={tuple(f'{t:.2g}' for t in cfg['thr'])} dtype={cfg['dtype']}"
+               + (f" norms=({cfg['norms'][0]:.1e},{cfg['norms'][1]:.1e}) k_range={cfg['k_range']}" if a.wild else ""))
         try:
             worst, dj = check_config(pkg, cfg, a.parcels, 1000 + c)
             print(f"ok   {tag}: max |hip-oracle|/scale {worst:.2e}, |jit-aot|/scale {dj:.1e}")
