@@ -97,7 +97,48 @@ def check_config(pkg, cfg, n, seed):
     dj = float(np.max(np.abs(a - b)[both] / np.maximum(scale[both], 1e-300))) if both.any() else 0.0
     assert dj <= (1e-14 if cfg["dtype"] == 0 else 1e-6), f"plan-time compiled and ahead-of-time kernels differ by {dj:.2e} of scale"
     worst = float(np.max(err[fin] / np.maximum(scale[fin], 1e-300))) if fin.any() else 0.0
+    if cfg["dtype"] == 0:
+        check_callers(pkg, cfg, cd, op, mom_in, jit, k_range, scale)
     return worst, dj
+
+
+def check_callers(pkg, cfg, cd, op, mom, plan, k_range, scale):
+    """the callers either side of the operator on the same random plan (fp64 planes): closure inversion bit for bit,
+    sedimentation flux, condensation, the rainshaft cell body"""
+    m = pkg.DeviceArray.from_numpy(mom)
+    # (n, theta, k): bit-equal to the oracle
+    got = pkg.update_dist_from_moments(plan, m).to_numpy()
+    want = O.update_dist_batch(op, mom)
+    N = cfg["N"]
+    for i, t in enumerate(cfg["dist"]):
+        rows = [3 * i, 3 * i + 1] + ([3 * i + 2] if t in (1, 3) else [])
+        g, w = got[rows], want[rows]
+        ok = np.isfinite(w)
+        if t == 3:  # Lognormal: log / sqrt of the device and the host library differ in the last place, and
+            # sigma^2 = log(M0 M2 / M1^2) is ill-conditioned for narrow distributions: compare where sigma > 0.05
+            wide = ok & (w[2] > 0.05)[None, :]
+            assert np.allclose(g[wide], w[wide], rtol=1e-11, atol=1e-300), f"update_dist_from_moments (Lognormal) mode {i}"
+        else:
+            assert np.array_equal(g[ok], w[ok]), f"update_dist_from_moments differs for mode {i}"
+    # sedimentation flux and the rainshaft cell body (FixedThreshold only, as in the reference)
+    vel = ((50.0, 1.0 / 6), (3.0, 0.0))  # same sign: no cancellation between the two terms
+    opv = O.make_params(cfg["dist"], cfg["kc"], cfg["thr"], norms=cfg.get("norms", bench.NORMS), k_range=k_range,
+                        threshold_style=O.MOVING_THRESHOLD if cfg["moving"] else O.FIXED_THRESHOLD, vel=vel)
+    pv = cd.plan(cfg["dist"], k_range=k_range, vel=vel)
+    if not cfg["moving"]:
+        cs, sf = pkg.rainshaft_sources(pv, m)
+        wcs, wsf = O.rainshaft_cell_batch(opv, mom)
+        okf = np.isfinite(wsf)
+        assert np.allclose(sf.to_numpy()[okf], wsf[okf], rtol=1e-10, atol=0), "sedimentation flux"
+        okc = np.isfinite(wcs)
+        tol = 1e-8 if any(np.isfinite(cfg["thr"])) else 1e-12
+        assert np.all(np.abs(cs.to_numpy() - wcs)[okc] <= tol * np.maximum(scale[okc], 1e-300)), "rainshaft coalescence source"
+    # condensation
+    dm = pkg.DeviceArray.zeros(*mom.shape)
+    pkg.rhs_condensation(plan, dm, m, 1e-8, 0.03)
+    wc = O.rhs_condensation_batch(op, 1e-8, 0.03, mom)
+    okc = np.isfinite(wc)
+    assert np.allclose(dm.to_numpy()[okc], wc[okc], rtol=1e-10, atol=0), "rhs_condensation"
 
 
 def main():
