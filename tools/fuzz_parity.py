@@ -133,6 +133,29 @@ def check_callers(pkg, cfg, cd, op, mom, plan, k_range, scale):
         okc = np.isfinite(wcs)
         tol = 1e-8 if any(np.isfinite(cfg["thr"])) else 1e-12
         assert np.all(np.abs(cs.to_numpy() - wcs)[okc] <= tol * np.maximum(scale[okc], 1e-300)), "rainshaft coalescence source"
+    # fused SSPRK33 (2 steps) against the oracle stepped by numpy, on the parcels whose tendencies are finite
+    f0 = O.rhs_coal_batch(op, mom)
+    reg = np.flatnonzero(np.all(np.isfinite(f0), axis=0) & np.all(mom > 0.0, axis=0))[:128]
+    if reg.size >= 8:
+        u0 = np.ascontiguousarray(mom[:, reg])
+        with np.errstate(divide="ignore", invalid="ignore"):
+            dt = 1e-3 * float(np.nanmin(np.where(f0[:, reg] != 0.0, np.abs(u0 / f0[:, reg]), np.inf)))
+        if np.isfinite(dt) and dt > 0.0:
+            u = u0.copy()
+            for _ in range(2):  # OrdinaryDiffEq SSPRK33
+                up = u
+                u = up + dt * O.rhs_coal_batch(op, up)
+                u = (3.0 * up + u + dt * O.rhs_coal_batch(op, u)) / 4.0
+                u = (up + 2.0 * u + 2.0 * dt * O.rhs_coal_batch(op, u)) / 3.0
+            d_in, d_out = pkg.DeviceArray.from_numpy(u0), pkg.DeviceArray.zeros(*u0.shape)
+            pkg._lib.check(pkg.lib().cloudy_ssprk33_steps(plan.handle, u0.shape[1], u0.shape[1], d_in.ptr, d_out.ptr, dt, 2,
+                                                          None))
+            got = d_out.to_numpy()
+            # (the explicit scheme blows up on some parcels -- one huge rate dominates the step size of the rest of the
+            # state -- and what a blown-up state cancels to is not a parity question)
+            okp = np.all(np.isfinite(u), axis=0) & np.all(u > 0.0, axis=0) & np.all(np.abs(u) < 10.0 * np.abs(u0), axis=0)
+            ref = np.abs(u[:, okp]).max(axis=1, keepdims=True) + 1e-300
+            assert np.all(np.abs(got[:, okp] - u[:, okp]) <= 1e-9 * ref), "cloudy_ssprk33_steps vs oracle stepping"
     # condensation
     dm = pkg.DeviceArray.zeros(*mom.shape)
     pkg.rhs_condensation(plan, dm, m, 1e-8, 0.03)
