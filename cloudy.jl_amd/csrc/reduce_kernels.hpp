@@ -15,8 +15,18 @@ __global__ void __launch_bounds__(kBlock)
     __shared__ double red[kBlock / 64];
     const size_t stride = (size_t)gridDim.x * kBlock;
     for (int q = 0; q < planes; ++q) {
-        double s = 0.0;
-        for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) s += (double)arr[(size_t)q * ld + i];
+        // four independent accumulators: four loads in flight per lane instead of one dependent add chain
+        const TIO *__restrict__ a = arr + (size_t)q * ld;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+        for (; i + 3 * stride < n; i += 4 * stride) {
+            s0 += (double)__builtin_nontemporal_load(a + i);
+            s1 += (double)__builtin_nontemporal_load(a + i + stride);
+            s2 += (double)__builtin_nontemporal_load(a + i + 2 * stride);
+            s3 += (double)__builtin_nontemporal_load(a + i + 3 * stride);
+        }
+        for (; i < n; i += stride) s0 += (double)a[i];
+        double s = (s0 + s1) + (s2 + s3);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
