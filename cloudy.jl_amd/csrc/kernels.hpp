@@ -928,7 +928,7 @@ __device__ __forceinline__ void ssprk33_body(const KArgs<N, P> *__restrict__ Ag,
                     kf = kk[m];
                     xtf = A.thr[m];
                 }
-            const float r = (MODE == MODE_FIXED) ? (float)((xtf / thf) / (kf + double(P + 2))) : (float)kf;
+            const float r = (MODE == MODE_FIXED) ? (float)(xtf / thf) : (float)kf;  // z0 (see coal_rhs_sorted_body.inc) or k
             valid = nf > 0.0 && r == r;
             rkey = r;
         }
@@ -1178,16 +1178,15 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
                 for (int m = N - 2; m >= 0; --m)
                     if (A.finite[m]) f = m;
-                double nf = nn[0], thf = th[0], kf = kk[0], xtf = A.thr[0];
+                double nf = nn[0], thf = th[0], xtf = A.thr[0];
 #pragma unroll
                 for (int m = 1; m < N; ++m)
                     if (m == f) {
                         nf = nn[m];
                         thf = th[m];
-                        kf = kk[m];
                         xtf = A.thr[m];
                     }
-                const float r = (float)((xtf / thf) / (kf + double(P + 2)));
+                const float r = (float)(xtf / thf);  // z0: see coal_rhs_sorted_body.inc
                 valid = nf > 0.0 && r == r;  // (empty cells and idle slots rank last)
                 rkey = r;
             }
