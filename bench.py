@@ -214,7 +214,7 @@ def _run_workload(pkg, name, n_parcels, steps, warmup, rank, dist, torch):
     plan = wl["coal_data"].plan(wl["dist_types"])
     m = pkg.DeviceArray.from_numpy(wl["mom"])
     dm = pkg.DeviceArray.zeros(*wl["mom"].shape)
-    rhs = pkg.make_box_model_rhs(pkg.AnalyticalCoalStyle())
+    rhs = pkg.make_box_model_rhs(pkg.AnalyticalCoalStyle(), pkg.MovingThreshold() if wl["spec"].get("moving") else None)
     # W untimed warm-up steps through the operator boundary -- and at least ~80 ms of back-to-back launches: after
     # idling the GPU needs tens of ms of continuous work to reach its sustained clocks (a 0.17 ms launch measured
     # 0.24 / 0.19 / 0.17 ms per step over the first 10 / 50 / 200 launches, tools/wall_test.py).
