@@ -98,8 +98,9 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
     if (h.mode != MODE_ALLINF) {
         const double *nodes = h.nodes_dev;
         void *args[] = {&nodes, &n, &ld, &in, &out};
-        return hipModuleLaunchKernel(r.rainshaft ? plan->rs_coal : plan->jit.sorted, g1, 1, 1, kBlock, 1, 1, 0, r.stream,
-                                     args, nullptr);
+        const unsigned bs = (unsigned)jit_sorted_block_size(h);
+        return hipModuleLaunchKernel(r.rainshaft ? plan->rs_coal : plan->jit.sorted, (unsigned)((n + bs - 1) / bs), 1, 1, bs, 1,
+                                     1, 0, r.stream, args, nullptr);
     }
     if (r.rainshaft) {
         void *args[] = {&n, &ld, &in, &out};

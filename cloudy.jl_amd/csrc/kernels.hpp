@@ -553,17 +553,19 @@ __device__ __forceinline__ void contract_promoted(const double (&ckk)[P][P], con
 // comparing every key with every other (1030 VALU instructions per lane, 6 % of the cfg3b kernel; measured equal
 // quality of the resulting waves).  Invalid / empty parcels (valid = false) rank last.  The order inside a bucket is
 // whatever order the atomics were served in: any permutation gives the same results, parcels are independent.
-// sh_cnt: kBlock counters; returns through sh_perm the lane -> slot map: slot `rank` is processed by lane sh_perm[rank].
-// `bucket_if_valid` in [0, 254]: regime_bucket(key).
+// sh_cnt: BS (= workgroup size) counters; returns through sh_perm the lane -> slot map: slot `rank` is processed by lane sh_perm[rank].
+// `bucket_if_valid` in [0, BS - 2]: regime_bucket<BS>(key).
+template <int BS = kBlock>
 __device__ __forceinline__ int regime_bucket(float key) {
     const int code = (int)(__float_as_uint(fmaxf(key, 0.0f)) >> 20) - (127 - 8) * 8;
-    return code < 0 ? 0 : (code > kBlock - 2 ? kBlock - 2 : code);
+    return code < 0 ? 0 : (code > BS - 2 ? BS - 2 : code);
 }
 
+template <int BS = kBlock>
 __device__ __forceinline__ void regime_rank(bool valid, int bucket_if_valid, unsigned int *sh_cnt,
                                             unsigned short *sh_perm) {
     const int t = threadIdx.x;
-    const int bucket = valid ? bucket_if_valid : kBlock - 1;
+    const int bucket = valid ? bucket_if_valid : BS - 1;
     sh_cnt[t] = 0u;
     __syncthreads();
     const unsigned int pos = atomicAdd(&sh_cnt[bucket], 1u);
@@ -577,12 +579,12 @@ __device__ __forceinline__ void regime_rank(bool valid, int bucket_if_valid, uns
         const unsigned int up = __shfl_up(incl, d, 64);
         if (lane >= d) incl += up;
     }
-    __shared__ unsigned int sh_wave_tot[kBlock / 64];
+    __shared__ unsigned int sh_wave_tot[BS / 64];
     if (lane == 63) sh_wave_tot[t >> 6] = incl;
     __syncthreads();
     unsigned int offs = 0;
 #pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w)
+    for (int w = 0; w < BS / 64; ++w)
         if (w < (t >> 6)) offs += sh_wave_tot[w];
     sh_cnt[t] = offs + incl - c;  // exclusive prefix of bucket t
     __syncthreads();
@@ -847,11 +849,16 @@ __global__ void __launch_bounds__(kBlock)
 // branch any of them takes, so for each thresholded mode the 256 parcels of a workgroup are ranked by that mode's r
 // (regime_rank) and each lane integrates the mode of the parcel of its rank: waves become regime-homogeneous.  The
 // three phases are described in coal_rhs_sorted_body.inc.
-template <int N, int P, int MODE, typename TIO, bool FAST = false, bool SPEC = false>
+// Workgroup size of the threshold kernel: 256, or 512 for plans with N <= 2 and a single thresholded mode (a ranking
+// over 512 parcels gives more homogeneous waves: cfg3b -6 %; with two thresholded modes, moving thresholds or the
+// larger LDS footprint of N >= 3 it measured slower).
+template <int N, int P, int MODE, typename TIO, bool FAST = false, bool SPEC = false, int BS = kBlock>
 __device__ __forceinline__ void coal_rhs_sorted_body(const KArgs<N, P> &A, const double *__restrict__ nodes, size_t n,
                                                      size_t ld, const TIO *__restrict__ in, TIO *__restrict__ out) {
 #define CLOUDY_SPEC SPEC
+#define CLOUDY_BS BS
 #include "coal_rhs_sorted_body.inc"
+#undef CLOUDY_BS
 #undef CLOUDY_SPEC
 }
 
@@ -861,12 +868,14 @@ __device__ __forceinline__ void coal_rhs_sorted_body(const KArgs<N, P> &A, const
 #ifndef CLOUDY_SORTED_WAVES
 #define CLOUDY_SORTED_WAVES 4
 #endif
-template <int N, int P, int MODE, typename TIO, bool FAST = false>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CLOUDY_SORTED_WAVES)))
+template <int N, int P, int MODE, typename TIO, bool FAST = false, int BS = kBlock>
+__global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(CLOUDY_SORTED_WAVES)))
     coal_rhs_sorted_kernel(const KArgs<N, P> A, const double *__restrict__ nodes, size_t n, size_t ld,
                            const TIO *__restrict__ in, TIO *__restrict__ out) {
 #define CLOUDY_SPEC false
+#define CLOUDY_BS BS
 #include "coal_rhs_sorted_body.inc"
+#undef CLOUDY_BS
 #undef CLOUDY_SPEC
 }
 

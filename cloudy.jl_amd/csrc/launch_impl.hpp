@@ -41,6 +41,14 @@ void fill_args(const HostPlan &h, const LaunchReq &r, KArgs<N, P> &A) {
                 for (int b = 0; b < P; ++b) A.c[j][k][a][b] = h.c[j][k][a][b];
 }
 
+// workgroup size of the threshold kernel for a plan (see coal_rhs_sorted_kernel in kernels.hpp)
+inline int sorted_block_size(const HostPlan &h) {
+    if (h.mode != MODE_FIXED || h.N > 2) return kBlock;
+    int passes = 0;
+    for (int i = 0; i < h.N - 1; ++i) passes += h.finite[i] ? 1 : 0;
+    return passes == 1 ? 512 : kBlock;
+}
+
 inline void fill_sedi(const HostPlan &h, SediArgs &S) {
     S.n_vel = h.n_vel;
     S.pad = 0;
@@ -68,19 +76,33 @@ hipError_t launch_io(const HostPlan &h, const LaunchReq &r, const KArgs<N, P> &A
         else if (h.mode == MODE_ALLINF)
             hipLaunchKernelGGL((coal_rhs_kernel<N, P, MODE_ALLINF, TIO>), dim3(g), dim3(kBlock), 0, r.stream, A,
                                h.nodes_dev, r.n, r.ld, in, out);
-        else if (h.dtype == CLOUDY_F32_FAST && sizeof(TIO) == 4 && r.input_kind == IN_MOMENTS) {
-            if (h.mode == MODE_FIXED)
-                hipLaunchKernelGGL((coal_rhs_sorted_kernel<N, P, MODE_FIXED, TIO, true>), dim3(g), dim3(kBlock), 0,
-                                   r.stream, A, h.nodes_dev, r.n, r.ld, in, out);
+        else {
+            // FixedThreshold plans with N <= 2 and one thresholded mode rank 512 parcels per workgroup (kernels.hpp)
+            const bool fast = h.dtype == CLOUDY_F32_FAST && sizeof(TIO) == 4 && r.input_kind == IN_MOMENTS;
+            if (N <= 2 && sorted_block_size(h) == 512) {
+                if constexpr (N <= 2) {
+                    const unsigned g5 = (unsigned)((r.n + 511) / 512);
+                    if (fast)
+                        hipLaunchKernelGGL((coal_rhs_sorted_kernel<N, P, MODE_FIXED, TIO, true, 512>), dim3(g5), dim3(512), 0,
+                                           r.stream, A, h.nodes_dev, r.n, r.ld, in, out);
+                    else
+                        hipLaunchKernelGGL((coal_rhs_sorted_kernel<N, P, MODE_FIXED, TIO, false, 512>), dim3(g5), dim3(512), 0,
+                                           r.stream, A, h.nodes_dev, r.n, r.ld, in, out);
+                }
+            } else if (fast) {
+                if (h.mode == MODE_FIXED)
+                    hipLaunchKernelGGL((coal_rhs_sorted_kernel<N, P, MODE_FIXED, TIO, true>), dim3(g), dim3(kBlock), 0,
+                                       r.stream, A, h.nodes_dev, r.n, r.ld, in, out);
+                else
+                    hipLaunchKernelGGL((coal_rhs_sorted_kernel<N, P, MODE_MOVING, TIO, true>), dim3(g), dim3(kBlock), 0,
+                                       r.stream, A, h.nodes_dev, r.n, r.ld, in, out);
+            } else if (h.mode == MODE_FIXED)
+                hipLaunchKernelGGL((coal_rhs_sorted_kernel<N, P, MODE_FIXED, TIO>), dim3(g), dim3(kBlock), 0, r.stream, A,
+                                   h.nodes_dev, r.n, r.ld, in, out);
             else
-                hipLaunchKernelGGL((coal_rhs_sorted_kernel<N, P, MODE_MOVING, TIO, true>), dim3(g), dim3(kBlock), 0,
-                                   r.stream, A, h.nodes_dev, r.n, r.ld, in, out);
-        } else if (h.mode == MODE_FIXED)
-            hipLaunchKernelGGL((coal_rhs_sorted_kernel<N, P, MODE_FIXED, TIO>), dim3(g), dim3(kBlock), 0, r.stream, A,
-                               h.nodes_dev, r.n, r.ld, in, out);
-        else
-            hipLaunchKernelGGL((coal_rhs_sorted_kernel<N, P, MODE_MOVING, TIO>), dim3(g), dim3(kBlock), 0, r.stream, A,
-                               h.nodes_dev, r.n, r.ld, in, out);
+                hipLaunchKernelGGL((coal_rhs_sorted_kernel<N, P, MODE_MOVING, TIO>), dim3(g), dim3(kBlock), 0, r.stream, A,
+                                   h.nodes_dev, r.n, r.ld, in, out);
+        }
         break;
     }
     case OP_SEDI: {
