@@ -90,7 +90,9 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
         if (h.mode != MODE_ALLINF) {
             const double *nodes = h.nodes_dev;
             void *args[] = {&nodes, &n, &ld, &in, &out, &dt, &n_steps};
-            return hipModuleLaunchKernel(plan->int_ssprk33, g1, 1, 1, kBlock, 1, 1, 0, r.stream, args, nullptr);
+            const unsigned bs = (unsigned)jit_sorted_block_size(h);
+            return hipModuleLaunchKernel(plan->int_ssprk33, (unsigned)((n + bs - 1) / bs), 1, 1, bs, 1, 1, 0, r.stream, args,
+                                         nullptr);
         }
         void *args[] = {&n, &ld, &in, &out, &dt, &n_steps};
         return hipModuleLaunchKernel(plan->jit.ssprk33, g1, 1, 1, kBlock, 1, 1, 0, r.stream, args, nullptr);

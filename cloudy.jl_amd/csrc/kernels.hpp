@@ -904,18 +904,19 @@ __device__ __forceinline__ void rhs_physical(const KArgs<N, P> &A, const double 
     }
 }
 
-template <int N, int P, int MODE, typename TIO, bool SPEC = false>
+// BS: workgroup size (256; 512 for thresholded plans with N <= 2 and one thresholded mode, as coal_rhs_sorted_kernel)
+template <int N, int P, int MODE, typename TIO, bool SPEC = false, int BS = kBlock>
 __device__ __forceinline__ void ssprk33_body(const KArgs<N, P> *__restrict__ Ag, const double *__restrict__ nodes, size_t n,
                                              size_t ld, const TIO *u_in, TIO *u_out, double dt, int n_steps) {
     // The plan constants come through a device pointer that is re-derived once per stage through an opaque zero offset: with by-value kernel arguments LICM hoists every scalar load of the tensors out of the step/stage
     // loops and then spills ~170 SGPRs into VGPR lanes (348 v_readlane per pass measured); re-deriving the pointer
     // keeps those s_loads inside the stage, where they hit the scalar cache.
     const KArgs<N, P> &A = *Ag;
-    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
     if (MODE != MODE_ALLINF) {
         // regime sort of the workgroup's parcels on the initial state (see coal_rhs_sorted_kernel)
-        __shared__ unsigned int sh_cnt[kBlock];
-        __shared__ unsigned short sh_perm[kBlock];
+        __shared__ unsigned int sh_cnt[BS];
+        __shared__ unsigned short sh_perm[BS];
         const int t = threadIdx.x;
         bool valid = false;
         float rkey = 0.0f;
@@ -941,8 +942,8 @@ __device__ __forceinline__ void ssprk33_body(const KArgs<N, P> *__restrict__ Ag,
             valid = nf > 0.0 && r == r;
             rkey = r;
         }
-        regime_rank(valid, regime_bucket(rkey), sh_cnt, sh_perm);
-        i = (size_t)blockIdx.x * kBlock + sh_perm[t];
+        regime_rank<BS>(valid, regime_bucket<BS>(rkey), sh_cnt, sh_perm);
+        i = (size_t)blockIdx.x * BS + sh_perm[t];
     }
     if (i >= n) return;
     double u[N][3], up[N][3], f[N][3];
@@ -996,11 +997,11 @@ __device__ __forceinline__ void ssprk33_body(const KArgs<N, P> *__restrict__ Ag,
     }
 }
 
-template <int N, int P, int MODE, typename TIO>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(CLOUDY_SORTED_WAVES)))
+template <int N, int P, int MODE, typename TIO, int BS = kBlock>
+__global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(CLOUDY_SORTED_WAVES)))
     ssprk33_kernel(const KArgs<N, P> *__restrict__ Ag, const double *__restrict__ nodes, size_t n, size_t ld,
                    const TIO *u_in, TIO *u_out, double dt, int n_steps) {
-    ssprk33_body<N, P, MODE, TIO>(Ag, nodes, n, ld, u_in, u_out, dt, n_steps);
+    ssprk33_body<N, P, MODE, TIO, false, BS>(Ag, nodes, n, ld, u_in, u_out, dt, n_steps);
 }
 
 // ---- diagnostics / the callers either side of the operator ---------------------------------------

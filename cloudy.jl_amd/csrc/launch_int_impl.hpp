@@ -23,7 +23,11 @@ hipError_t launch_int_io(const HostPlan &h, const LaunchReq &r) {
         if (h.mode == MODE_ALLINF)
             hipLaunchKernelGGL((ssprk33_kernel<N, P, MODE_ALLINF, TIO>), dim3(g), dim3(kBlock), 0, r.stream, Ad,
                                h.nodes_dev, r.n, r.ld, in, out, r.dt, r.n_steps);
-        else if (h.mode == MODE_FIXED)
+        else if (h.mode == MODE_FIXED && N <= 2 && sorted_block_size(h) == 512) {
+            if constexpr (N <= 2)
+                hipLaunchKernelGGL((ssprk33_kernel<N, P, MODE_FIXED, TIO, 512>), dim3((unsigned)((r.n + 511) / 512)),
+                                   dim3(512), 0, r.stream, Ad, h.nodes_dev, r.n, r.ld, in, out, r.dt, r.n_steps);
+        } else if (h.mode == MODE_FIXED)
             hipLaunchKernelGGL((ssprk33_kernel<N, P, MODE_FIXED, TIO>), dim3(g), dim3(kBlock), 0, r.stream, Ad,
                                h.nodes_dev, r.n, r.ld, in, out, r.dt, r.n_steps);
         else
