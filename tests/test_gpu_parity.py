@@ -1068,3 +1068,37 @@ def test_randomised_plan_sweep(gpu_cloudy, oracle, seed):
         cfg = F.random_config(rng)
         worst, dj = F.check_config(gpu_cloudy, cfg, 300, 5000 + 100 * seed + c)
         assert dj <= 1e-6
+
+
+def test_error_returns_of_the_column_and_integrator_entry_points(gpu_cloudy):
+    """Argument checking of the newer entry points: status codes, never exceptions or launches."""
+    cloudy = gpu_cloudy
+    L, E = cloudy.lib(), cloudy._lib
+    kc = [[0.0, 5.0], [5.0, 0.0]]
+    cd = cloudy.CoalescenceData(cloudy.CoalescenceTensor(kc), (3,), (INF,), bench.NORMS)
+    no_vel = cd.plan([1])
+    with_vel = cd.plan([1], vel=((50.0, 1.0 / 6),))
+    u = cloudy.DeviceArray.zeros(3, 40)
+    # no terminal velocity in the plan
+    assert L.cloudy_rainshaft_ssprk33_steps(no_vel.handle, 20, 2, 40, u.ptr, u.ptr, 150.0, 1.0, 1, None) == E.EINVAL
+    assert b"n_vel" in L.cloudy_last_error()
+    # bad geometry / step arguments
+    assert L.cloudy_rainshaft_ssprk33_steps(with_vel.handle, 0, 2, 40, u.ptr, u.ptr, 150.0, 1.0, 1, None) == E.EINVAL
+    assert L.cloudy_rainshaft_ssprk33_steps(with_vel.handle, 20, 2, 40, u.ptr, u.ptr, -1.0, 1.0, 1, None) == E.EINVAL
+    assert L.cloudy_rainshaft_ssprk33_steps(with_vel.handle, 20, 2, 40, u.ptr, u.ptr, 150.0, 1.0, -3, None) == E.EINVAL
+    assert L.cloudy_rainshaft_ssprk33_steps(with_vel.handle, 20, 2, 39, u.ptr, u.ptr, 150.0, 1.0, 1, None) == E.EINVAL  # ld < n
+    assert L.cloudy_rainshaft_ssprk33_steps(with_vel.handle, 20, 2, 40, None, u.ptr, 150.0, 1.0, 1, None) == E.EINVAL
+    assert L.cloudy_rainshaft_ssprk33_steps(None, 20, 2, 40, u.ptr, u.ptr, 150.0, 1.0, 1, None) == E.EINVAL
+    assert L.cloudy_rainshaft_ssprk33_steps(with_vel.handle, 300, 1, 300, u.ptr, u.ptr, 150.0, 1.0, 1, None) == E.EUNSUPPORTED
+    # an empty batch is fine
+    assert L.cloudy_rainshaft_ssprk33_steps(with_vel.handle, 20, 0, 0, None, None, 150.0, 1.0, 1, None) == 0
+    # MovingThreshold plans have no rainshaft driver in the reference
+    cdm = cloudy.CoalescenceData(tuple(tuple(cloudy.CoalescenceTensor(kc) for _ in range(2)) for _ in range(2)), (3, 3),
+                                 (0.9, 1.0), bench.NORMS, cloudy.MovingThreshold())
+    pm = cdm.plan([1, 1], vel=((50.0, 1.0 / 6),))
+    u6 = cloudy.DeviceArray.zeros(6, 40)
+    assert L.cloudy_rainshaft_ssprk33_steps(pm.handle, 20, 2, 40, u6.ptr, u6.ptr, 150.0, 1.0, 1, None) == E.EINVAL
+    assert L.cloudy_ssprk33_steps(pm.handle, 40, 40, u6.ptr, u6.ptr, float("nan"), 1, None) == E.EINVAL
+    assert L.cloudy_ssprk33_steps(pm.handle, 40, 40, u6.ptr, u6.ptr, 1.0, -1, None) == E.EINVAL
+    assert L.cloudy_plan_specialized(None) == E.EINVAL and L.cloudy_plan_jit_log(None) == b"plan is NULL"
+    assert L.cloudy_jit_selfcheck(None, None) == E.EINVAL
