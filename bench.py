@@ -150,6 +150,32 @@ def oracle_params(name):
 
 
 # ------------------------------------------------------------------------------------------------
+def _spawn_ranks(n_gpus, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher (WORLD_SIZE unset): this parent -- which never touches the
+    GPU, never imports torch and never loads libcloudy_hip.so -- starts N fresh child processes of this script, one rank
+    per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would), waits for them and relays
+    rank 0's JSON line.  Non-zero exit if any rank fails."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [q.wait() for q in procs[1:]]
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    if any(codes):
+        raise SystemExit(f"bench.py --gpus {n_gpus}: rank exit codes {codes}")
+
+
 def _dist_setup(n_gpus):
     """torch.distributed over RCCL when launched by torch.distributed.run; -> (rank, world, dist or None)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -209,6 +235,17 @@ def _event_ms(pkg, plan, m, dm, iters):
     return float(ms.value)
 
 
+def _gather(x, dist, torch):
+    """[x of rank 0, x of rank 1, ...] (all ranks get the list)."""
+    if dist is None:
+        return [float(x)]
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    mine = torch.tensor([float(x)], dtype=torch.float64, device=dev)
+    parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    return [float(t.item()) for t in parts]
+
+
 def _run_workload(pkg, name, n_parcels, steps, warmup, rank, dist, torch):
     wl = make_workload(name, n_parcels, seed=SEED + 1000 * rank)
     plan = wl["coal_data"].plan(wl["dist_types"])
@@ -217,7 +254,7 @@ def _run_workload(pkg, name, n_parcels, steps, warmup, rank, dist, torch):
     rhs = pkg.make_box_model_rhs(pkg.AnalyticalCoalStyle(), pkg.MovingThreshold() if wl["spec"].get("moving") else None)
     # W untimed warm-up steps through the operator boundary -- and at least ~80 ms of back-to-back launches: after
     # idling the GPU needs tens of ms of continuous work to reach its sustained clocks (a 0.17 ms launch measured
-    # 0.24 / 0.19 / 0.17 ms per step over the first 10 / 50 / 200 launches, tools/wall_test.py).
+    # 0.24 / 0.19 / 0.17 ms per step over the first 10 / 50 / 200 launches, tools/launch_ramp_timing.py).
     t_w = time.perf_counter()
     done = 0
     while done < max(warmup, 1) or (time.perf_counter() - t_w) < 0.08:
@@ -247,39 +284,159 @@ def _run_workload(pkg, name, n_parcels, steps, warmup, rank, dist, torch):
                 mass_per_parcel=per_parcel, nmom=plan.nmom)
 
 
+# the reference's only published performance statements for this path: BenchmarkTools minimum-time CEILINGS asserted in
+# its CI (test/unit_tests/performance_tests.jl:66-112, one CPU of a CliMA Buildkite slurm node), per call, Julia
+REFERENCE_CI_CEILINGS_NS = {
+    "update_dist_from_moments (each closure family)": 200,                                # performance_tests.jl:66
+    "get_moments": 60,                                                                    # :67-73
+    "moment_source_helper(Exponential(10,1), 1.0, 0.0, 1.2)": 16_000,                     # :76-82
+    "moment_source_helper(Gamma(5,10,2), 1.0, 0.0, 1.2)": 27_000,                         # :83-89
+    "moment_source_helper(Monodisperse(1,0.5), 1.0, 0.0, 1.2)": 60,                       # :92
+    "get_standard_N_q((mono, lognormal, gamma))": 250_000,                                # :94-99
+    "integrate_SimpsonEvenFast(90, dx, y)": 1_200,                                        # :106-112
+}
+
+
+_CPUS = None
+
+
+def _usable_cpus():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (a pod sees every logical CPU
+    of the host in nproc but may be throttled to a fraction of them -- an OpenMP team of nproc threads then runs at a
+    few per cent efficiency)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())    # cgroup v1
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    return n, quota
+
+
+def _time_oracle(O, p, mom, out, n_threads, reps=1):
+    best = float("inf")
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        O.rhs_coal_batch(p, mom, n_threads=n_threads, out=out)
+        best = min(best, time.perf_counter() - t0)
+    return best
+
+
 def _cpu_baseline(name, target_seconds=12.0):
-    """The C oracle (kind 'port' of the reference algorithm) on the host cores, bounded sample of the same batch."""
+    """The C oracle (kind 'port' of the reference algorithm; julia is not installed) on the host cores: a bounded sample
+    of the same batch, timed single-threaded and on the thread count that measures fastest (output pre-faulted, threads
+    bound to cores), with the parallel efficiency of that team."""
+    # libgomp reads these when it is first loaded (the oracle is the first OpenMP user of this process)
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
+    os.environ.setdefault("OMP_DYNAMIC", "false")
+    global _CPUS
+    if _CPUS is None:
+        _CPUS = _usable_cpus()   # before libgomp loads: with OMP_PROC_BIND it pins this thread to the first place
+    nproc, quota = _CPUS
     from oracle import cloudy_oracle as O
 
     p = oracle_params(name)
-    nthreads = O.max_threads()
     n_modes = workload_spec(name)["n_modes"]
-    probe = synth_moments(n_modes, 200 * nthreads, SEED)
-    O.rhs_coal_batch(p, probe, n_threads=nthreads)          # spawns the OpenMP team
-    t0 = time.perf_counter()
-    O.rhs_coal_batch(p, probe, n_threads=nthreads)
-    per = max((time.perf_counter() - t0) / probe.shape[1], 1e-9)
-    cap = 60_000_000
+    hw = min(O.max_threads(), nproc)
+    try:
+        import psutil
+
+        phys = psutil.cpu_count(logical=False) or hw
+    except Exception:
+        phys = hw
+    # single thread: ~1.5 s sample
+    probe = synth_moments(n_modes, 2000, SEED)
+    out = np.zeros_like(probe)
+    per1 = max(_time_oracle(O, p, probe, out, 1, reps=2) / probe.shape[1], 1e-9)
+    n1 = int(min(max(1.5 / per1, 2000), 4_000_000))
+    mom1 = synth_moments(n_modes, n1, SEED)
+    out1 = np.zeros_like(mom1)            # pre-faulted: first touch is not in the timed call
+    t1 = _time_oracle(O, p, mom1, out1, 1, reps=2)
+    rate1 = n1 / t1
+    # candidate team sizes (physical cores, logical CPUs, the cgroup quota): short probes, keep the fastest
+    cands = sorted({c for c in (hw, min(phys, hw), int(quota) if quota and quota >= 1 else hw, max(hw // 2, 1),
+                                max(hw // 4, 1)) if 1 <= c <= hw})
+    pool = synth_moments(n_modes, int(min(max(0.6 * hw * rate1, 4000), 4_000_000)), SEED)   # generated once, tiled below
+    probes = {}
+    for c in cands:
+        n_c = int(min(max(0.6 * c * rate1, 4000), pool.shape[1]))
+        mom_c = np.ascontiguousarray(pool[:, :n_c])
+        out_c = np.zeros_like(mom_c)
+        warm = np.ascontiguousarray(pool[:, :min(max(200 * c, 1000), n_c)])
+        _time_oracle(O, p, warm, np.zeros_like(warm), c)   # spawns / resizes the OpenMP team outside the timed call
+        probes[c] = n_c / _time_oracle(O, p, mom_c, out_c, c, reps=2)
+    best_c = max(probes, key=probes.get)
+    cap = 40_000_000
     try:
         import psutil
 
         cap = int(min(cap, psutil.virtual_memory().available / (8 * 3 * 8 * 3 * n_modes)))  # 3 arrays, 1/8 of free RAM
     except Exception:
         cap = 20_000_000
-    n = int(min(max(target_seconds / per, 2000), cap))
-    mom = synth_moments(n_modes, n, SEED)
-    t0 = time.perf_counter()
-    O.rhs_coal_batch(p, mom, n_threads=nthreads)
-    dt = time.perf_counter() - t0
-    if dt < 0.4 * target_seconds and n < cap:  # the probe over-estimated the per-parcel cost: repeat, larger
-        n = int(min(n * 0.8 * target_seconds / max(dt, 1e-3), cap))
-        mom = synth_moments(n_modes, n, SEED)
-        t0 = time.perf_counter()
-        O.rhs_coal_batch(p, mom, n_threads=nthreads)
-        dt = time.perf_counter() - t0
-    return dict(value=n / dt, unit="parcel-RHS/s", cores=nthreads, kind="port",
+    n = int(min(max(target_seconds * probes[best_c], 2000), cap))
+    mom = np.ascontiguousarray(np.tile(pool, (1, -(-n // pool.shape[1])))[:, :n])   # the same batch, repeated
+    out = np.zeros_like(mom)
+    dt = _time_oracle(O, p, mom, out, best_c)
+    rate = n / dt
+    return dict(value=rate, unit="parcel-RHS/s", cores=best_c, kind="port",
                 sample=f"{n} parcels of the {name} batch, oracle/cloudy_oracle.c (C restatement of the Julia "
-                       f"reference; julia is not installed), OpenMP x{nthreads}, {dt:.1f} s")
+                       f"reference; julia is not installed), OpenMP x{best_c} bound to cores, output pre-faulted, "
+                       f"{dt:.1f} s",
+                one_thread={"value": rate1, "unit": "parcel-RHS/s", "sample": f"{n1} parcels, {t1:.1f} s",
+                            "us_per_parcel": 1e6 / rate1},
+                parallel_efficiency=rate / (best_c * rate1),
+                nproc=nproc, physical_cores=phys, cgroup_cpu_quota=quota,
+                team_probe_parcels_per_s={str(c): v for c, v in probes.items()},
+                reference_ci_ceilings_ns=REFERENCE_CI_CEILINGS_NS,
+                reference_ci_ceilings_source="test/unit_tests/performance_tests.jl:66-112 (BenchmarkTools minimum time, "
+                                             "1 CPU of the reference's CI; upper bounds, not measurements)")
+
+
+def _kernel_label(plan, n_modes, P):
+    """Name of the kernel behind cloudy_coal_rhs for this plan, as rocprofv3 shows it (jit.hpp: jit_suffix)."""
+    sfx = f"_n{n_modes}p{P}_f64"
+    if plan.all_inf:
+        return ("cloudy_jit_allinf2" + sfx + " (coal_rhs_allinf2_body compiled for this plan at plan creation)"
+                if plan.specialized else f"coal_rhs_allinf2_kernel<{n_modes}, {P}, double>")
+    return ("cloudy_jit_sorted" + sfx + " (coal_rhs_sorted_body compiled for this plan at plan creation)"
+            if plan.specialized else f"coal_rhs_sorted_kernel<{n_modes}, {P}, ...>")
+
+
+def _headline_roofline(workload, plan, n_local, nmom, event_ms, per_rank_ms, traffic, measured):
+    """HBM roofline for plans whose thresholds are all Inf (the kernel streams 2 x nmom x 8 B per parcel and does
+    ~300 VALU instructions on it); fp64-VALU roofline for plans with a Simpson pass (13-33 k VALU instructions per
+    parcel: the HBM fraction of such a kernel says nothing)."""
+    bytes_per_launch = 2 * nmom * 8 * n_local
+    label = _kernel_label(plan, plan.n_modes, plan.tensor_p)
+    hbm = lambda ms: bytes_per_launch / (ms * 1e-3) / 1e9
+    if plan.all_inf:
+        a = hbm(event_ms)
+        return {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
+                "traffic": traffic, "kernel": label, "kernel_ms": event_ms,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "per_rank": [{"rank": r, "kernel_ms": ms, "achieved": hbm(ms), "frac": hbm(ms) / HBM_PEAK_GBS}
+                             for r, ms in enumerate(per_rank_ms)]}
+    flops = measured.get(f"{workload}_fp64_flops_per_parcel")
+    if flops is None and workload == "cfg3b" and measured.get("cfg3b_fp64_flops_per_launch"):
+        flops = measured["cfg3b_fp64_flops_per_launch"] / measured["n_parcels"]
+    tf = (lambda ms: flops * n_local / (ms * 1e-3) / 1e12) if flops else (lambda ms: None)
+    a = tf(event_ms)
+    return {"bound": "fp64-valu", "achieved": a, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": a / FP64_VALU_PEAK_TFLOPS if a else None, "traffic": None, "kernel": label, "kernel_ms": event_ms,
+            "fp64_flops_per_parcel": flops, "hbm_GBs": hbm(event_ms),
+            "note": "fp64 flops per parcel from the committed SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 counters x active-lane "
+                    "fraction (profiles/measured_latest.json)",
+            "per_rank": [{"rank": r, "kernel_ms": ms, "achieved": tf(ms),
+                          "frac": tf(ms) / FP64_VALU_PEAK_TFLOPS if flops else None} for r, ms in enumerate(per_rank_ms)]}
 
 
 def main():
@@ -292,6 +449,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return _spawn_ranks(args.gpus, sys.argv[1:])   # before anything touches the GPU
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: launch one rank per GPU")
 
     t_start = time.perf_counter()
     rank, world, local_rank, dist, torch = _dist_setup(args.gpus)
@@ -311,6 +474,7 @@ def main():
     total = n_local * world
     value = total * args.steps / res["wall"]
     achieved = bytes_per_eval * n_local / (res["event_ms"] * 1e-3) / 1e9
+    per_rank_ms = _gather(res["event_ms"], dist, torch)   # every rank's HIP-event average of its own launches
 
     measured = _measured_latest()
     traffic = None
@@ -526,12 +690,8 @@ def main():
                                    f"order-{2 if spec['kernel'] == 'long' else 1} polynomial CoalescenceTensor, "
                                    f"{nmom} moments, thresholds {spec['thresholds']}, norms {NORMS}",
                        "parcels_per_gpu": n_local, "global_parcels": total, "sharding": f"parcel ranges x{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("cloudy_jit_allinf2_n2p3_f64 (coal_rhs_allinf2_body compiled for this plan at plan "
-                                    "creation)" if res["plan"].specialized else "coal_rhs_allinf2_kernel<2, 3, double>"),
-                         "kernel_ms": res["event_ms"],
-                         "algorithmic_bytes_per_launch": bytes_per_eval * n_local},
+            "roofline": _headline_roofline(args.workload, res["plan"], n_local, nmom, res["event_ms"], per_rank_ms,
+                                           traffic, measured),
             "cpu_baseline": cpu,
             "mass_rate_residual": abs(res["mass_rate_sum"]) / max(res["mass_rate_gross"], 1e-300),
             "mass_residual_per_parcel_max": res["mass_per_parcel"],

@@ -60,8 +60,12 @@ class Plan:
         h = C.c_void_p()
         _lib.check(L.cloudy_plan_create(C.byref(d), C.byref(h)))
         self.handle = h
-        self.N = N
-        self.P = int(d.tensor_p)
+        self.N = self.n_modes = N
+        self.P = self.tensor_p = int(d.tensor_p)
+        # which kernel family serves cloudy_coal_rhs (cloudy_hip.hip, build_host_plan): the streaming all-Inf kernel,
+        # or the regime-sorted kernel with a Simpson pass (a finite FixedThreshold below the last mode / MovingThreshold)
+        thr = [float(t) for t in dist_thresholds][:N]
+        self.all_inf = (N == 1) or (d.threshold_style == 0 and all(t == float("inf") for t in thr[:N - 1]))
         self.nmom = L.cloudy_plan_nmom(h)
         self.specialized = bool(L.cloudy_plan_specialized(h))
 

@@ -46,8 +46,10 @@ int fail(int code, const char *fmt, ...) {
 }
 
 int fail_hip(hipError_t e, const char *what) {
-    return fail(e == hipErrorNoDevice || e == hipErrorInvalidDevice ? CLOUDY_ENODEVICE : CLOUDY_EHIP, "%s: %s", what,
-                hipGetErrorString(e));
+    const int code = (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? CLOUDY_ENODEVICE
+                     : (e == hipErrorOutOfMemory)                             ? CLOUDY_ENOMEM
+                                                                              : CLOUDY_EHIP;
+    return fail(code, "%s: %s", what, hipGetErrorString(e));
 }
 
 #define HIP_TRY(expr)                                   \

@@ -374,12 +374,14 @@ def rhs_coal(p, mom, with_scale=False):
     return (d, s) if with_scale else d
 
 
-def rhs_coal_batch(p, mom, with_scale=False, n_threads=0):
-    """mom: [nmom, n_parcels] moment-major (C-contiguous) -> dmom of the same shape."""
+def rhs_coal_batch(p, mom, with_scale=False, n_threads=0, out=None):
+    """mom: [nmom, n_parcels] moment-major (C-contiguous) -> dmom of the same shape (`out`: preallocated result)."""
     m = _darr(mom)
     nm, n = m.shape
     assert nm == nmom_of(p)
-    d = np.empty_like(m)
+    if out is not None:
+        assert out.shape == m.shape and out.dtype == np.float64 and out.flags.c_contiguous
+    d = out if out is not None else np.empty_like(m)
     s = np.empty_like(m) if with_scale else None
     if lib().co_rhs_coal_batch(C.byref(p), n, n, _d(m), _d(d), _d(s) if s is not None else None, int(n_threads)) < 0:
         raise ValueError("rhs_coal_batch failed")

@@ -1047,7 +1047,7 @@ def test_more_than_2_to_32_elements_per_array(gpu_cloudy):
 
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "big_batch_check.py"), "800000000"],
                        capture_output=True, text=True, timeout=600)
-    if p.returncode != 0 and ("-4" in p.stderr or "out of memory" in p.stderr.lower()):
+    if p.returncode == 77:  # EXIT_NOMEM of the script: cloudy_malloc returned CLOUDY_ENOMEM, nothing else skips
         pytest.skip("not enough free device memory for the 77 GB check")
     assert p.returncode == 0, p.stdout + p.stderr
     assert "mismatching tiles: 0" in p.stdout

@@ -14,8 +14,15 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 800_000_000
 tile = 1 << 20
 wl = bench.make_workload("cfg3a", tile, seed=3)
 plan = wl["coal_data"].plan(wl["dist_types"])
-m = pkg.DeviceArray(6, n)
-dm = pkg.DeviceArray(6, n)
+EXIT_NOMEM = 77  # the caller (tests/test_gpu_parity.py) skips on exactly this status
+try:
+    m = pkg.DeviceArray(6, n)
+    dm = pkg.DeviceArray(6, n)
+except pkg._lib.CloudyError as e:
+    if e.code == pkg._lib.ENOMEM:
+        print(f"cloudy_malloc: CLOUDY_ENOMEM for 2 x {6 * n * 8 / 1e9:.0f} GB", file=sys.stderr)
+        sys.exit(EXIT_NOMEM)
+    raise
 host = np.ascontiguousarray(wl["mom"])
 for q in range(6):                                   # replicate the tile along every plane
     for off in range(0, n, tile):
