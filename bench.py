@@ -401,6 +401,51 @@ def _cpu_baseline(name, target_seconds=12.0):
                                              "1 CPU of the reference's CI; upper bounds, not measurements)")
 
 
+CFG4Q_PARCELS = 12_500_000
+
+
+def cfg4q_par(pkg, quad_order=10):
+    """BASELINE configs[3] as worded: 3 Gamma modes, HydrodynamicKernelFunction(1e2 pi) (box_gamma_mixture_hydro.jl:22)
+    evaluated by a 10-point Gauss rule per distribution (NumericalCoalStyle plan), 9 moments."""
+    kf = pkg.get_normalized_kernel_func(pkg.HydrodynamicKernelFunction(1e2 * np.pi), NORMS)
+    pd = tuple(pkg.GammaPrimitiveParticleDistribution(1.0, 1.0, 1.0) for _ in range(3))
+    return pkg.ODEParameters(pd, None, (3, 3, 3), NORMS, kernel_func=kf, quad_order=quad_order)
+
+
+def _cfg4q_variant(pkg, rank, world, measured, n=CFG4Q_PARCELS, reps=3):
+    import ctypes as C
+
+    par = cfg4q_par(pkg)
+    plan = pkg.numerical_plan([1, 1, 1], par.kernel_func, NORMS, 10)
+    mom = synth_moments(3, n, SEED + 1000 * rank)
+    m, dm = pkg.DeviceArray.from_numpy(mom), pkg.DeviceArray.zeros(9, n)
+    L = pkg.lib()
+    for _ in range(2):
+        pkg._lib.check(L.cloudy_coal_rhs(plan.handle, n, n, m.ptr, dm.ptr, None))
+    ms = C.c_float()
+    pkg._lib.check(L.cloudy_time_coal_rhs(plan.handle, n, n, m.ptr, dm.ptr, None, reps, C.byref(ms)))
+    ms = float(ms.value)
+    d = dm.to_numpy()[:, :200_000]
+    net = d[1] + d[4] + d[7]
+    mag = np.abs(d[1]) + np.abs(d[4]) + np.abs(d[7])
+    ok = np.isfinite(net)
+    out = {"workload": f"cfg4q: {n} parcels/GPU, 3 Gamma modes, hydrodynamic kernel FUNCTION (E = 1e2 pi) by a 10-point "
+                       "Gauss rule per distribution (NumericalCoalStyle plan: per-parcel generalised Gauss-Laguerre "
+                       "nodes, tensor-product pair sums, weighting_fn split), 9 moments, fp64",
+           "value": n * world / (ms * 1e-3), "unit": "parcel-RHS/s", "kernel_ms": ms,
+           "kernel": "cloudy_jit_quad_n3q10_hydro_f64" if plan.specialized else "coal_rhs_quad_kernel<3, 2, double>",
+           "hbm_GBs": 2 * 9 * 8 * n / (ms * 1e-3) / 1e9,
+           "mass_residual_per_parcel_max": float(np.max(np.abs(net[ok]) / np.maximum(mag[ok], 1e-300)))}
+    flops = measured.get("cfg4q_fp64_flops_per_parcel")
+    if flops:
+        tf = flops * n / (ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "fp64-valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": tf / FP64_VALU_PEAK_TFLOPS, "fp64_flops_per_parcel": flops,
+                           "note": "fp64 flops per parcel from the committed SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 counters x "
+                                   "active-lane fraction (profiles/measured_latest.json)"}
+    return out
+
+
 def _kernel_label(plan, n_modes, P):
     """Name of the kernel behind cloudy_coal_rhs for this plan, as rocprofv3 shows it (jit.hpp: jit_suffix)."""
     sfx = f"_n{n_modes}p{P}_f64"
@@ -664,6 +709,9 @@ def main():
             "column_mass_left": float(o1.to_numpy()[[1, 4]].sum() / 5e-3),
         }
         del ur, outr
+
+    if not args.no_variants and args.workload == "cfg3a":
+        variants["cfg4q"] = _cfg4q_variant(pkg, rank, world, measured)
 
     t_variants = time.perf_counter()
     cpu = None

@@ -6,6 +6,8 @@ import numpy as np
 from . import _lib
 from .device import DeviceArray, as_device
 from .EquationTypes import (AnalyticalCoalStyle, FixedThreshold, MovingThreshold, NumericalCoalStyle, ThresholdStyle)
+from .KernelFunctions import (ConstantKernelFunction, HydrodynamicKernelFunction, LinearKernelFunction,
+                              LongKernelFunction)
 from .KernelTensors import CoalescenceTensor, check_symmetry
 
 EPS = float(np.finfo(np.float64).eps)
@@ -97,6 +99,80 @@ class Plan:
             pass
 
 
+def kernel_func_code(kf):
+    """(CLOUDY_KFUNC_* id, parameters) of a CoalescenceKernelFunction (KernelFunctions.jl:39-86)."""
+    if isinstance(kf, ConstantKernelFunction):
+        return 0, (kf.coll_coal_rate,)
+    if isinstance(kf, LinearKernelFunction):
+        return 1, (kf.coll_coal_rate,)
+    if isinstance(kf, HydrodynamicKernelFunction):
+        return 2, (kf.coal_eff,)
+    if isinstance(kf, LongKernelFunction):
+        return 3, (kf.x_threshold, kf.coal_rate_below_threshold, kf.coal_rate_above_threshold)
+    raise TypeError("kernel_func must be a CoalescenceKernelFunction")
+
+
+class NumericalPlan(Plan):
+    """Plan of a NumericalCoalStyle operator: get_coal_ints(::NumericalCoalStyle, pdists, kernel_func)
+    (Coalescence.jl:470-489) with a fixed `quad_order`-point Gauss rule per distribution (csrc/quad.hpp).
+    `kernel_func` is the normalised kernel function the reference passes in p.kernel_func
+    (get_normalized_kernel_func(kernel, norms), Numerical/n_particles_gamma.jl:35)."""
+
+    @staticmethod
+    def make_desc(dist_types, kernel_func, norms, quad_order=10, k_range=(EPS, 10.0), device=-1, dtype=0, specialize=0,
+                  kernel_func_is_normalized=True):
+        L = _lib.lib()
+        d = _lib.PlanDesc()
+        L.cloudy_plan_desc_init(C.byref(d))
+        N = len(dist_types)
+        if N > _lib.MAX_MODES:
+            raise _lib.CloudyError(_lib.EUNSUPPORTED, f"more than {_lib.MAX_MODES} modes")
+        d.n_modes = N
+        for i, t in enumerate(dist_types):
+            d.dist_type[i] = int(t)
+        d.norms[0], d.norms[1] = float(norms[0]), float(norms[1])
+        d.k_range[0], d.k_range[1] = float(k_range[0]), float(k_range[1])
+        d.device, d.dtype, d.specialize = int(device), int(dtype), int(specialize)
+        d.coal_style = 1
+        d.kernel_func, params = kernel_func_code(kernel_func)
+        for i, v in enumerate(params):
+            d.kernel_func_params[i] = float(v)
+        d.kernel_func_is_normalized = int(bool(kernel_func_is_normalized))
+        d.quad_order = int(quad_order)
+        return d
+
+    def __init__(self, dist_types, kernel_func, norms, quad_order=10, k_range=(EPS, 10.0), device=-1, dtype=0,
+                 specialize=0, kernel_func_is_normalized=True):
+        L = _lib.lib()
+        d = NumericalPlan.make_desc(dist_types, kernel_func, norms, quad_order, k_range, device, dtype, specialize,
+                                    kernel_func_is_normalized)
+        N = len(dist_types)
+        h = C.c_void_p()
+        _lib.check(L.cloudy_plan_create(C.byref(d), C.byref(h)))
+        self.handle = h
+        self.dtype = int(dtype)
+        self.N = self.n_modes = N
+        self.P = self.tensor_p = 1
+        self.quad_order = int(quad_order)
+        self.all_inf = True
+        self.numerical = True
+        self.nmom = L.cloudy_plan_nmom(h)
+        self.specialized = bool(L.cloudy_plan_specialized(h))
+
+
+_numerical_plans = {}
+
+
+def numerical_plan(dist_types, kernel_func, norms, quad_order=10, k_range=(EPS, 10.0), dtype=0, specialize=0):
+    """Cached NumericalPlan (one per distinct configuration)."""
+    key = (tuple(int(t) for t in dist_types), kernel_func, tuple(norms), int(quad_order), tuple(k_range), int(dtype),
+           int(specialize))
+    if key not in _numerical_plans:
+        _numerical_plans[key] = NumericalPlan(key[0], kernel_func, norms, quad_order, k_range, dtype=dtype,
+                                              specialize=specialize)
+    return _numerical_plans[key]
+
+
 class CoalescenceData:
     """CoalescenceData(kernel, NProgMoms, dist_thresholds, norms=(1, 1), ts=FixedThreshold())
     (Coalescence.jl:55-104).  `kernel` is one CoalescenceTensor or an N x N nested tuple of them."""
@@ -153,18 +229,21 @@ class CoalescenceData:
         return self._plans[key]
 
 
-def get_coal_ints(cs, pdists, coal_data, ts=None, out=None, stream=None, k_range=(EPS, 10.0)):
-    """get_coal_ints(::AnalyticalCoalStyle, pdists, coal_data[, ::MovingThreshold])  (Coalescence.jl:115-185),
-    batched: `pdists` = (dist_types, params) with params a (3N, n) device array of (n, theta, k) in normalised
-    units.  Returns the (nmom, n) device array of normalised tendencies."""
-    if isinstance(cs, NumericalCoalStyle):
-        raise NotImplementedError("NumericalCoalStyle (nested adaptive quadgk) is not built for the GPU; see DESIGN.md")
-    if not isinstance(cs, AnalyticalCoalStyle):
-        raise ValueError("Invalid coal style!")
-    if isinstance(ts, MovingThreshold) != isinstance(coal_data.ts, MovingThreshold):
-        raise ValueError("threshold style of the call does not match the CoalescenceData")
+def get_coal_ints(cs, pdists, coal_data, ts=None, out=None, stream=None, k_range=(EPS, 10.0), quad_order=10):
+    """get_coal_ints(::AnalyticalCoalStyle, pdists, coal_data[, ::MovingThreshold])  (Coalescence.jl:115-185) and
+    get_coal_ints(::NumericalCoalStyle, pdists, kernel_func) (:470-489; third argument = the normalised kernel
+    function, integrals by the fixed `quad_order`-point rule), batched: `pdists` = (dist_types, params) with params a
+    (3N, n) device array of (n, theta, k) in normalised units.  Returns the (nmom, n) device array of normalised
+    tendencies."""
     dist_types, params = pdists
-    plan = coal_data.plan(dist_types, k_range=k_range)
+    if isinstance(cs, NumericalCoalStyle):
+        plan = numerical_plan(dist_types, coal_data, (1.0, 1.0), quad_order, k_range)
+    elif not isinstance(cs, AnalyticalCoalStyle):
+        raise ValueError("Invalid coal style!")
+    else:
+        if isinstance(ts, MovingThreshold) != isinstance(coal_data.ts, MovingThreshold):
+            raise ValueError("threshold style of the call does not match the CoalescenceData")
+        plan = coal_data.plan(dist_types, k_range=k_range)
     ptr, planes, n, ld = as_device(params)
     if planes != 3 * plan.N:
         raise ValueError("params must have 3N planes")

@@ -10,7 +10,9 @@ class CoalescenceStyle(AbstractStyle):
 
 
 class NumericalCoalStyle(CoalescenceStyle):
-    """Nested adaptive quadrature (Coalescence.jl:470-708): not built for the GPU (out of scope)."""
+    """Integrals of a kernel FUNCTION over the densities (Coalescence.jl:470-708).  The reference nests adaptive quadgk;
+    the device path evaluates every integral by one fixed `quad_order`-point Gauss rule per distribution
+    (csrc/quad.hpp; the order is a field of the ODE parameters, default 10)."""
 
 
 class AnalyticalCoalStyle(CoalescenceStyle):

@@ -40,6 +40,11 @@ class PlanDesc(C.Structure):
         ("vel", C.c_double * (MAX_VEL * 2)),
         ("device", C.c_int32),
         ("specialize", C.c_int32),
+        ("coal_style", C.c_int32),
+        ("kernel_func", C.c_int32),
+        ("kernel_func_is_normalized", C.c_int32),
+        ("quad_order", C.c_int32),
+        ("kernel_func_params", C.c_double * 3),
     ]
 
 
@@ -52,6 +57,8 @@ SYMBOLS = {
     "cloudy_plan_specialized": (_i, [_vp]),
     "cloudy_plan_jit_log": (C.c_char_p, [_vp]),
     "cloudy_jit_selfcheck": (_i, [C.POINTER(PlanDesc), C.c_char_p]),
+    "cloudy_plan_desc_layout": (_i, [C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _i]),
+    "cloudy_quad_rule_host": (_i, [_i, C.c_double, C.c_double, _dp, _dp]),
     "cloudy_plan_nmom": (_i, [_vp]),
     "cloudy_plan_nparams": (_i, [_vp]),
     "cloudy_plan_get": (_i, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _dp, _dp, _dp]),
@@ -69,6 +76,8 @@ SYMBOLS = {
     "cloudy_rainshaft_rhs": (_i, [_vp, _sz, _sz, _sz, _vp, C.c_double, _vp, _vp, _vp]),
     "cloudy_rainshaft_ssprk33_steps": (_i, [_vp, _sz, _sz, _sz, _vp, _vp, C.c_double, C.c_double, C.c_int, _vp]),
     "cloudy_moment_sums": (_i, [_vp, _sz, _sz, _i, _vp, _vp, _vp]),
+    "cloudy_moment_sums_workspace_bytes": (_sz, [_i]),
+    "cloudy_moment_sums_ws": (_i, [_vp, _sz, _sz, _i, _vp, _vp, _vp, _sz, _vp]),
     "cloudy_device_count": (_i, []),
     "cloudy_set_device": (_i, [_i]),
     "cloudy_malloc": (_i, [C.POINTER(_vp), _sz]),

@@ -19,9 +19,20 @@ EPS = float(np.finfo(np.float64).eps)
 
 
 def ODEParameters(pdists, coal_data, NProgMoms, norms, **extra):
-    """The ODE_parameters NamedTuple of the examples (e.g. box_gamma_mixture.jl:29-35)."""
+    """The ODE_parameters NamedTuple of the examples (e.g. box_gamma_mixture.jl:29-35; NumericalCoalStyle drivers pass
+    coal_data=None and kernel_func=<normalised kernel function>, Numerical/n_particles_gamma.jl:37-38)."""
     return SimpleNamespace(pdists=tuple(pdists), coal_data=coal_data, NProgMoms=tuple(NProgMoms), norms=tuple(norms),
                            **extra)
+
+
+def _numerical_plan_for(par, dtype=0):
+    from .Coalescence import numerical_plan
+
+    if tuple(nparams(d) for d in par.pdists) != tuple(par.NProgMoms):
+        raise ValueError("NProgMoms must equal nparams of p.pdists")
+    return numerical_plan([d.type_id for d in par.pdists], par.kernel_func, par.norms,
+                          quad_order=getattr(par, "quad_order", 10), k_range=getattr(par, "k_range", (EPS, 10.0)),
+                          dtype=dtype)
 
 
 def _plan_for(par, dtype=0):
@@ -38,15 +49,17 @@ def _plan_for(par, dtype=0):
 def rhs_coal(coal_type, dmom, mom, p, threshold_style, stream=None):
     """rhs_coal! (box_model_helpers.jl:29-53): normalise, invert closures, get_coal_ints, de-normalise --
     one fused HIP kernel per call."""
-    if isinstance(coal_type, NumericalCoalStyle):
-        raise NotImplementedError("NumericalCoalStyle is not built for the GPU; see DESIGN.md")
-    if not isinstance(coal_type, AnalyticalCoalStyle):
+    if not isinstance(coal_type, (AnalyticalCoalStyle, NumericalCoalStyle)):
         raise ValueError("Invalid coal style!")
-    if isinstance(threshold_style, MovingThreshold) != isinstance(p.coal_data.ts, MovingThreshold):
-        raise ValueError("threshold style of the RHS does not match the CoalescenceData")
     if dtype_code(mom) != dtype_code(dmom):
         raise TypeError("mom and dmom must have the same element type")
-    plan = _plan_for(p, dtype_code(mom))  # float32 arrays select a CLOUDY_F32 plan (fp32 planes, fp64 arithmetic)
+    if isinstance(coal_type, NumericalCoalStyle):
+        # get_coal_ints(coal_type, p.pdists, p.kernel_func), box_model_helpers.jl:47-48
+        plan = _numerical_plan_for(p, dtype_code(mom))
+    else:
+        if isinstance(threshold_style, MovingThreshold) != isinstance(p.coal_data.ts, MovingThreshold):
+            raise ValueError("threshold style of the RHS does not match the CoalescenceData")
+        plan = _plan_for(p, dtype_code(mom))  # float32 arrays select a CLOUDY_F32 plan (fp32 planes, fp64 arithmetic)
     mptr, planes, n, ld = as_device(mom)
     dptr, dplanes, dn, dld = as_device(dmom)
     if planes != plan.nmom or dplanes != plan.nmom or dn != n or dld != ld:

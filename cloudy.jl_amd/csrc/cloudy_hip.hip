@@ -12,10 +12,13 @@
 #include <new>
 #include <vector>
 
+#include <map>
 #include <mutex>
 #include <string>
+#include <utility>
 
 #include "host_plan.hpp"
+#include "host_quad.hpp"
 #include "kernels.hpp"
 #include "jit.hpp"
 #include "reduce_kernels.hpp"
@@ -68,8 +71,30 @@ hipError_t dispatch(const HostPlan &h, const LaunchReq &r) {
         {launch_n3_p1, launch_n3_p2, launch_n3_p3, launch_n3_p4, launch_n3_p5},
         {launch_n4_p1, launch_n4_p2, launch_n4_p3, launch_n4_p4, launch_n4_p5}};
     if (h.N < 1 || h.N > CLOUDY_MAX_MODES || h.P < 1 || h.P > CLOUDY_MAX_P) return hipErrorInvalidValue;
+    if (h.coal_style == CLOUDY_NUMERICAL_COAL && r.op == OP_COAL) {
+        static const Fn quad[CLOUDY_MAX_MODES] = {launch_quad_n1, launch_quad_n2, launch_quad_n3, launch_quad_n4};
+        return quad[h.N - 1](h, r);
+    }
     return table[h.N - 1][h.P - 1](h, r);
 }
+
+// A plan belongs to one device (its constant block, node tables and code objects live there): every entry point that
+// launches makes that device current for the call and restores the caller's device on return.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) {
+            err = hipSetDevice(device);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
 
 int check_batch(const cloudy_plan *plan, size_t n, size_t ld, const void *a, const void *b) {
     if (!plan) return fail(CLOUDY_EINVAL, "plan is NULL");
@@ -86,6 +111,12 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
     const void *in = r.in;
     void *out = r.out;
     const unsigned g1 = (unsigned)((n + kBlock - 1) / kBlock);
+    if (h.coal_style == CLOUDY_NUMERICAL_COAL) {
+        void *args[] = {&n, &ld, &in, &out};
+        const unsigned qb = (unsigned)quad_block(h.q.nq);
+        return hipModuleLaunchKernel(plan->jit.quad, (unsigned)((n + qb - 1) / qb), 1, 1, qb, 1, 1, 0, r.stream, args,
+                                     nullptr);
+    }
     if (r.op == OP_SSPRK33) {
         double dt = r.dt;
         int n_steps = r.n_steps;
@@ -123,7 +154,14 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
 }
 
 int run(const cloudy_plan *plan, const LaunchReq &r) {
+    if (plan->h.coal_style == CLOUDY_NUMERICAL_COAL &&
+        (r.op == OP_FINITE_2D || r.op == OP_SSPRK33 || r.op == OP_RAINSHAFT_SSPRK33 || r.rainshaft))
+        return fail(CLOUDY_EUNSUPPORTED,
+                    "NumericalCoalStyle plans serve cloudy_coal_rhs / cloudy_get_coal_ints and the per-mode diagnostics; "
+                    "thresholds, the rainshaft body and the fused integrators belong to AnalyticalCoalStyle plans");
     if (r.n == 0) return CLOUDY_OK;
+    DeviceGuard guard(plan->h.device);
+    if (guard.err != hipSuccess) return fail_hip(guard.err, "selecting the plan's device");
     bool use_jit = plan->jit_on && r.input_kind == IN_MOMENTS && r.physical_out &&
                    (r.op == OP_COAL || (r.op == OP_SSPRK33 && !r.rainshaft));
     if (use_jit && r.op == OP_COAL && r.rainshaft) {
@@ -163,6 +201,8 @@ void cloudy_plan_desc_init(cloudy_plan_desc *d) {
     for (int i = 0; i < CLOUDY_MAX_MODES; ++i) d->dist_thresholds[i] = INFINITY;
     d->dtype = CLOUDY_F64;
     d->device = -1;
+    d->coal_style = CLOUDY_ANALYTICAL_COAL;
+    d->quad_order = 10;
 }
 
 }  // extern "C"
@@ -177,10 +217,25 @@ int build_host_plan(const cloudy_plan_desc *d, cloudy_plan **out, std::vector<do
     if (d->struct_size != sizeof(cloudy_plan_desc))
         return fail(CLOUDY_EINVAL, "struct_size %u != %zu (call cloudy_plan_desc_init)", d->struct_size,
                     sizeof(cloudy_plan_desc));
-    const int N = d->n_modes, P = d->tensor_p;
+    if (d->coal_style != CLOUDY_ANALYTICAL_COAL && d->coal_style != CLOUDY_NUMERICAL_COAL)
+        return fail(CLOUDY_EINVAL, "Invalid coal style!");  // box_model_helpers.jl:49-50
+    const bool numerical = d->coal_style == CLOUDY_NUMERICAL_COAL;
+    const int N = d->n_modes, P = numerical ? 1 : d->tensor_p;
     if (N < 1 || N > CLOUDY_MAX_MODES) return fail(CLOUDY_EUNSUPPORTED, "n_modes %d outside 1..%d", N, CLOUDY_MAX_MODES);
     if (P < 1 || P > CLOUDY_MAX_P) return fail(CLOUDY_EUNSUPPORTED, "tensor_p %d outside 1..%d", P, CLOUDY_MAX_P);
-    if (!d->kernel_c) return fail(CLOUDY_EINVAL, "kernel_c is NULL");
+    if (!numerical && !d->kernel_c) return fail(CLOUDY_EINVAL, "kernel_c is NULL");
+    if (numerical) {
+        if (d->kernel_func < CLOUDY_KFUNC_CONSTANT || d->kernel_func > CLOUDY_KFUNC_LONG)
+            return fail(CLOUDY_EINVAL, "kernel_func %d is not a CoalescenceKernelFunction family", d->kernel_func);
+        if (d->quad_order < 2 || d->quad_order > CLOUDY_MAX_QUAD)
+            return fail(CLOUDY_EUNSUPPORTED, "quad_order %d outside 2..%d", d->quad_order, CLOUDY_MAX_QUAD);
+        if (d->dtype == CLOUDY_F32_FAST)
+            return fail(CLOUDY_EUNSUPPORTED, "CLOUDY_F32_FAST is the single-precision Simpson pass of threshold plans");
+        for (int i = 0; i < N; ++i)
+            if (d->dist_type[i] == CLOUDY_DIST_MONODISPERSE)
+                return fail(CLOUDY_EINVAL, "no method normed_density_func for a Monodisperse distribution "
+                                           "(weighting_fn, Coalescence.jl:624-642)");
+    }
     if (d->dtype != CLOUDY_F64 && d->dtype != CLOUDY_F32 && d->dtype != CLOUDY_F32_FAST)
         return fail(CLOUDY_EINVAL, "bad dtype");
     if (!(d->norms[0] > 0) || !(d->norms[1] > 0))
@@ -224,6 +279,50 @@ int build_host_plan(const cloudy_plan_desc *d, cloudy_plan **out, std::vector<do
     }
     h.nmom = off;
 
+    if (numerical) {
+        // get_normalized_kernel_func, KernelFunctions.jl:124-154
+        h.coal_style = CLOUDY_NUMERICAL_COAL;
+        h.q.kind = d->kernel_func;
+        const double *kp = d->kernel_func_params;
+        const double n0 = d->kernel_func_is_normalized ? 1.0 : d->norms[0], m0 = d->kernel_func_is_normalized ? 1.0 : d->norms[1];
+        h.q.kf[0] = h.q.kf[1] = h.q.kf[2] = 0.0;
+        switch (d->kernel_func) {
+        case CLOUDY_KFUNC_CONSTANT: h.q.kf[0] = kp[0] * n0; break;
+        case CLOUDY_KFUNC_LINEAR: h.q.kf[0] = kp[0] * n0 * m0; break;
+        case CLOUDY_KFUNC_HYDRODYNAMIC: h.q.kf[0] = kp[0] * n0 * std::pow(m0, 4.0 / 3.0); break;
+        default:
+            h.q.kf[0] = kp[0] / m0;
+            h.q.kf[1] = kp[1] * n0 * (m0 * m0);
+            h.q.kf[2] = kp[2] * n0 * m0;
+        }
+        for (int k = 0; k < 3; ++k)
+            if (std::isnan(h.q.kf[k])) {
+                delete p;
+                return fail(CLOUDY_EINVAL, "kernel_func_params[%d] is NaN", k);
+            }
+        // start-value table of the per-parcel Gauss-Laguerre rules over k in (0, max(k_range[1], 1)] (Exponential: k = 1)
+        std::string msg;
+        if (!quad_host::build_table(d->quad_order, std::fmax(d->k_range[1], 1.0), h.q, h.qtab, msg)) {
+            delete p;
+            return fail(CLOUDY_EUNSUPPORTED, "%s", msg.c_str());
+        }
+        h.n_mom_max = np_max;
+        for (int i = 0; i < N; ++i) {
+            h.n_2d[i] = 0;
+            h.thr[i] = INFINITY;
+        }
+        h.mode = MODE_ALLINF;
+        h.n_vel = d->n_vel;
+        for (int v = 0; v < d->n_vel; ++v) {
+            h.vel[v][0] = d->vel[v][0];
+            h.vel[v][1] = d->vel[v][1];
+            h.vel_n[v][0] = d->vel[v][0] * std::pow(d->norms[1], d->vel[v][1]);
+            h.vel_n[v][1] = d->vel[v][1];
+        }
+        nodes.clear();
+        *out = p;
+        return CLOUDY_OK;
+    }
     // kernels: check_symmetry (KernelTensors.jl:157-171) + get_normalized_kernel_tensor (:189-199)
     for (int j = 0; j < N; ++j)
         for (int k = 0; k < N; ++k) {
@@ -357,14 +456,14 @@ int cloudy_plan_create(const cloudy_plan_desc *d, cloudy_plan **out) {
             delete p;
             return fail(CLOUDY_EINVAL, "device %d out of range (%d devices)", d->device, ndev);
         }
-        e = hipSetDevice(d->device);
-        if (e != hipSuccess) {
-            delete p;
-            return fail_hip(e, "hipSetDevice");
-        }
         h.device = d->device;
     } else {
         (void)hipGetDevice(&h.device);
+    }
+    DeviceGuard guard(h.device);  // the caller's current device is restored on every return path
+    if (guard.err != hipSuccess) {
+        delete p;
+        return fail_hip(guard.err, "hipSetDevice");
     }
     {
         const char *e = std::getenv("CLOUDY_HIP_PPL1");
@@ -377,6 +476,15 @@ int cloudy_plan_create(const cloudy_plan_desc *d, cloudy_plan **out) {
         if (e != hipSuccess) {
             cloudy_plan_destroy(p);
             return fail_hip(e, "node table upload");
+        }
+    }
+    if (!h.qtab.empty()) {
+        e = hipMalloc((void **)&h.qtab_dev, h.qtab.size() * sizeof(double));
+        if (e == hipSuccess)
+            e = hipMemcpy(h.qtab_dev, h.qtab.data(), h.qtab.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            cloudy_plan_destroy(p);
+            return fail_hip(e, "rule table upload");
         }
     }
     e = hipMalloc((void **)&h.partial_dev, sizeof(double) * kSumBlocks * (CLOUDY_MAX_MOMENTS + 64));
@@ -425,9 +533,10 @@ int cloudy_jit_selfcheck(const cloudy_plan_desc *d, const char *arch) {
     std::string log;
     std::vector<char> code;
     const std::string a = (arch && *arch) ? arch : "gfx950";
-    bool ok = jit_compile(jit_source(p->h, 0), a, p->h.mode == MODE_ALLINF, code, log);
-    if (ok && p->h.mode != MODE_ALLINF) ok = jit_compile(jit_source(p->h, 1), a, true, code, log);
-    if (ok) ok = jit_compile(jit_source(p->h, 2), a, false, code, log);  // rainshaft cell body
+    const bool numerical = p->h.coal_style == CLOUDY_NUMERICAL_COAL;
+    bool ok = jit_compile(jit_source(p->h, 0), a, !numerical && p->h.mode == MODE_ALLINF, code, log);
+    if (ok && !numerical && p->h.mode != MODE_ALLINF) ok = jit_compile(jit_source(p->h, 1), a, true, code, log);
+    if (ok && !numerical) ok = jit_compile(jit_source(p->h, 2), a, false, code, log);  // rainshaft cell body
     delete p;
     if (!ok) return fail(CLOUDY_EUNSUPPORTED, "plan-time compilation failed: %.440s", log.c_str());
     return CLOUDY_OK;
@@ -438,7 +547,52 @@ void cloudy_plan_destroy(cloudy_plan *plan) {
     if (plan->h.nodes_dev) (void)hipFree(plan->h.nodes_dev);
     if (plan->h.partial_dev) (void)hipFree(plan->h.partial_dev);
     if (plan->h.kargs_dev) (void)hipFree(plan->h.kargs_dev);
+    if (plan->h.qtab_dev) (void)hipFree(plan->h.qtab_dev);
     delete plan;
+}
+
+int cloudy_plan_desc_layout(const char **names, uint32_t *offsets, uint32_t *sizes, int cap) {
+    struct Field {
+        const char *name;
+        size_t off, size;
+    };
+#define CLOUDY_FIELD(f) {#f, offsetof(cloudy_plan_desc, f), sizeof(((cloudy_plan_desc *)nullptr)->f)}
+    static const Field fields[] = {
+        CLOUDY_FIELD(struct_size), CLOUDY_FIELD(n_modes), CLOUDY_FIELD(dist_type), CLOUDY_FIELD(tensor_p),
+        CLOUDY_FIELD(kernel_layout), CLOUDY_FIELD(kernel_is_normalized), CLOUDY_FIELD(kernel_c),
+        CLOUDY_FIELD(dist_thresholds), CLOUDY_FIELD(threshold_style), CLOUDY_FIELD(norms), CLOUDY_FIELD(k_range),
+        CLOUDY_FIELD(n_bins_per_log_unit), CLOUDY_FIELD(dtype), CLOUDY_FIELD(n_vel), CLOUDY_FIELD(vel),
+        CLOUDY_FIELD(device), CLOUDY_FIELD(specialize), CLOUDY_FIELD(coal_style), CLOUDY_FIELD(kernel_func),
+        CLOUDY_FIELD(kernel_func_is_normalized), CLOUDY_FIELD(quad_order), CLOUDY_FIELD(kernel_func_params)};
+#undef CLOUDY_FIELD
+    const int nf = (int)(sizeof(fields) / sizeof(fields[0]));
+    for (int i = 0; i < nf && i < cap; ++i) {
+        if (names) names[i] = fields[i].name;
+        if (offsets) offsets[i] = (uint32_t)fields[i].off;
+        if (sizes) sizes[i] = (uint32_t)fields[i].size;
+    }
+    return nf;
+}
+
+int cloudy_quad_rule_host(int quad_order, double k_hi, double k, double *u, double *W) {
+    if (quad_order < 2 || quad_order > CLOUDY_MAX_QUAD) return fail(CLOUDY_EUNSUPPORTED, "quad_order outside 2..%d", CLOUDY_MAX_QUAD);
+    if (!u || !W) return fail(CLOUDY_EINVAL, "u / W is NULL");
+    if (!(k_hi >= 1.0) || !(k > 0.0) || !(k <= k_hi)) return fail(CLOUDY_EINVAL, "need k_hi >= 1 and 0 < k <= k_hi");
+    // one table per (order, k_hi) for the life of the process, as a plan would hold it
+    static std::mutex mu;
+    static std::map<std::pair<int, double>, std::pair<QArgs, std::vector<double>>> tables;
+    std::lock_guard<std::mutex> lock(mu);
+    auto key = std::make_pair(quad_order, k_hi);
+    auto it = tables.find(key);
+    if (it == tables.end()) {
+        QArgs q = {};
+        std::vector<double> tab;
+        std::string msg;
+        if (!quad_host::build_table(quad_order, k_hi, q, tab, msg)) return fail(CLOUDY_EUNSUPPORTED, "%s", msg.c_str());
+        it = tables.emplace(key, std::make_pair(q, std::move(tab))).first;
+    }
+    gamma_rule<0>(it->second.first, it->second.second.data(), k, u, W);
+    return CLOUDY_OK;
 }
 
 int cloudy_plan_nmom(const cloudy_plan *plan) { return plan ? plan->h.nmom : fail(CLOUDY_EINVAL, "plan is NULL"); }
@@ -585,6 +739,8 @@ int cloudy_rainshaft_rhs(const cloudy_plan *plan, size_t nz, size_t n_columns, s
     if (nz < 1 || !(dz > 0)) return fail(CLOUDY_EINVAL, "nz must be >= 1 and dz positive");
     rc = cloudy_rainshaft_sources(plan, n, ld, mom_dev, rhs_dev, flux_work_dev, stream);
     if (rc || n == 0) return rc;
+    DeviceGuard guard(plan->h.device);
+    if (guard.err != hipSuccess) return fail_hip(guard.err, "selecting the plan's device");
     const unsigned g = (unsigned)((n + kBlock - 1) / kBlock);
     if (plan->h.dtype != CLOUDY_F64)
         hipLaunchKernelGGL(rainshaft_divergence_kernel<float>, dim3(g), dim3(kBlock), 0, (hipStream_t)stream, n, ld,
@@ -620,25 +776,43 @@ int cloudy_rainshaft_ssprk33_steps(const cloudy_plan *plan, size_t nz, size_t n_
     return run(plan, r);
 }
 
-int cloudy_moment_sums(const cloudy_plan *plan, size_t n, size_t ld, int planes, const void *arr_dev, double *sums_dev,
-                       void *stream) {
+size_t cloudy_moment_sums_workspace_bytes(int planes) {
+    return planes < 1 ? 0 : sizeof(double) * (size_t)kSumBlocks * (size_t)planes;
+}
+
+int cloudy_moment_sums_ws(const cloudy_plan *plan, size_t n, size_t ld, int planes, const void *arr_dev, double *sums_dev,
+                          void *workspace_dev, size_t workspace_bytes, void *stream) {
     if (!plan) return fail(CLOUDY_EINVAL, "plan is NULL");
     if (planes < 1 || planes > CLOUDY_MAX_MOMENTS + 64) return fail(CLOUDY_EINVAL, "planes out of range");
     if (ld < n) return fail(CLOUDY_EINVAL, "ld must be >= n_parcels");
     if (!sums_dev || (n > 0 && !arr_dev)) return fail(CLOUDY_EINVAL, "device buffer is NULL");
+    if (!workspace_dev || workspace_bytes < cloudy_moment_sums_workspace_bytes(planes))
+        return fail(CLOUDY_EINVAL, "workspace must hold cloudy_moment_sums_workspace_bytes(planes) = %zu bytes",
+                    cloudy_moment_sums_workspace_bytes(planes));
+    DeviceGuard guard(plan->h.device);
+    if (guard.err != hipSuccess) return fail_hip(guard.err, "selecting the plan's device");
     size_t blocks = (n + kBlock - 1) / kBlock;
     if (blocks > (size_t)kSumBlocks) blocks = kSumBlocks;
     if (blocks < 1) blocks = 1;
+    double *partial = static_cast<double *>(workspace_dev);
     if (plan->h.dtype != CLOUDY_F64)
         hipLaunchKernelGGL(plane_partial_sums_kernel<float>, dim3((unsigned)blocks), dim3(kBlock), 0,
-                           (hipStream_t)stream, n, ld, planes, (const float *)arr_dev, plan->h.partial_dev);
+                           (hipStream_t)stream, n, ld, planes, (const float *)arr_dev, partial);
     else
         hipLaunchKernelGGL(plane_partial_sums_kernel<double>, dim3((unsigned)blocks), dim3(kBlock), 0,
-                           (hipStream_t)stream, n, ld, planes, (const double *)arr_dev, plan->h.partial_dev);
+                           (hipStream_t)stream, n, ld, planes, (const double *)arr_dev, partial);
     hipLaunchKernelGGL(plane_final_sums_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, (int)blocks, planes,
-                       (const double *)plan->h.partial_dev, sums_dev);
+                       (const double *)partial, sums_dev);
     HIP_TRY(hipGetLastError());
     return CLOUDY_OK;
+}
+
+int cloudy_moment_sums(const cloudy_plan *plan, size_t n, size_t ld, int planes, const void *arr_dev, double *sums_dev,
+                       void *stream) {
+    if (!plan) return fail(CLOUDY_EINVAL, "plan is NULL");
+    // the plan's own workspace: one reduction at a time per plan (header); cloudy_moment_sums_ws is the re-entrant form
+    return cloudy_moment_sums_ws(plan, n, ld, planes, arr_dev, sums_dev, plan->h.partial_dev,
+                                 sizeof(double) * kSumBlocks * (CLOUDY_MAX_MOMENTS + 64), stream);
 }
 
 int cloudy_coal_rhs_host(const cloudy_plan *plan, size_t n, size_t ld, const void *mom_host, void *dmom_host) {
@@ -646,6 +820,8 @@ int cloudy_coal_rhs_host(const cloudy_plan *plan, size_t n, size_t ld, const voi
     if (rc) return rc;
     if (n == 0) return CLOUDY_OK;
     const size_t bytes = (size_t)plan->h.nmom * ld * (plan->h.dtype != CLOUDY_F64 ? sizeof(float) : sizeof(double));
+    DeviceGuard guard(plan->h.device);
+    if (guard.err != hipSuccess) return fail_hip(guard.err, "selecting the plan's device");
     char *buf = nullptr;
     HIP_TRY(hipMalloc((void **)&buf, 2 * bytes));
     hipError_t e = hipMemcpy(buf, mom_host, bytes, hipMemcpyHostToDevice);

@@ -5,7 +5,10 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "../../include/cloudy_hip.h"
+#include "quad.hpp"
 
 namespace cloudy {
 
@@ -29,6 +32,11 @@ struct HostPlan {
     int n_nodes = 0;
     double *partial_dev = nullptr;                      // moment_sums workspace
     void *kargs_dev = nullptr;                          // KArgs<N,P> of (moments in, physical out) followed by SediArgs, uploaded at plan creation
+    // NumericalCoalStyle plans (quad.hpp): P = 1, no tensors, no thresholds
+    int coal_style = 0;                                 // CLOUDY_ANALYTICAL_COAL / CLOUDY_NUMERICAL_COAL
+    QArgs q = {};                                       // kernel function (normalised), rule order, start-value table shape
+    std::vector<double> qtab;                           // quad_tab_size(q.nq, q.deg) doubles (host copy: the plan-time compiled kernel embeds it)
+    double *qtab_dev = nullptr;
 };
 
 enum Op { OP_COAL = 0, OP_UPDATE_DIST = 1, OP_FINITE_2D = 2, OP_SEDI = 3, OP_SSPRK33 = 4, OP_COND = 5, OP_PREPARE = 6 /* plan creation: upload the constant block */, OP_NQ = 7, OP_RAINSHAFT_SSPRK33 = 8 };
@@ -77,5 +85,10 @@ hipError_t launch_n4_p2(const HostPlan &h, const LaunchReq &r);
 hipError_t launch_n4_p3(const HostPlan &h, const LaunchReq &r);
 hipError_t launch_n4_p4(const HostPlan &h, const LaunchReq &r);
 hipError_t launch_n4_p5(const HostPlan &h, const LaunchReq &r);
+// cloudy_coal_rhs / cloudy_get_coal_ints of a NumericalCoalStyle plan, ahead-of-time kernels (quad_n<N>.hip)
+hipError_t launch_quad_n1(const HostPlan &h, const LaunchReq &r);
+hipError_t launch_quad_n2(const HostPlan &h, const LaunchReq &r);
+hipError_t launch_quad_n3(const HostPlan &h, const LaunchReq &r);
+hipError_t launch_quad_n4(const HostPlan &h, const LaunchReq &r);
 
 }  // namespace cloudy

@@ -1,0 +1,34 @@
+// launch_quad_impl.hpp -- ahead-of-time kernels of the NumericalCoalStyle plans for one N (quad_n<N>.hip): every kernel
+// function family x both plane types, run-time rule order.  The plan-time compiled kernels (jit.hpp) are the fast path.
+#pragma once
+#include "launch_impl.hpp"
+#include "quad_kernels.hpp"
+
+namespace cloudy {
+
+template <int N, int KIND, typename TIO>
+hipError_t launch_quad_io(const HostPlan &h, const LaunchReq &r, const KArgs<N, 1> &A) {
+    hipLaunchKernelGGL((coal_rhs_quad_kernel<N, KIND, TIO>), dim3(grid_for(r.n, true)), dim3(kBlock), 0, r.stream, A, h.q,
+                       h.qtab_dev, r.n, r.ld, static_cast<const TIO *>(r.in), static_cast<TIO *>(r.out));
+    return hipGetLastError();
+}
+
+template <int N>
+hipError_t launch_quad(const HostPlan &h, const LaunchReq &r) {
+    if (r.op != OP_COAL || h.P != 1 || !h.qtab_dev) return hipErrorInvalidValue;
+    KArgs<N, 1> A;
+    fill_args<N, 1>(h, r, A);
+    const bool f32 = h.dtype != CLOUDY_F64 && r.input_kind == IN_MOMENTS;  // (n, theta, k) planes are always fp64
+    switch (h.q.kind) {
+#define CLOUDY_QUAD_CASE(K) \
+    case K: return f32 ? launch_quad_io<N, K, float>(h, r, A) : launch_quad_io<N, K, double>(h, r, A);
+        CLOUDY_QUAD_CASE(KF_CONSTANT)
+        CLOUDY_QUAD_CASE(KF_LINEAR)
+        CLOUDY_QUAD_CASE(KF_HYDRODYNAMIC)
+        CLOUDY_QUAD_CASE(KF_LONG)
+#undef CLOUDY_QUAD_CASE
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace cloudy

@@ -1,0 +1,199 @@
+// quad_kernels.hpp -- the kernel behind cloudy_coal_rhs / cloudy_get_coal_ints of a NumericalCoalStyle plan
+// (quad.hpp states the rule; reference: src/Sources/Coalescence.jl:470-708).
+//
+// One lane owns one parcel, as everywhere (kernels.hpp): load -> normalise -> closure inversion -> the Gauss rule of
+// every mode (nodes and weights in registers when the kernel is compiled for its plan) -> pair sums -> store.
+//
+// Algebra.  With Kab = K(x^j_a, x^k_b) v^j_a v^k_b (v = n W) and, per unordered pair of modes,
+//     s0 = sum Kab,  sa = sum Kab x^j_a,  saa = sum Kab (x^j_a)^2,  sab = sum Kab x^j_a x^k_b,
+// the reference's  sum_j Q[m][j,k] - sum_j R[m][j,k]  (:478-487) is, order by order (m = 0, 1, 2),
+//     pair j < k:   mode k gains (0, sa, saa + 2 sab)   [Q_jk - R_jk: the terms in x^k_b alone cancel],
+//                   mode j loses (s0, sa, saa)          [R_kj],
+//     pair j = k:   S_1 + S_2 - R_kk = (-s0/2, 0, sab)  [mass conservation is exact in the discrete rule],
+// and the self collisions that weighting_fn (:624-642) assigns to the next mode,
+//     T_m = S_2k^(m) = 1/2 sum_ab Kab (x_a + x_b)^m (1 - w(x_a + x_b, k)),
+// move from mode k to mode k + 1 (for the last mode w == 1).  The products common to Q and R are never formed, as in
+// the tensor kernels (kernels.hpp, pair_terms).  1 - w is evaluated from density RATIOS against the mode's own density,
+//     1 - w = sum_{j > k} rho_j / (1 + sum_{j != k} rho_j),   rho_j = g_j(x) / g_k(x) = exp(ln g_j - ln g_k),
+// which needs N - 1 exponentials per point instead of N and cannot underflow to 0 / 0 at a mode's own nodes.
+#pragma once
+#include "kernels.hpp"
+#include "quad.hpp"
+
+namespace cloudy {
+
+// ln of the normed density (ParticleDistributions.jl:363-388) at x given lx = ln x:
+//   Gamma / Exponential: (k - 1) lx - x / theta - [ln Gamma(k) + k ln theta];  Lognormal (theta = mu, k = sigma):
+//   -(lx - mu)^2 / (2 sigma^2) - lx - ln(sigma sqrt(2 pi))
+struct LogDensity {
+    double a, b, c;   // Gamma: a = k - 1, b = 1 / theta, c = lnGamma(k) + k ln theta;  Lognormal: a = mu, b = 1/(2 sigma^2), c = ln(sigma sqrt(2 pi))
+    bool lognormal;
+    __device__ __forceinline__ double operator()(double x, double lx) const {
+        if (lognormal) {
+            const double d = lx - a;
+            return -(d * d) * b - lx - c;
+        }
+        return fma(a, lx, -(x * b)) - c;
+    }
+};
+
+template <int N, int KIND, int NQ, typename TIO>
+__device__ __forceinline__ void coal_rhs_quad_body(const KArgs<N, 1> &A, const QArgs &Q, const double *__restrict__ tab,
+                                                   size_t n, size_t ld, const TIO *__restrict__ in,
+                                                   TIO *__restrict__ out) {
+    constexpr int NQA = NQ ? NQ : kQuadMax;
+    constexpr int QB = NQ ? quad_block(NQ) : kBlock;
+    const int nq = NQ ? NQ : Q.nq;
+    const int t = threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * QB + t;
+    if (i >= n) return;
+    double nn[N], th[N], kk[N];
+    load_parcel<N, 1, TIO>(A, i, ld, in, nn, th, kk);
+    // ---- the rule of every mode: aux (x or x^(1/3)) and v = n W
+    double X[N][NQA], V[N][NQA];
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        if (A.dist_type[m] == DIST_LOGNORMAL) {  // wave-uniform
+            const double *gh = tab + nq * (Q.deg + 1);
+            const double s2 = 1.4142135623730951 * kk[m];
+#pragma unroll
+            for (int a = 0; a < nq; ++a) {
+                X[m][a] = kf_aux<KIND>(exp(fma(s2, gh[a], th[m])));
+                V[m][a] = nn[m] * gh[nq + a];
+            }
+        } else {
+            double u[NQA], W[NQA];
+            gamma_rule<NQ>(Q, tab, kk[m], u, W);
+#pragma unroll
+            for (int a = 0; a < nq; ++a) {
+                X[m][a] = kf_aux<KIND>(th[m] * u[a]);
+                V[m][a] = nn[m] * W[a];
+            }
+        }
+    }
+    double acc[N][3];
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.0;
+    const double ksc = kf_scale<KIND>(Q);
+    LogDensity lg[N];
+    if (N > 1) {
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+            lg[m].lognormal = A.dist_type[m] == DIST_LOGNORMAL;
+            if (lg[m].lognormal) {
+                lg[m].a = th[m];
+                lg[m].b = 0.5 / (kk[m] * kk[m]);
+                lg[m].c = log_pos(kk[m] * 2.5066282746310002);
+            } else {
+                lg[m].a = kk[m] - 1.0;
+                lg[m].b = 1.0 / th[m];
+                lg[m].c = fma(kk[m], log_pos(th[m]), lgamma_pos(kk[m]));
+            }
+        }
+    }
+    // Mode j in turn is the OUTER mode: its nodes are parked in the lane's own LDS slots (sh_x[a][t]: conflict-free, no
+    // barrier -- a lane only reads what it wrote) and walked by ROLLED loops, first against itself (the self collisions:
+    // a log and N - 1 exponentials per point -- unrolled that is ~150 KB of code), then against every mode k > j, whose
+    // nodes are register operands of the unrolled inner loop.  Rolled outer loops keep the code small and stop the
+    // compiler from hoisting per-node subexpressions of ALL modes at once (measured: 350-500 VGPRs, up to 1400 spills
+    // for the Long family, when everything was unrolled).  After its turn a mode's registers are dead.  The
+    // ahead-of-time kernel (run-time point count) indexes its scratch-resident arrays instead of LDS.
+    __shared__ double sh_x[NQ ? NQ : 1][QB], sh_v[NQ ? NQ : 1][QB];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        if (NQ) {
+#pragma unroll
+            for (int a = 0; a < nq; ++a) {
+                sh_x[a][t] = X[j][a];
+                sh_v[a][t] = V[j][a];
+            }
+        }
+        // ---- self collisions of mode j
+        {
+            double s0 = 0.0, sab = 0.0, T0 = 0.0, T1 = 0.0, T2 = 0.0;
+#pragma unroll 1
+            for (int a = 0; a < nq; ++a) {
+                const double Xa = NQ ? sh_x[a][t] : X[j][a], va = NQ ? sh_v[a][t] : V[j][a];
+                const double xa = kf_x<KIND>(Xa);
+#pragma unroll 1
+                for (int b = a; b < nq; ++b) {
+                    const double Xb = NQ ? sh_x[b][t] : X[j][b], vb = NQ ? sh_v[b][t] : V[j][b];
+                    const double xb = kf_x<KIND>(Xb);
+                    // Kab + Kba = 2 Kab for a < b (K is symmetric)
+                    const double Kab = kf_eval<KIND>(Q, Xa, Xb) * (va * vb) * (a == b ? 1.0 : 2.0);
+                    s0 += Kab;
+                    sab = fma(Kab, xa * xb, sab);
+                    if (j < N - 1) {
+                        const double xs = xa + xb, lx = log_pos(xs);
+                        const double own = lg[j](xs, lx);
+                        double up = 0.0, den = 1.0;
+#pragma unroll
+                        for (int m = 0; m < N; ++m) {
+                            if (m == j) continue;
+                            const double rho = exp(fmin(lg[m](xs, lx) - own, 700.0));
+                            den += rho;
+                            if (m > j) up += rho;
+                        }
+                        const double h = 0.5 * Kab * (up * quad_recip(den));  // 1/2 Kab (1 - w)
+                        T0 += h;
+                        T1 = fma(h, xs, T1);
+                        T2 = fma(h * xs, xs, T2);
+                    }
+                }
+            }
+            acc[j][0] -= fma(0.5, s0, T0);
+            acc[j][1] -= T1;
+            acc[j][2] += sab - T2;
+            if (j < N - 1) {
+                acc[j + 1][0] += T0;
+                acc[j + 1][1] += T1;
+                acc[j + 1][2] += T2;
+            }
+        }
+        // ---- pairs (j, k > j)
+#pragma unroll
+        for (int k = j + 1; k < N; ++k) {
+            double s0 = 0.0, sa = 0.0, saa = 0.0, sab = 0.0;
+#pragma unroll 1
+            for (int a = 0; a < nq; ++a) {
+                const double Xa = NQ ? sh_x[a][t] : X[j][a], va = NQ ? sh_v[a][t] : V[j][a];
+                const double xa = kf_x<KIND>(Xa);
+                double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+                for (int b = 0; b < nq; ++b) {
+                    const double Kv = kf_eval<KIND>(Q, Xa, X[k][b]) * V[k][b];
+                    t0 += Kv;
+                    t1 = fma(Kv, kf_x<KIND>(X[k][b]), t1);
+                }
+                const double w0 = va * t0, w1 = w0 * xa;
+                s0 += w0;
+                sa += w1;
+                saa = fma(w1, xa, saa);
+                sab = fma(va * xa, t1, sab);
+            }
+            acc[j][0] -= s0;
+            acc[j][1] -= sa;
+            acc[j][2] -= saa;
+            acc[k][1] += sa;
+            acc[k][2] += fma(2.0, sab, saa);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int off = A.off[k];
+        st_stream(out + (size_t)(off + 0) * ld + i, acc[k][0] * (ksc * A.out_scale[3 * k + 0]));
+        st_stream(out + (size_t)(off + 1) * ld + i, acc[k][1] * (ksc * A.out_scale[3 * k + 1]));
+        if (A.np[k] == 3) st_stream(out + (size_t)(off + 2) * ld + i, acc[k][2] * (ksc * A.out_scale[3 * k + 2]));
+    }
+}
+
+// ahead-of-time instance: run-time point count, the rule arrays in scratch (the plan-time compiled kernel of jit.hpp
+// has them in registers)
+template <int N, int KIND, typename TIO>
+__global__ void __launch_bounds__(kBlock)
+    coal_rhs_quad_kernel(const KArgs<N, 1> A, const QArgs Q, const double *__restrict__ tab, size_t n, size_t ld,
+                         const TIO *__restrict__ in, TIO *__restrict__ out) {
+    coal_rhs_quad_body<N, KIND, 0, TIO>(A, Q, tab, n, ld, in, out);
+}
+
+}  // namespace cloudy

@@ -13,6 +13,10 @@
  *                                    test/examples/utils/box_model_helpers.jl:22-53
  *   cloudy_get_coal_ints          <- get_coal_ints(::AnalyticalCoalStyle, pdists, coal_data[, ::MovingThreshold])
  *                                    src/Sources/Coalescence.jl:115-185
+ *   (coal_style = CLOUDY_NUMERICAL_COAL: the same two entry points are
+ *    rhs_coal!(NumericalCoalStyle(), dm, m, par, ts) with par.kernel_func, box_model_helpers.jl:47-48, and
+ *    get_coal_ints(::NumericalCoalStyle, pdists, kernel_func), src/Sources/Coalescence.jl:470-489 -- with a fixed
+ *    Gauss rule in place of the reference's adaptive quadgk, see cloudy_plan_desc.quad_order)
  *   cloudy_update_dist_from_moments <- update_dist_from_moments(pdist, moments)
  *                                    src/ParticleDistributions/ParticleDistributions.jl:456-476, 512-523
  *   cloudy_finite_2d_integrals    <- get_finite_2d_integrals / moment_source_helper
@@ -41,7 +45,13 @@
  *
  * Ownership: the caller owns every buffer; a plan owns only its constant block and a small reduction
  * workspace (used by cloudy_moment_sums: do not run that call concurrently on ONE plan from several
- * streams; every other batched call only reads the plan and may).  No call allocates, except the
+ * streams -- cloudy_moment_sums_ws takes the workspace from the caller and is re-entrant; every other batched
+ * call only reads the plan and may run concurrently).
+ *
+ * Devices: a plan belongs to the device it was created on (desc.device, or the caller's current device): its constant
+ * block, node tables and plan-time compiled code objects live there.  Every batched call makes that device current
+ * for the duration of the call and restores the caller's current device before returning, as does
+ * cloudy_plan_create; `stream` and all buffers must belong to the plan's device.  No call allocates, except the
  * host-pointer convenience cloudy_coal_rhs_host.  All device entry points are asynchronous on `stream` (a hipStream_t passed as
  * void*; NULL = the default stream).  Errors: int status, never a C++ exception; the message
  * of the last failure on the calling thread is cloudy_last_error().
@@ -71,6 +81,12 @@ enum { CLOUDY_DIST_EXPONENTIAL = 0, CLOUDY_DIST_GAMMA = 1, CLOUDY_DIST_MONODISPE
 /* EquationTypes.jl:20-22 */
 enum { CLOUDY_FIXED_THRESHOLD = 0, CLOUDY_MOVING_THRESHOLD = 1 };
 enum { CLOUDY_F64 = 0, CLOUDY_F32 = 1, CLOUDY_F32_FAST = 2 };
+/* EquationTypes.jl:15-16 */
+enum { CLOUDY_ANALYTICAL_COAL = 0, CLOUDY_NUMERICAL_COAL = 1 };
+/* CoalescenceKernelFunction families, KernelFunctions.jl:39-86; parameters in cloudy_plan_desc.kernel_func_params:
+ * (coll_coal_rate) | (coll_coal_rate) | (coal_eff) | (x_threshold, coal_rate_below_threshold, coal_rate_above_threshold) */
+enum { CLOUDY_KFUNC_CONSTANT = 0, CLOUDY_KFUNC_LINEAR = 1, CLOUDY_KFUNC_HYDRODYNAMIC = 2, CLOUDY_KFUNC_LONG = 3 };
+#define CLOUDY_MAX_QUAD 32  /* points of the fixed Gauss rule per distribution */
 /* layout of cloudy_plan_desc.kernel_c */
 enum { CLOUDY_KERNEL_SINGLE = 0 /* [P][P] shared by all pairs, Coalescence.jl:89-104 */,
        CLOUDY_KERNEL_MATRIX = 1 /* [N][N][P][P], Coalescence.jl:55-87 */ };
@@ -115,10 +131,23 @@ typedef struct cloudy_plan_desc {
                                                 compile-time constants: 0 = when available (default; the
                                                 environment variable CLOUDY_HIP_JIT=0 turns it off), 1 = required
                                                 (plan creation fails otherwise), -1 = off */
+    /* ---- NumericalCoalStyle plans (make_box_model_rhs(NumericalCoalStyle()), Coalescence.jl:470-708) ----
+     * coal_style = CLOUDY_NUMERICAL_COAL: the integrals of the kernel FUNCTION p.kernel_func over the densities, each by
+     * one fixed quad_order-point Gauss rule per distribution (generalised Gauss-Laguerre for Gamma / Exponential modes,
+     * Gauss-Hermite in ln x for Lognormal modes; tensor product over a pair of modes after the substitution x' = x - y)
+     * where the reference nests adaptive quadgk(rtol = 1e-8).  Exact for the constant and linear kernels; a
+     * discretisation for the hydrodynamic and Long kernels (DESIGN.md states the measured error).  kernel_c, tensor_p,
+     * dist_thresholds and threshold_style are ignored (the style has no thresholds: weighting_fn splits the self
+     * collisions, Coalescence.jl:624-642).  Monodisperse modes: CLOUDY_EINVAL (no normed_density_func method). */
+    int32_t coal_style;                      /* CLOUDY_ANALYTICAL_COAL (default) / CLOUDY_NUMERICAL_COAL */
+    int32_t kernel_func;                     /* CLOUDY_KFUNC_* */
+    int32_t kernel_func_is_normalized;       /* 0: library applies get_normalized_kernel_func(kernel, norms), :124-154 */
+    int32_t quad_order;                      /* points per distribution, 2..CLOUDY_MAX_QUAD; default 10 */
+    double kernel_func_params[3];            /* physical units unless kernel_func_is_normalized */
 } cloudy_plan_desc;
 
 /* fills defaults: k_range = (eps, 10), n_bins_per_log_unit = 15, norms = (1, 1), thresholds = +Inf,
- * dtype = F64, device = -1 */
+ * dtype = F64, device = -1, coal_style = ANALYTICAL, quad_order = 10 */
 void cloudy_plan_desc_init(cloudy_plan_desc *desc);
 
 int cloudy_plan_create(const cloudy_plan_desc *desc, cloudy_plan **out);
@@ -132,6 +161,16 @@ const char *cloudy_plan_jit_log(const cloudy_plan *plan);
  * with hiprtc for `arch` (NULL = "gfx950"); nothing is loaded or launched.  CLOUDY_OK, or CLOUDY_EUNSUPPORTED with the
  * compiler log in cloudy_last_error(). */
 int cloudy_jit_selfcheck(const cloudy_plan_desc *desc, const char *arch);
+/* Layout of cloudy_plan_desc as this library was compiled: for each field, in declaration order, name / byte offset /
+ * byte size.  A binding in another language (julia/CloudyHIP.jl, the ctypes mirror) checks its own struct against this
+ * before the first cloudy_plan_create.  Returns the number of fields; fills at most `cap` entries of each array (any of
+ * which may be NULL).  Names are static strings. */
+int cloudy_plan_desc_layout(const char **names, uint32_t *offsets, uint32_t *sizes, int cap);
+/* The per-parcel Gauss rule of the NumericalCoalStyle kernels, evaluated on the HOST by the same source the device
+ * compiles (quad.hpp: start values from the staged table, two Newton steps, Christoffel weights): nodes u[quad_order]
+ * and normalised weights W[quad_order] for the weight u^(k-1) e^-u / Gamma(k), 0 < k <= k_hi.  A diagnostic for tests
+ * and hosts (no device involved, nothing batched: this is not a compute path). */
+int cloudy_quad_rule_host(int quad_order, double k_hi, double k, double *u, double *W);
 int cloudy_plan_nmom(const cloudy_plan *plan);      /* sum(NProgMoms) */
 int cloudy_plan_nparams(const cloudy_plan *plan);   /* 3 * N planes of (n, theta, k) */
 /* copies of the derived CoalescenceData fields (Coalescence.jl:69-84), for tests and hosts */
@@ -212,6 +251,11 @@ int cloudy_rainshaft_ssprk33_steps(const cloudy_plan *plan, size_t nz, size_t n_
  * The multi-GPU conservation check all-reduces these nmom doubles (RCCL), see INTEGRATION.md. */
 int cloudy_moment_sums(const cloudy_plan *plan, size_t n_parcels, size_t ld, int planes, const void *arr_dev,
                        double *sums_dev, void *stream);
+/* the same with a caller-supplied workspace of cloudy_moment_sums_workspace_bytes(planes) bytes of device memory:
+ * re-entrant (any number of streams may reduce with one plan concurrently, each with its own workspace) */
+size_t cloudy_moment_sums_workspace_bytes(int planes);
+int cloudy_moment_sums_ws(const cloudy_plan *plan, size_t n_parcels, size_t ld, int planes, const void *arr_dev,
+                          double *sums_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
 
 /* thin device-memory helpers so that a host without a HIP binding can keep state device-resident */
 int cloudy_device_count(void);

@@ -30,6 +30,7 @@ extern "C" {
 #define CO_MAX_P 8            /* tensor order + 1 */
 #define CO_MAX_M (CO_MAX_P + 2)
 #define CO_MAX_VEL 8
+#define CO_MAX_QUAD 64        /* points of the fixed Gauss rule (cloudy_oracle_quad.c) */
 
 enum { CO_EXPONENTIAL = 0, CO_GAMMA = 1, CO_MONODISPERSE = 2, CO_LOGNORMAL = 3 };
 enum { CO_FIXED_THRESHOLD = 0, CO_MOVING_THRESHOLD = 1 };
@@ -132,6 +133,25 @@ int co_rainshaft_cell_batch(const co_params *p, long n, long ld, const double *m
                             double *sedi_flux, int n_threads);
 int co_update_dist_batch(const co_params *p, long n, long ld, const double *mom, double *params /* [3N][ld] */);
 int co_max_threads(void);
+
+/* ---- Coalescence.jl (NumericalCoalStyle) with a FIXED Gauss rule in place of quadgk: cloudy_oracle_quad.c ---- */
+enum { CO_KF_CONSTANT = 0, CO_KF_LINEAR = 1, CO_KF_HYDRODYNAMIC = 2, CO_KF_LONG = 3 };
+/* CoalescenceKernelFunction, KernelFunctions.jl:39-86: p = (rate) | (rate) | (coal_eff) | (x_threshold, below, above) */
+typedef struct {
+    int kind;
+    double p[3];
+} co_kernel_func;
+double co_kernel_func_eval(const co_kernel_func *kf, double x, double y);                        /* KernelFunctions.jl:94-116 */
+int co_get_normalized_kernel_func(const co_kernel_func *kf, const double norms[2], co_kernel_func *out); /* :124-154 */
+int co_gauss_gamma_rule(int nq, double k, double *u, double *W);   /* weight u^(k-1) e^-u / Gamma(k) */
+int co_gauss_hermite_rule(int nq, double *t, double *W);           /* weight e^(-t^2) / sqrt(pi) */
+int co_dist_rule(const co_dist *d, int nq, double *x, double *w);
+int co_get_coal_ints_numerical_fixed(const co_dist *pdists, int N, const co_kernel_func *kf, int nq, double *out,
+                                     double *scale, double *noise);
+int co_rhs_coal_numerical(const co_params *p, const co_kernel_func *kf_normalized, int nq, const double *mom,
+                          double *dmom, double *scale, double *noise);
+int co_rhs_coal_numerical_batch(const co_params *p, const co_kernel_func *kf_normalized, int nq, long n_parcels, long ld,
+                                const double *mom, double *dmom, double *scale, double *noise, int n_threads);
 
 #ifdef __cplusplus
 }

@@ -19,7 +19,7 @@ FIXED_THRESHOLD, MOVING_THRESHOLD = 0, 1
 
 def build(force=False):
     """Compile the oracle with gcc (recipe: oracle/Makefile)."""
-    src = [os.path.join(_HERE, f) for f in ("cloudy_oracle.c", "cloudy_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("cloudy_oracle.c", "cloudy_oracle_quad.c", "cloudy_oracle.h")]
     if (not force and os.path.exists(_LIB_PATH)
             and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src)):
         return _LIB_PATH
@@ -55,6 +55,14 @@ class Params(C.Structure):
         ("n_vel", C.c_int),
         ("vel", C.c_double * (MAX_VEL * 2)),
     ]
+
+
+KF_CONSTANT, KF_LINEAR, KF_HYDRODYNAMIC, KF_LONG = 0, 1, 2, 3
+
+
+class KernelFunc(C.Structure):
+    """co_kernel_func: CoalescenceKernelFunction (KernelFunctions.jl:39-86) as (kind, parameters)."""
+    _fields_ = [("kind", C.c_int), ("p", C.c_double * 3)]
 
 
 _lib = None
@@ -114,6 +122,16 @@ def lib():
         L.co_rhs_coal_batch.argtypes = [C.POINTER(Params), C.c_long, C.c_long, _dp, _dp, _dp, C.c_int]
         L.co_rainshaft_cell_batch.argtypes = [C.POINTER(Params), C.c_long, C.c_long, _dp, _dp, _dp, C.c_int]
         L.co_update_dist_batch.argtypes = [C.POINTER(Params), C.c_long, C.c_long, _dp, _dp]
+        # cloudy_oracle_quad.c: NumericalCoalStyle with a fixed Gauss rule
+        L.co_kernel_func_eval.restype = C.c_double
+        L.co_kernel_func_eval.argtypes = [C.POINTER(KernelFunc), C.c_double, C.c_double]
+        L.co_get_normalized_kernel_func.argtypes = [C.POINTER(KernelFunc), _dp, C.POINTER(KernelFunc)]
+        L.co_gauss_gamma_rule.argtypes = [C.c_int, C.c_double, _dp, _dp]
+        L.co_gauss_hermite_rule.argtypes = [C.c_int, _dp, _dp]
+        L.co_dist_rule.argtypes = [C.POINTER(Dist), C.c_int, _dp, _dp]
+        L.co_get_coal_ints_numerical_fixed.argtypes = [C.POINTER(Dist), C.c_int, C.POINTER(KernelFunc), C.c_int, _dp, _dp, _dp]
+        L.co_rhs_coal_numerical_batch.argtypes = [C.POINTER(Params), C.POINTER(KernelFunc), C.c_int, C.c_long, C.c_long,
+                                                  _dp, _dp, _dp, _dp, C.c_int]
         _lib = L
     return _lib
 
@@ -407,3 +425,65 @@ def update_dist_batch(p, mom):
 
 def max_threads():
     return lib().co_max_threads()
+
+
+# ---- Coalescence.jl NumericalCoalStyle with a fixed Gauss rule (cloudy_oracle_quad.c) --------------------------
+def kernel_func(kind, *params):
+    kf = KernelFunc()
+    kf.kind = int(kind)
+    for i, v in enumerate(params):
+        kf.p[i] = float(v)
+    return kf
+
+
+def kernel_func_eval(kf, x, y):
+    return lib().co_kernel_func_eval(C.byref(kf), float(x), float(y))
+
+
+def get_normalized_kernel_func(kf, norms):
+    out = KernelFunc()
+    if lib().co_get_normalized_kernel_func(C.byref(kf), _d(_darr(norms)), C.byref(out)) < 0:
+        raise ValueError("unknown kernel function")
+    return out
+
+
+def gauss_gamma_rule(nq, k):
+    """(u, W): nq-point rule for the normalised weight u^(k-1) e^-u / Gamma(k)."""
+    u, w = np.zeros(nq), np.zeros(nq)
+    if lib().co_gauss_gamma_rule(int(nq), float(k), _d(u), _d(w)) < 0:
+        raise ValueError("bad rule arguments")
+    return u, w
+
+
+def gauss_hermite_rule(nq):
+    t, w = np.zeros(nq), np.zeros(nq)
+    if lib().co_gauss_hermite_rule(int(nq), _d(t), _d(w)) < 0:
+        raise ValueError("bad rule arguments")
+    return t, w
+
+
+def get_coal_ints_numerical_fixed(pdists, kf, nq=10, with_scale=False):
+    arr = (Dist * len(pdists))(*pdists)
+    nmom = sum(nparams(d.type) for d in pdists)
+    out, sc = np.zeros(nmom), np.zeros(nmom)
+    if lib().co_get_coal_ints_numerical_fixed(arr, len(pdists), C.byref(kf), int(nq), _d(out), _d(sc), None) < 0:
+        raise ValueError("get_coal_ints_numerical_fixed failed (Monodisperse has no normed density)")
+    return (out, sc) if with_scale else out
+
+
+def rhs_coal_numerical_batch(p, kf_normalized, nq, mom, with_scale=False, n_threads=0, out=None, with_noise=False):
+    """rhs_coal!(NumericalCoalStyle(), ...) for a moment-major batch; p: make_params(...) (its tensors are unused).
+    with_noise: also the absolute rounding error of the reference's (1 - weighting_fn) form (cloudy_oracle_quad.c)."""
+    m = _darr(mom)
+    nm, n = m.shape
+    assert nm == nmom_of(p)
+    d = out if out is not None else np.empty_like(m)
+    s = np.empty_like(m) if (with_scale or with_noise) else None
+    z = np.empty_like(m) if with_noise else None
+    if lib().co_rhs_coal_numerical_batch(C.byref(p), C.byref(kf_normalized), int(nq), n, n, _d(m), _d(d),
+                                         _d(s) if s is not None else None, _d(z) if z is not None else None,
+                                         int(n_threads)) < 0:
+        raise ValueError("rhs_coal_numerical_batch failed")
+    if with_noise:
+        return d, s, z
+    return (d, s) if with_scale else d

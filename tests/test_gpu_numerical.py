@@ -1,0 +1,214 @@
+"""GPU parity of the NumericalCoalStyle (fixed Gauss rule) plans, through the C ABI, against the same-rule CPU oracle
+(oracle/cloudy_oracle_quad.c) -- BASELINE configs[3] as worded: "3-mode mixture, hydrodynamic kernel via 10-pt Gauss
+quadrature".
+
+Tolerances (north_star): <= 1e-8 x scale against the same rule on the CPU for quadrature kernels (measured ~1e-14:
+asserted at 1e-11 so that a regression shows); <= 1e-12 x scale against the ANALYTIC tensor path on the device for
+polynomial kernels where the two closures coincide (one mode).  `scale` = sum of |Q|, |R|, |S| terms of an output as the
+oracle reports it.  The discretisation error of the rule against adaptive quadrature is a CPU test
+(tests/test_numerical_oracle.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import bench
+from test_gpu_parity import INF, assert_close_scaled, dev, mixed_moments
+
+pytestmark = pytest.mark.gpu
+
+TOL_SAME_RULE = 1e-11   # north_star allows 1e-8; the two implementations of the rule agree to ~1e-14
+NORMS = bench.NORMS
+
+
+def assert_same_rule(got, want, scale, noise, what, tol=TOL_SAME_RULE):
+    """|hip - oracle| <= tol * scale + 8 * noise.  `noise` is the rounding error of the ORACLE's (= the reference's)
+    `(1 - weighting_fn) * inner` form of S_2 (Coalescence.jl:703-708): where a mode barely overlaps the next one the
+    difference 1 - w keeps only a few digits, while the kernel forms 1 - w directly from density ratios."""
+    assert got.shape == want.shape
+    assert np.array_equal(np.isnan(got), np.isnan(want)), f"{what}: NaN pattern differs"
+    ok = ~np.isnan(want)
+    err = np.abs(got[ok] - want[ok])
+    excess = err - 8.0 * noise[ok]
+    worst = float((np.maximum(excess, 0.0) / np.maximum(scale[ok], 1e-300)).max()) if err.size else 0.0
+    assert worst <= tol, f"{what}: max (|diff| - 8 noise) / scale = {worst:.3e} > {tol:g}"
+    return worst
+
+
+def kernel_funcs(cloudy, oracle):
+    return {
+        "constant": (cloudy.ConstantKernelFunction(1e-4), oracle.kernel_func(oracle.KF_CONSTANT, 1e-4)),
+        "linear": (cloudy.LinearKernelFunction(5.0), oracle.kernel_func(oracle.KF_LINEAR, 5.0)),
+        "hydro": (cloudy.HydrodynamicKernelFunction(1e2 * np.pi), oracle.kernel_func(oracle.KF_HYDRODYNAMIC, 1e2 * np.pi)),
+        "long": (cloudy.LongKernelFunction(5.236e-10, 9.44e9, 5.78), oracle.kernel_func(oracle.KF_LONG, 5.236e-10, 9.44e9, 5.78)),
+    }
+
+
+def numerical_case(cloudy, oracle, dist_types, kname, nq=10, k_range=None):
+    """product-side ODE parameters (p.kernel_func normalised, as the reference's drivers pass it) + oracle params"""
+    kf, okf = kernel_funcs(cloudy, oracle)[kname]
+    mk = {0: lambda: cloudy.ExponentialPrimitiveParticleDistribution(1.0, 1.0),
+          1: lambda: cloudy.GammaPrimitiveParticleDistribution(1.0, 1.0, 1.0),
+          3: lambda: cloudy.LognormalPrimitiveParticleDistribution(1.0, 1.0, 1.0)}
+    pd = tuple(mk[t]() for t in dist_types)
+    npm = tuple({0: 2, 1: 3, 3: 3}[t] for t in dist_types)
+    extra = {"k_range": k_range} if k_range else {}
+    par = cloudy.ODEParameters(pd, None, npm, NORMS, kernel_func=cloudy.get_normalized_kernel_func(kf, NORMS),
+                               quad_order=nq, **extra)
+    op = oracle.make_params(list(dist_types), np.zeros((1, 1)), (INF,) * len(dist_types), norms=NORMS,
+                            **({"k_range": k_range} if k_range else {}))
+    return par, op, oracle.get_normalized_kernel_func(okf, NORMS)
+
+
+def run_numerical(cloudy, par, mom):
+    rhs = cloudy.make_box_model_rhs(cloudy.NumericalCoalStyle())
+    m = dev(cloudy, mom)
+    dm = cloudy.DeviceArray.zeros(*mom.shape, dtype=mom.dtype)
+    rhs(dm, m, par, 0.0)
+    return dm.to_numpy()
+
+
+def test_cfg4_three_modes_hydrodynamic_kernel_10pt_rule(gpu_cloudy, oracle):
+    """BASELINE configs[3]: 3 Gamma modes (bench.synth_moments incl. ~1 % degenerate parcels), HydrodynamicKernelFunction
+    (1e2 pi) (box_gamma_mixture_hydro.jl:22), 10-point rule, 9 moments -- against the same rule on the CPU"""
+    cloudy = gpu_cloudy
+    par, op, okf = numerical_case(cloudy, oracle, [1, 1, 1], "hydro")
+    mom = bench.synth_moments(3, 6000, seed=41)
+    got = run_numerical(cloudy, par, mom)
+    want, scale, noise = oracle.rhs_coal_numerical_batch(op, okf, 10, mom, with_noise=True)
+    worst = assert_same_rule(got, want, scale, noise, "cfg4q")
+    print(f"cfg4q (3 Gamma modes, hydrodynamic, nq = 10): max |hip - oracle| / scale = {worst:.2e}")
+    ok = np.all(np.isfinite(got), axis=0)
+    mass = got[1] + got[4] + got[7]
+    assert np.all(np.abs(mass[ok]) <= 1e-11 * (scale[1] + scale[4] + scale[7])[ok])     # mass is conserved by the rule
+    assert np.all((got[0] + got[3] + got[6])[ok] <= 0.0)                               # coalescence only removes particles
+
+
+@pytest.mark.parametrize("dist_types,kname,nq", [
+    ([1], "hydro", 10), ([1], "long", 10), ([0], "linear", 10), ([3], "hydro", 10),
+    ([1, 1], "hydro", 10), ([1, 1], "long", 10), ([0, 1], "hydro", 10), ([1, 0], "linear", 6), ([0, 0], "long", 10),
+    ([1, 3], "hydro", 10), ([3, 3], "linear", 8),
+    ([1, 1, 1], "long", 10), ([1, 1, 1], "constant", 4), ([1, 0, 1], "hydro", 12), ([1, 1, 1], "hydro", 16),
+    ([1, 1, 1, 1], "hydro", 10), ([0, 1, 1, 1], "long", 8), ([1, 1], "hydro", 32), ([1, 1], "hydro", 2),
+])
+def test_numerical_families_vs_same_rule_oracle(gpu_cloudy, oracle, dist_types, kname, nq):
+    cloudy = gpu_cloudy
+    par, op, okf = numerical_case(cloudy, oracle, dist_types, kname, nq)
+    mom = mixed_moments(dist_types, 1500, seed=100 + 7 * len(dist_types) + nq)
+    got = run_numerical(cloudy, par, mom)
+    want, scale, noise = oracle.rhs_coal_numerical_batch(op, okf, nq, mom, with_noise=True)
+    if 3 in dist_types:
+        # a Lognormal mode clamped to sigma = eps (zero / negative variance inputs, ParticleDistributions.jl:483-505) puts
+        # all its Gauss-Hermite nodes at exp(mu) to within an ulp: kernels that vanish on the diagonal (hydrodynamic) are
+        # then pure rounding noise on both sides, and so is the oracle's `scale`.  Such parcels are not compared.
+        prm = oracle.update_dist_batch(op, mom)
+        degenerate = np.zeros(mom.shape[1], dtype=bool)
+        for i, t in enumerate(dist_types):
+            if t == 3:
+                degenerate |= ~(prm[3 * i + 2] > 1e-6)
+        assert degenerate.mean() < 0.02
+        got, want, scale, noise = got[:, ~degenerate], want[:, ~degenerate], scale[:, ~degenerate], noise[:, ~degenerate]
+    worst = assert_same_rule(got, want, scale, noise, f"{dist_types} {kname} nq={nq}")
+    print(f"{dist_types} {kname} nq={nq}: {worst:.2e}")
+
+
+@pytest.mark.parametrize("kname,kc", [("constant", [[1e-4]]), ("linear", [[0.0, 5.0], [5.0, 0.0]])])
+def test_polynomial_kernels_match_the_analytic_path_on_the_device(gpu_cloudy, oracle, kname, kc):
+    """one mode: weighting_fn == 1, the Numerical and Analytical closures coincide, and the rule integrates polynomial
+    kernels exactly -> the quadrature plan and the tensor plan must agree to 1e-12 of the term scale (north_star)"""
+    cloudy = gpu_cloudy
+    par, op, okf = numerical_case(cloudy, oracle, [1], kname)
+    mom = bench.synth_moments(1, 50_000, seed=9)
+    got = run_numerical(cloudy, par, mom)
+    cd = cloudy.CoalescenceData(cloudy.CoalescenceTensor(np.array(kc)), (3,), (INF,), NORMS)
+    par_a = cloudy.ODEParameters(par.pdists, cd, (3,), NORMS)
+    rhs = cloudy.make_box_model_rhs(cloudy.AnalyticalCoalStyle())
+    m, dm = dev(cloudy, mom), cloudy.DeviceArray.zeros(*mom.shape)
+    rhs(dm, m, par_a, 0.0)
+    ana = dm.to_numpy()
+    _, scale = oracle.rhs_coal_numerical_batch(op, okf, 10, mom, with_scale=True)
+    worst = assert_close_scaled(got, ana, scale, 1e-12, f"quadrature vs tensor plan, {kname}")
+    print(f"{kname}: max |quadrature plan - tensor plan| / scale = {worst:.2e}")
+
+
+def test_ahead_of_time_kernels_params_input_and_float_planes(gpu_cloudy, oracle):
+    cloudy = gpu_cloudy
+    L = cloudy.lib()
+    par, op, okf = numerical_case(cloudy, oracle, [1, 1, 1], "hydro")
+    mom = bench.synth_moments(3, 2000, seed=5)
+    want, scale, noise = oracle.rhs_coal_numerical_batch(op, okf, 10, mom, with_noise=True)
+    kf = par.kernel_func
+    jit = cloudy.NumericalPlan([1, 1, 1], kf, NORMS, 10, specialize=1)
+    aot = cloudy.NumericalPlan([1, 1, 1], kf, NORMS, 10, specialize=-1)
+    assert jit.specialized and not aot.specialized
+    m = dev(cloudy, mom)
+    outs = []
+    for plan in (jit, aot):
+        dm = cloudy.DeviceArray.zeros(9, mom.shape[1])
+        cloudy._lib.check(L.cloudy_coal_rhs(plan.handle, mom.shape[1], mom.shape[1], m.ptr, dm.ptr, None))
+        outs.append(dm.to_numpy())
+        assert_same_rule(outs[-1], want, scale, noise, "specialised" if plan is jit else "ahead of time")
+    # get_coal_ints(::NumericalCoalStyle, pdists, kernel_func) on (n, theta, k) planes, normalised units out
+    cd = cloudy.CoalescenceData(cloudy.CoalescenceTensor(np.array([[0.0]])), (3, 3, 3), (INF,) * 3, NORMS)
+    params = cloudy.DeviceArray.zeros(9, mom.shape[1])
+    cloudy._lib.check(L.cloudy_update_dist_from_moments(cd.plan([1, 1, 1]).handle, mom.shape[1], mom.shape[1], m.ptr,
+                                                        params.ptr, None))
+    ci = cloudy.get_coal_ints(cloudy.NumericalCoalStyle(), ([1, 1, 1], params), kf).to_numpy()
+    norms9 = np.tile([NORMS[0], NORMS[0] * NORMS[1], NORMS[0] * NORMS[1] ** 2], 3)[:, None]
+    assert_same_rule(ci * norms9, want, scale, noise, "get_coal_ints on parameter planes")
+    # float planes: final rounding only
+    got32 = run_numerical(cloudy, par, mom.astype(np.float32))
+    want32, scale32 = oracle.rhs_coal_numerical_batch(op, okf, 10, mom.astype(np.float32).astype(np.float64), with_scale=True)
+    ok = np.isfinite(want32) & (np.abs(want32) < 3e38)
+    assert np.all(np.abs(got32[ok] - want32[ok]) <= 1e-6 * scale32[ok] + 1e-37)
+
+
+def test_numerical_plan_status_codes(gpu_cloudy):
+    cloudy = gpu_cloudy
+    L, E = cloudy.lib(), cloudy._lib
+    plan = cloudy.NumericalPlan([1, 1], cloudy.LinearKernelFunction(5e-3), NORMS, 10)
+    u = cloudy.DeviceArray.zeros(6, 64)
+    assert L.cloudy_ssprk33_steps(plan.handle, 64, 64, u.ptr, u.ptr, 1.0, 1, None) == E.EUNSUPPORTED
+    assert b"NumericalCoalStyle" in L.cloudy_last_error()
+    assert L.cloudy_finite_2d_integrals(plan.handle, 64, 64, u.ptr, u.ptr, None) == E.EUNSUPPORTED
+    assert L.cloudy_compute_thresholds(plan.handle, 64, 64, u.ptr, u.ptr, None) == E.EUNSUPPORTED
+    assert L.cloudy_coal_rhs(plan.handle, 0, 0, None, None, None) == 0          # empty batch
+    assert L.cloudy_coal_rhs(plan.handle, 64, 32, u.ptr, u.ptr, None) == E.EINVAL  # ld < n
+    with pytest.raises(cloudy.CloudyError) as ei:
+        cloudy.NumericalPlan([1, 2], cloudy.LinearKernelFunction(5e-3), NORMS, 10)
+    assert ei.value.code == E.EINVAL
+    with pytest.raises(cloudy.CloudyError) as ei:
+        cloudy.NumericalPlan([1], cloudy.LinearKernelFunction(5e-3), NORMS, 33)
+    assert ei.value.code == E.EUNSUPPORTED
+
+
+def test_cfg4q_full_size_properties(gpu_cloudy):
+    """BASELINE configs[3] at its per-GPU size (1.25e7 parcels, 9 moments): size-independent properties -- mass
+    conservation parcel by parcel, number never created, bilinearity in the number concentrations (all moments x s
+    => tendencies x s^2) and linearity in the coalescence efficiency."""
+    cloudy = gpu_cloudy
+    n = 12_500_000
+    mom = bench.synth_moments(3, n, seed=bench.SEED, degenerate_frac=0.0)
+    kf = cloudy.HydrodynamicKernelFunction(1e2 * np.pi)
+    mk = lambda e: cloudy.ODEParameters(tuple(cloudy.GammaPrimitiveParticleDistribution(1.0, 1.0, 1.0) for _ in range(3)),
+                                        None, (3, 3, 3), NORMS,
+                                        kernel_func=cloudy.get_normalized_kernel_func(cloudy.HydrodynamicKernelFunction(e), NORMS))
+    rhs = cloudy.make_box_model_rhs(cloudy.NumericalCoalStyle())
+    m, dm = dev(cloudy, mom), cloudy.DeviceArray.zeros(9, n)
+    rhs(dm, m, mk(1e2 * np.pi), 0.0)
+    d = dm.to_numpy()
+    assert np.all(np.isfinite(d))
+    mass = d[1] + d[4] + d[7]
+    mag = np.abs(d[1]) + np.abs(d[4]) + np.abs(d[7])
+    assert np.max(np.abs(mass) / np.maximum(mag, 1e-300)) < 1e-9
+    assert np.all(d[0] + d[3] + d[6] <= 0.0) and np.all(d[0] <= 0.0)
+    assert np.all(d[8] >= 0.0)                                   # the largest mode's M2 only grows
+    # bilinear in number: scale every moment by 2 (same theta, k) -> tendencies x 4
+    m2 = dev(cloudy, 2.0 * mom)
+    rhs(dm, m2, mk(1e2 * np.pi), 0.0)
+    d2 = dm.to_numpy()
+    assert np.max(np.abs(d2 - 4.0 * d) / np.maximum(np.abs(4.0 * d), 1e-300)) < 1e-12
+    # linear in the efficiency
+    rhs(dm, m, mk(3e2 * np.pi), 0.0)
+    d3 = dm.to_numpy()
+    assert np.max(np.abs(d3 - 3.0 * d) / np.maximum(np.abs(3.0 * d), 1e-300)) < 1e-12

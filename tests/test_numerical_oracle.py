@@ -1,0 +1,163 @@
+"""CPU tests of the fixed-rule NumericalCoalStyle oracle (oracle/cloudy_oracle_quad.c), of the host instance of the
+device's per-parcel Gauss rule (cloudy_quad_rule_host) and of the host side of NumericalCoalStyle plans.
+
+What pins the oracle here:
+  * its Gauss rules against scipy.special.roots_genlaguerre / roots_hermite and against the moments of the densities;
+  * the reference's own NumericalCoalStyle tests (test/unit_tests/test_Sources_correctness.jl:175-263): weighting_fn
+    values, signs and zero patterns of Q / R / S, dM[1] < 0, |dM[2]| <= 1e-2, dM[3] > 0 for three Gamma modes with
+    LinearKernelFunction(1.0);
+  * exactness for polynomial kernels: for one mode the Numerical and Analytical closures coincide, so the fixed rule
+    must reproduce co_get_coal_ints (all thresholds Inf) to rounding; for several modes the sums over modes must;
+  * the adaptive-quadrature restatement of the reference integrals (oracle/numerical_adaptive.py ->
+    tests/golden/numerical_adaptive.json): the discretisation error of the rule is REPORTED and bounded, per kernel.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INF = float("inf")
+_dp = C.POINTER(C.c_double)
+
+
+def _device_rule(cloudy, nq, k, k_hi=10.0):
+    u, w = np.zeros(nq), np.zeros(nq)
+    rc = cloudy.lib().cloudy_quad_rule_host(nq, k_hi, k, u.ctypes.data_as(_dp), w.ctypes.data_as(_dp))
+    assert rc == 0, cloudy.lib().cloudy_last_error()
+    return u, w
+
+
+@pytest.mark.parametrize("nq", [2, 5, 10, 16, 32])
+def test_gauss_rules_vs_scipy_and_moments(oracle, cloudy, nq):
+    """oracle rule, device rule (host instance of the same source) and scipy agree; both integrate the moments
+    E[U^p] = Gamma(k+p)/Gamma(k), p < 2 nq, of the Gamma(k) weight exactly -- down to the clamp k = eps"""
+    from scipy.special import gamma, roots_genlaguerre, roots_hermite
+
+    for k in (2.220446049250313e-16, 1e-9, 1e-4, 0.03, 0.5, 1.0, 2.7, 6.1, 9.99, 10.0):
+        uo, wo = oracle.gauss_gamma_rule(nq, k)
+        ud, wd = _device_rule(cloudy, nq, k)
+        assert np.max(np.abs(ud - uo) / uo) < 5e-13 and np.max(np.abs(wd - wo) / wo) < 5e-12
+        if k > 1e-6:
+            xs, ws = roots_genlaguerre(nq, k - 1.0)
+            ws = ws / gamma(k)
+            assert np.max(np.abs(uo - xs) / xs) < 1e-12 and np.max(np.abs(wo - ws) / ws) < 2e-12
+        for u, w in ((uo, wo), (ud, wd)):
+            assert abs(w.sum() - 1.0) < 1e-12
+            for p in range(1, min(2 * nq, 9)):
+                want = np.prod([k + i for i in range(p)])
+                assert abs((w * u ** p).sum() - want) <= 5e-12 * want
+    t, w = oracle.gauss_hermite_rule(nq)
+    ts, ws = roots_hermite(nq)
+    assert np.max(np.abs(t - ts)) < 1e-13 and np.max(np.abs(w - ws / np.sqrt(np.pi)) / w) < 1e-12
+
+
+def test_device_rule_table_covers_other_k_ranges(cloudy):
+    """a plan with param_range k <= 5 (test_ParticleDistributions_correctness.jl:128-132) or k <= 40 gets its own table"""
+    from scipy.special import gamma, roots_genlaguerre
+
+    for k_hi, ks in ((5.0, (0.2, 3.3, 5.0)), (40.0, (0.5, 17.0, 40.0)), (1.0, (0.01, 1.0))):
+        for k in ks:
+            u, w = _device_rule(cloudy, 10, k, k_hi)
+            xs, ws = roots_genlaguerre(10, k - 1.0)
+            assert np.max(np.abs(u - xs) / xs) < 1e-12 and np.max(np.abs(w - ws / gamma(k)) / w) < 1e-11
+    L = cloudy.lib()
+    u = np.zeros(10)
+    assert L.cloudy_quad_rule_host(10, 10.0, 11.0, u.ctypes.data_as(_dp), u.ctypes.data_as(_dp)) == cloudy._lib.EINVAL
+    assert L.cloudy_quad_rule_host(1, 10.0, 1.0, u.ctypes.data_as(_dp), u.ctypes.data_as(_dp)) == cloudy._lib.EUNSUPPORTED
+
+
+def test_reference_numerical_style_tests(oracle):
+    """test/unit_tests/test_Sources_correctness.jl:175-263 on the fixed-rule oracle (linear kernel: the rule is exact
+    up to the weighting split, which only moves self-collision output between neighbouring modes)"""
+    O = oracle
+    d1, d2, d3 = O.make_dist(O.GAMMA, 10.0, 10.0, 3.0), O.make_dist(O.GAMMA, 20.0, 100.0, 5.0), O.make_dist(O.GAMMA, 2.0, 500.0, 6.0)
+    assert O.weighting_fn(10.0, 1, [d1]) == 1.0                                   # :177
+    assert O.weighting_fn(100.0, 1, [d1, d2]) == 0.5969233398831713               # :181
+    assert O.weighting_fn(100.0, 2, [d1, d2]) == 1.0                              # :182
+    kf = O.kernel_func(O.KF_LINEAR, 1.0)
+    ci = O.get_coal_ints_numerical_fixed([d1, d2, d3], kf, 10)
+    assert ci[0] < 0.0                                                            # :253
+    dM = ci.reshape(3, 3).sum(axis=0)
+    assert dM[0] < 0.0 and abs(dM[1]) <= 1e-2 and dM[2] > 0.0                     # :260-262
+    # the same totals follow from the analytic closure (thresholds Inf): they do not depend on how self collisions split
+    cd = O.coalescence_data(np.array([[0.0, 1.0], [1.0, 0.0]]), [3, 3, 3], [INF] * 3)
+    tot = O.get_coal_ints([d1, d2, d3], cd).reshape(3, 3).sum(axis=0)
+    assert np.allclose(dM[[0, 2]], tot[[0, 2]], rtol=1e-12) and abs(dM[1] - tot[1]) <= 1e-12 * 9e11
+
+
+@pytest.mark.parametrize("kind,c", [("constant", [[0.7]]), ("linear", [[0.0, 5e-3], [5e-3, 0.0]])])
+def test_fixed_rule_is_exact_for_polynomial_kernels(oracle, kind, c):
+    """one mode: NumericalCoalStyle == AnalyticalCoalStyle with thresholds Inf (weighting_fn == 1); the fixed rule
+    integrates polynomial kernels exactly, any k"""
+    O = oracle
+    kf = O.kernel_func(O.KF_CONSTANT if kind == "constant" else O.KF_LINEAR, 0.7 if kind == "constant" else 5e-3)
+    rng = np.random.default_rng(3)
+    for _ in range(40):
+        k = float(rng.uniform(0.05, 10.0))
+        d = [O.make_dist(O.GAMMA, float(10 ** rng.uniform(-2, 3)), float(10 ** rng.uniform(-3, 2)), k)]
+        num, sc = O.get_coal_ints_numerical_fixed(d, kf, 10, with_scale=True)
+        ana = O.get_coal_ints(d, O.coalescence_data(np.array(c), [3], [INF]))
+        assert np.max(np.abs(num - ana) / sc) < 1e-13
+    e = [O.make_dist(O.EXPONENTIAL, 100.0, 0.3)]
+    num, sc = O.get_coal_ints_numerical_fixed(e, kf, 6, with_scale=True)
+    ana = O.get_coal_ints(e, O.coalescence_data(np.array(c), [2], [INF]))
+    assert np.max(np.abs(num - ana) / sc) < 1e-13
+
+
+def test_discretisation_error_against_adaptive_quadrature(oracle):
+    """The fixed rule against the nested adaptive quadrature of the reference integrals (Coalescence.jl:503-708 restated
+    with scipy's QUADPACK in oracle/numerical_adaptive.py, epsrel 1e-8).  This is the discretisation error of the rule,
+    not a parity claim: printed per case and order, bounded loosely, and required to fall as the order grows."""
+    O = oracle
+    with open(os.path.join(ROOT, "tests", "golden", "numerical_adaptive.json")) as f:
+        cases = json.load(f)["cases"]
+    bound_nq10 = {"ref_test_3gamma_linear": 5e-4, "3gamma_hydrodynamic": 2e-3, "2gamma_long": 5e-3, "1gamma_hydrodynamic": 5e-2}
+    for c in cases:
+        pd = [O.make_dist(int(t), n, th, k) for t, n, th, k in c["pdists"]]
+        kf = O.kernel_func(c["kf"][0], *c["kf"][1])
+        want = np.array(c["coal_ints"])
+        errs = {}
+        for nq in (6, 10, 32, 64):
+            got, sc = O.get_coal_ints_numerical_fixed(pd, kf, nq, with_scale=True)
+            errs[nq] = float(np.max(np.abs(got - want) / sc))
+        print(f"{c['name']}: max |fixed - adaptive| / scale = " + ", ".join(f"nq={q}: {e:.2e}" for q, e in errs.items()))
+        assert errs[10] <= bound_nq10[c["name"]]
+        assert errs[64] < errs[6]
+
+
+def test_numerical_rhs_batch_wrapper_and_monodisperse(oracle):
+    O = oracle
+    p = O.make_params([O.GAMMA, O.GAMMA], np.zeros((1, 1)), (INF, INF), norms=(1e6, 1e-9))
+    kf = O.get_normalized_kernel_func(O.kernel_func(O.KF_HYDRODYNAMIC, 1e2 * np.pi), (1e6, 1e-9))
+    assert kf.p[0] == pytest.approx(1e2 * np.pi * 1e6 * (1e-9) ** (4.0 / 3.0), rel=1e-15)
+    import bench
+
+    mom = bench.synth_moments(2, 64, seed=11)
+    d, s = O.rhs_coal_numerical_batch(p, kf, 10, mom, with_scale=True)
+    assert d.shape == mom.shape and np.all(np.isfinite(d[:, np.all(mom > 0, axis=0)]))
+    mass = d[1] + d[4]
+    assert np.all(np.abs(mass) <= 1e-12 * (s[1] + s[4]))          # the discrete rule conserves mass
+    with pytest.raises(ValueError):
+        O.get_coal_ints_numerical_fixed([O.make_dist(O.MONODISPERSE, 1.0, 0.5)], kf, 10)
+
+
+def test_numerical_plan_host_side(cloudy):
+    """plan description of a NumericalCoalStyle configuration: validation without a device, plan-time source builds"""
+    L, E = cloudy.lib(), cloudy._lib
+    kf = cloudy.HydrodynamicKernelFunction(1e2 * np.pi)
+    d = cloudy.NumericalPlan.make_desc([1, 1, 1], kf, (1e6, 1e-9), 10, kernel_func_is_normalized=False)
+    assert L.cloudy_jit_selfcheck(C.byref(d), b"gfx950") == 0, L.cloudy_last_error()
+    bad = cloudy.NumericalPlan.make_desc([1, 2], kf, (1e6, 1e-9), 10)
+    assert L.cloudy_jit_selfcheck(C.byref(bad), b"gfx950") == E.EINVAL and b"Monodisperse" in L.cloudy_last_error()
+    bad = cloudy.NumericalPlan.make_desc([1], kf, (1e6, 1e-9), 64)
+    assert L.cloudy_jit_selfcheck(C.byref(bad), b"gfx950") == E.EUNSUPPORTED
+    bad = cloudy.NumericalPlan.make_desc([1], kf, (1e6, 1e-9), 10)
+    bad.kernel_func = 9
+    assert L.cloudy_jit_selfcheck(C.byref(bad), b"gfx950") == E.EINVAL
+    bad = cloudy.NumericalPlan.make_desc([1], kf, (1e6, 1e-9), 10)
+    bad.coal_style = 3
+    assert L.cloudy_jit_selfcheck(C.byref(bad), b"gfx950") == E.EINVAL and b"Invalid coal style" in L.cloudy_last_error()
+    assert cloudy.kernel_func_code(cloudy.LongKernelFunction(1.0, 2.0, 3.0)) == (3, (1.0, 2.0, 3.0))
