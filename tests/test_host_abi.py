@@ -37,6 +37,58 @@ def test_plan_desc_layout_and_defaults(cloudy):
     assert all(np.isinf(d.dist_thresholds[i]) for i in range(4))
 
 
+def test_plan_desc_layout_matches_every_binding(cloudy):
+    """cloudy_plan_desc_layout() (offsets / sizes as the library was compiled) against the two bindings that mirror the
+    struct by hand: the ctypes PlanDesc and `mutable struct PlanDesc` of julia/CloudyHIP.jl (parsed here -- julia is not
+    installed, so the shim cannot be run; its field order, types and hence C layout can still be checked)."""
+    import re
+
+    L = cloudy.lib()
+    cap = 64
+    names, offs, sizes = (C.c_char_p * cap)(), (C.c_uint32 * cap)(), (C.c_uint32 * cap)()
+    nf = L.cloudy_plan_desc_layout(names, offs, sizes, cap)
+    lib_fields = [(names[i].decode(), offs[i], sizes[i]) for i in range(nf)]
+    # ctypes mirror
+    PD = cloudy._lib.PlanDesc
+    assert [f[0] for f in PD._fields_] == [f[0] for f in lib_fields]
+    for name, off, size in lib_fields:
+        fld = getattr(PD, name)
+        assert (fld.offset, fld.size) == (off, size), name
+    assert lib_fields[-1][1] + lib_fields[-1][2] <= C.sizeof(PD) < lib_fields[-1][1] + lib_fields[-1][2] + 8
+    # Julia mirror: parse the struct, lay it out with C rules (natural alignment), compare
+    src = open(os.path.join(ROOT, "julia", "CloudyHIP.jl")).read()
+    consts = {k: int(v) for k, v in zip(("MAX_MODES", "MAX_P", "MAX_VEL"),
+                                        re.search(r"const MAX_MODES, MAX_P, MAX_VEL = (\d+), (\d+), (\d+)", src).groups())}
+    body = re.search(r"mutable struct PlanDesc\n(.*?)\nend", src, re.S).group(1)
+    prim = {"UInt32": 4, "Int32": 4, "Float64": 8, "Ptr{Float64}": 8}
+    off, jl = 0, []
+    for line in body.splitlines():
+        line = line.split("#")[0].strip()
+        if not line:
+            continue
+        name, typ = [x.strip() for x in line.split("::")]
+        m = re.fullmatch(r"NTuple\{(.+),\s*(\w+)\}", typ)
+        if m:
+            count = eval(m.group(1).replace("2 * MAX_VEL", str(2 * consts["MAX_VEL"])), {}, consts)
+            esz = prim[m.group(2)]
+            size = count * esz
+        else:
+            esz = size = prim[typ]
+        off = (off + esz - 1) // esz * esz
+        jl.append((name, off, size))
+        off += size
+    assert jl == lib_fields
+    assert (consts["MAX_MODES"], consts["MAX_P"], consts["MAX_VEL"]) == (cloudy._lib.MAX_MODES, cloudy._lib.MAX_P, cloudy._lib.MAX_VEL)
+    # every ccall in the shim names an exported symbol
+    for sym in set(re.findall(r"ccall\(\(:(\w+), lib\)", src)):
+        assert hasattr(L, sym), sym
+
+
+def test_moment_sums_workspace_size(cloudy):
+    L = cloudy.lib()
+    assert L.cloudy_moment_sums_workspace_bytes(6) == 8 * 1024 * 6 and L.cloudy_moment_sums_workspace_bytes(0) == 0
+
+
 def test_plan_validation_errors_precede_device_lookup(cloudy):
     L = cloudy.lib()
 
