@@ -59,3 +59,36 @@ def test_allreduce_of_moment_sums_gloo_world2(tmp_path):
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert p.stdout.count("ok") == 2
+
+
+def test_bench_gpus_flag_rejects_mismatched_launch():
+    """`--gpus N` under a launcher that started a different number of ranks is an error, not a silent 1-rank run."""
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=3" in (p.stderr + p.stdout)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_spawns_two_ranks(gpu_cloudy):
+    """`python bench.py --gpus 2` without a launcher: the parent starts two ranks (before touching the GPU), rank 0's
+    JSON line reports n_gpus = 2, a per-rank roofline entry for each rank and the all-reduced mass residual.  On the
+    1-GPU test box both ranks share GPU 0 and rendezvous over gloo (CLOUDY_BENCH_BACKEND); the driver's multi-GPU runs
+    use nccl (= RCCL) with one GPU per rank."""
+    import json
+
+    env = dict(os.environ, CLOUDY_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--parcels", "400000", "--steps", "5",
+                        "--warmup", "2", "--no-variants", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["global_parcels"] == 800000 and out["scaling"] == "weak"
+    assert [r["rank"] for r in out["roofline"]["per_rank"]] == [0, 1]
+    assert all(r["kernel_ms"] > 0 for r in out["roofline"]["per_rank"])
+    assert out["mass_rate_residual"] is not None and out["value"] > 0
