@@ -1,9 +1,13 @@
 """GPU parity tests: the HIP path (through the C ABI of libcloudy_hip.so) against the CPU oracle, the reference's
 known-answer values, and closed forms.  Tolerances (stated here, from BASELINE.json north_star):
 
-  * all-Inf polynomial path (constant / Golovin / Long pieces):  |hip - oracle| <= 1e-12 * scale, and rel 1e-12
-    against the closed forms;  rel 1e-10 vs the oracle on the Golovin analytic case
-  * Simpson / incomplete-gamma path (finite or moving thresholds): |hip - oracle| <= 1e-8 * scale
+  * all-Inf polynomial path (constant / Golovin / Long pieces):  north_star asks |hip - oracle| <= 1e-12 * scale, and
+    rel 1e-12 against the closed forms;  rel 1e-10 vs the oracle on the Golovin analytic case
+  * Simpson / incomplete-gamma path (finite or moving thresholds): north_star asks |hip - oracle| <= 1e-8 * scale
+
+The asserted envelopes are tighter -- regression guards around what is measured on MI355X (<= 7.3e-15 on every
+configuration, 2.0e-14 over random plans): TOL_POLY = 1e-13 x scale, TOL_QUAD = 1e-12 x scale, plus a plain RELATIVE
+1e-10 on every output that is not a cancellation (|want| > 1e-3 x scale).
 
 `scale` is the sum of |Q|, |R|, |S| terms of an output as reported by the oracle: a tendency is a small difference
 of large terms (e.g. the net mass tendency of a mode), so rounding is measured against the terms."""
@@ -21,8 +25,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 EPS = float(np.finfo(np.float64).eps)
 INF = float("inf")
-TOL_POLY = 1e-12
-TOL_QUAD = 1e-8
+TOL_POLY = 1e-13   # all-Inf polynomial path (north_star: 1e-12)
+TOL_QUAD = 1e-12   # Simpson / incomplete-gamma path, fp64 (north_star: 1e-8)
+TOL_REL = 1e-10    # plain relative error of outputs that are not small differences of large terms
 TYPES = {"exponential": 0, "gamma": 1}
 
 
@@ -70,6 +75,10 @@ def assert_close_scaled(got, want, scale, tol, what=""):
     bad = err > bound
     worst = (err / np.maximum(scale[ok], 1e-300)).max() if err.size else 0.0
     assert not bad.any(), f"{what}: max |diff|/scale = {worst:.3e} > {tol:g} ({bad.sum()} of {err.size})"
+    if tol <= TOL_QUAD:   # fp64 comparisons: outputs that are not cancellations must also agree RELATIVELY
+        big = np.abs(want[ok]) > 1e-3 * scale[ok]
+        rel = err[big] / np.abs(want[ok][big])
+        assert not (rel > TOL_REL).any(), f"{what}: max relative error of non-cancelling outputs {rel.max():.3e} > {TOL_REL:g}"
     return worst
 
 
@@ -108,7 +117,7 @@ def test_closed_forms_constant_and_golovin(gpu_cloudy, oracle):
     assert_close_scaled(d, want, scale, TOL_POLY, "golovin")
 
 
-@pytest.mark.parametrize("name,n,tol", [("cfg2", 200_000, TOL_POLY), ("cfg3a", 200_000, TOL_POLY),
+@pytest.mark.parametrize("name,n,tol", [("cfg2", 1_000_000, TOL_POLY), ("cfg3a", 200_000, TOL_POLY),
                                         ("cfg3b", 20_000, TOL_QUAD), ("cfg4", 4_000, TOL_QUAD),
                                         ("moving4", 4_000, TOL_QUAD)])
 def test_bench_workloads_vs_oracle(gpu_cloudy, oracle, name, n, tol):
@@ -454,6 +463,59 @@ def test_full_size_properties_1e7(gpu_cloudy):
             lin = outs[0] + outs[1]
             assert np.all(np.abs(lin - d) <= 1e-11 * (np.abs(outs[0]) + np.abs(outs[1]) + 1e-300))
         del m, dm, d
+
+
+def test_full_size_properties_cfg4_cfg5_1p25e7(gpu_cloudy):
+    """BASELINE configs[3] (reference formulation: 3 Gamma modes, order-4 hydrodynamic tensor, two thresholds) and
+    configs[4] (Long pieces + sedimentation flux, float planes) at their per-GPU size of 1.25e7 parcels, through
+    size-independent properties: mass conservation parcel by parcel, number never created, the largest mode's M2 never
+    destroyed, agreement of a 1e5-parcel slice computed alone with the same parcels inside the full batch (the result of a
+    parcel does not depend on its neighbours or on the launch geometry), fluxes downward and linear in the velocity."""
+    cloudy = gpu_cloudy
+    n = 12_500_000
+    L = cloudy.lib()
+    rhs = cloudy.make_box_model_rhs(cloudy.AnalyticalCoalStyle())
+    # ---- cfg4
+    wl = bench.make_workload("cfg4", n, seed=2)
+    m, dm = dev(cloudy, wl["mom"]), cloudy.DeviceArray.zeros(9, n)
+    rhs(dm, m, wl["par"], 0.0)
+    d = dm.to_numpy()
+    fin = np.all(np.isfinite(d), axis=0)
+    assert fin.mean() > 0.97            # (clamped closures of the ~1 % degenerate parcels may overflow, as in the oracle)
+    mass, gross = d[1] + d[4] + d[7], np.abs(d[1]) + np.abs(d[4]) + np.abs(d[7])
+    # (the fitted order-4 tensor has coefficients of both signs up to 1e7 times its net effect: each mass tendency is
+    # itself a cancellation, so the residual is judged against the tendencies for the bulk and bounded for the tail)
+    resid = np.abs(mass[fin]) / np.maximum(gross[fin], 1e-300)
+    print(f"cfg4 @ {n}: mass residual / gross: median {np.median(resid):.1e}, 99.9 % {np.quantile(resid, 0.999):.1e}, max {resid.max():.1e}")
+    # (max is 1 for a handful of the degenerate parcels: with M_p M_q < eps the reference's F = 0 rule drops self-collision
+    # terms of the LAST mode, which no mode receives -- Coalescence.jl:213-216 -- so tendencies of order eps do not cancel)
+    assert np.quantile(resid, 0.999) <= 1e-9
+    # (the fitted order-4 tensor is not sign-definite, so number / M2 monotonicity is not a property of this configuration)
+    sl = slice(7_000_003, 7_100_003)
+    ms, dms = dev(cloudy, np.ascontiguousarray(wl["mom"][:, sl])), cloudy.DeviceArray.zeros(9, 100_000)
+    rhs(dms, ms, wl["par"], 0.0)
+    assert np.array_equal(dms.to_numpy(), d[:, sl], equal_nan=True)
+    del m, dm, d, ms, dms
+    # ---- cfg5: cfg3b tensors and thresholds + sedimentation, CLOUDY_F32 planes
+    wl = bench.make_workload("cfg3b", n, seed=4)
+    vel = ((50.0, 1.0 / 6),)
+    mom32 = wl["mom"].astype(np.float32)
+    m = dev(cloudy, mom32)
+    cs, sf = cloudy.DeviceArray.zeros(6, n, np.float32), cloudy.DeviceArray.zeros(6, n, np.float32)
+    plan = wl["coal_data"].plan(wl["dist_types"], vel=vel, dtype=1)
+    cloudy._lib.check(L.cloudy_rainshaft_sources(plan.handle, n, n, m.ptr, cs.ptr, sf.ptr, None))
+    c, f = cs.to_numpy().astype(np.float64), sf.to_numpy().astype(np.float64)
+    fin = np.all(np.isfinite(c), axis=0) & np.all(np.isfinite(f), axis=0)
+    assert fin.mean() > 0.97
+    gross = np.abs(c[1]) + np.abs(c[4])
+    assert np.all(np.abs(c[1] + c[4])[fin] <= 4e-7 * np.maximum(gross[fin], 1e-300))   # float planes: final rounding of each source
+    assert np.all(c[0][fin] + c[3][fin] <= 1e-6 * (np.abs(c[0]) + np.abs(c[3]))[fin])   # number only decreases
+    assert np.all(f[:, fin] <= 0.0)                                                      # sedimentation fluxes point down
+    plan2 = wl["coal_data"].plan(wl["dist_types"], vel=((100.0, 1.0 / 6),), dtype=1)
+    cloudy._lib.check(L.cloudy_sedimentation_flux(plan2.handle, n, n, m.ptr, sf.ptr, None))
+    f2 = sf.to_numpy().astype(np.float64)
+    ok = fin & np.all(np.abs(f) > 1e-30, axis=0) & np.all(np.abs(f2) < 1e37, axis=0)
+    assert np.all(np.abs(f2[:, ok] - 2.0 * f[:, ok]) <= 3e-7 * np.abs(f2[:, ok]))       # linear in the velocity coefficient
 
 
 def _ssprk33_host(rhs_fn, u, dt, n_steps):
