@@ -17,6 +17,7 @@
 #include <string>
 #include <utility>
 
+#include "host_gamma.hpp"
 #include "host_plan.hpp"
 #include "host_quad.hpp"
 #include "kernels.hpp"
@@ -417,6 +418,19 @@ int build_host_plan(const cloudy_plan_desc *d, cloudy_plan **out, std::vector<do
                 return fail(CLOUDY_EINVAL, "no method compute_threshold for dist_type[%d] = %d", i, h.dist_type[i]);
             }
         }
+        // start values of the per-parcel inversion gamma_inc_inv(k, p_i, 1 - p_i) (:760): ln x as a polynomial in ln k
+        // over k in [0.03, kmax], one per Gamma mode; kept only if every fit is good to 1e-3 (two Halley steps then
+        // reach machine precision); otherwise the kernels use the generic start value
+        bool any_fit = false, all_good = true;
+        const double k_lo = 0.03, k_hi = std::fmax(h.kmax, 1.0);
+        for (int i = 0; i < N - 1 && k_hi > 2.0 * k_lo; ++i) {
+            if (h.dist_type[i] != CLOUDY_DIST_GAMMA || !(h.thr[i] > 0.0 && h.thr[i] < 1.0)) continue;
+            const double err = gamma_host::fit_inverse(h.thr[i], k_lo, k_hi, kInvTerms, h.inv_map[0], h.inv_map[1], h.inv_tab[i]);
+            any_fit = true;
+            all_good = all_good && err < 1e-3;
+        }
+        if (!any_fit || !all_good) h.inv_map[0] = h.inv_map[1] = 0.0;
+        h.inv_klo = k_lo;
     }
 
     // sedimentation velocity, rescaled as the rainshaft caller does (rainshaft_helpers.jl:74-76)

@@ -160,26 +160,31 @@ __device__ __forceinline__ float inc_gamma_p_from_E_f32(float a, float z, float 
     }
 }
 
-// P(a, z), Q(a, z) for a standalone call (one exp + one lgamma)
-__device__ __forceinline__ double inc_gamma_p(double a, double z, double lgamma_a1, double *q_out) {
+__device__ __forceinline__ double log_pos(double x);
+__device__ __forceinline__ double lgamma_pos(double k);
+
+// P(a, z), Q(a, z) for a standalone call (one exp; lz = ln z)
+__device__ __forceinline__ double inc_gamma_p(double a, double z, double lz, double lgamma_a1, double *q_out) {
     if (!(z > 0.0)) {
         if (q_out) *q_out = 1.0;
         return 0.0;
     }
-    double E = exp(a * log(z) - z - lgamma_a1);
+    double E = exp(fma(a, lz, -z) - lgamma_a1);
     return inc_gamma_p_from_E(a, z, E, q_out);
 }
 
 // x with P(a, x) = p, Q(a, x) = q  (SpecialFunctions.gamma_inc_inv; ParticleDistributions.jl:760).
 // Safeguarded Halley iteration on the smaller tail.
-__device__ inline double inc_gamma_inv(double a, double p, double q) {
+__device__ inline double inc_gamma_inv(double a, double p, double q, double x_start = 0.0) {
     if (!(p > 0.0)) return 0.0;
     if (!(q > 0.0)) return INFINITY;
     const double a1 = a - 1.0;
-    const double lga1 = lgamma(a + 1.0);  // log Gamma(a+1)
-    const double lga = lga1 - log(a);     // log Gamma(a)
+    const double lga1 = lgamma_pos(a + 1.0);  // log Gamma(a+1)
+    const double lga = lga1 - log_pos(a);     // log Gamma(a)
     double x;
-    if (a > 1.0) {
+    if (x_start > 0.0) {  // the caller's start value (moving_threshold: a staged fit, good to ~1e-7)
+        x = x_start;
+    } else if (a > 1.0) {
         double pp = (p < 0.5) ? p : q;
         double t = sqrt(-2.0 * log(pp));
         double zz = (2.30753 + t * 0.27061) / (1.0 + t * (0.99229 + t * 0.04481)) - t;
@@ -189,6 +194,10 @@ __device__ inline double inc_gamma_inv(double a, double p, double q) {
         if (x < 1e-3) x = 1e-3;
     } else {
         double t = 1.0 - a * (0.253 + a * 0.12);
+        // x ~ (p Gamma(a+1))^(1/a) for small a: below the smallest double the answer is 0 (callers clamp it from below;
+        // without this exit a shape clamped to k = eps spends the full iteration budget bisecting towards 0 while the
+        // other 63 parcels of its wave wait)
+        if (p < t && log(p / t) < -744.0 * a) return 0.0;
         if (p < t)
             x = pow(p / t, 1.0 / a);
         else
@@ -199,7 +208,8 @@ __device__ inline double inc_gamma_inv(double a, double p, double q) {
     for (int it = 0; it < 100; ++it) {
         if (!(x > 0.0)) x = (hi < INFINITY) ? 0.5 * (lo + hi) : 1e-300;
         double Q;
-        double Pv = inc_gamma_p(a, x, lga1, &Q);
+        const double lx = log_pos(x);
+        double Pv = inc_gamma_p(a, x, lx, lga1, &Q);
         double err = (p <= 0.5) ? (Pv - p) : (q - Q);
         if (err > 0.0) {
             if (x < hi) hi = x;
@@ -208,7 +218,7 @@ __device__ inline double inc_gamma_inv(double a, double p, double q) {
         } else {
             return x;
         }
-        double dens = exp(-x + a1 * log(x) - lga);
+        double dens = exp(fma(a1, lx, -x) - lga);
         double xn;
         if (dens > 0.0 && dens < INFINITY) {
             double u = err / dens;
@@ -220,6 +230,8 @@ __device__ inline double inc_gamma_inv(double a, double p, double q) {
         if (!(xn > lo) || !(xn < hi)) xn = (hi < INFINITY) ? 0.5 * (lo + hi) : 2.0 * x;
         double step = fabs(xn - x);
         if (step <= 4.0 * kEps * fabs(xn)) return xn;
+        // a start value from the staged fit is good to ~1e-7: one Halley step (third order) then leaves ~1e-18
+        if (x_start > 0.0 && it == 0 && step <= 1e-6 * fabs(xn) && xn > lo && xn < hi) return xn;
         // rounding-level limit cycle: the step stopped shrinking and is already negligible
         if (step >= prev_step && step <= 1e-13 * fabs(xn)) return xn;
         prev_step = step;

@@ -26,6 +26,9 @@ struct HostPlan {
     int n_vel = 0;
     double vel[CLOUDY_MAX_VEL][2] = {{0}};              // physical
     double vel_n[CLOUDY_MAX_VEL][2] = {{0}};            // rainshaft_helpers.jl:74-76
+    // MovingThreshold: start-value fit of the percentile inversion (kernels.hpp, KArgs::inv_tab)
+    double inv_map[2] = {0.0, 0.0}, inv_klo = 0.0;
+    double inv_tab[CLOUDY_MAX_MODES][16] = {{0}};
     int device = 0;
     int force_ppl1 = 0;  // CLOUDY_HIP_PPL1=1: always the one-parcel-per-lane ALLINF kernel (A/B timing)
     double *nodes_dev = nullptr;                        // [n_nodes][kNodeStride]

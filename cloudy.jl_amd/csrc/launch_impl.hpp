@@ -39,6 +39,12 @@ void fill_args(const HostPlan &h, const LaunchReq &r, KArgs<N, P> &A) {
         for (int k = 0; k < N; ++k)
             for (int a = 0; a < P; ++a)
                 for (int b = 0; b < P; ++b) A.c[j][k][a][b] = h.c[j][k][a][b];
+    static_assert(kInvTerms == 16, "HostPlan::inv_tab holds 16 coefficients per mode");
+    A.inv_map[0] = h.inv_map[0];
+    A.inv_map[1] = h.inv_map[1];
+    A.inv_klo = h.inv_klo;
+    for (int i = 0; i < N; ++i)
+        for (int d = 0; d < kInvTerms; ++d) A.inv_tab[i][d] = h.inv_tab[i][d];
 }
 
 // workgroup size of the threshold kernel for a plan (see coal_rhs_sorted_kernel in kernels.hpp)

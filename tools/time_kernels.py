@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Kernel time of cloudy_coal_rhs for named bench workloads (HIP events on the launch stream), one line per workload.
+usage: python tools/time_kernels.py [--reps R] cfg3b cfg4 moving4 ...      (CLOUDY_HIP_LIB / CLOUDY_HIP_JIT respected)"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from __graft_entry__ import load_package
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--parcels", type=int, default=0)
+    ap.add_argument("workloads", nargs="+")
+    a = ap.parse_args()
+    pkg = load_package()
+    L = pkg.lib()
+    out = []
+    for name in a.workloads:
+        n = a.parcels or bench.workload_spec(name)["default_parcels"]
+        wl = bench.make_workload(name, n)
+        plan = wl["coal_data"].plan(wl["dist_types"])
+        m, dm = pkg.DeviceArray.from_numpy(wl["mom"]), pkg.DeviceArray.zeros(plan.nmom, n)
+        for _ in range(2):
+            pkg._lib.check(L.cloudy_coal_rhs(plan.handle, n, n, m.ptr, dm.ptr, None))
+        ms = C.c_float()
+        pkg._lib.check(L.cloudy_time_coal_rhs(plan.handle, n, n, m.ptr, dm.ptr, None, a.reps, C.byref(ms)))
+        out.append(f"{name} {ms.value:.3f} ms ({n / ms.value * 1e3:.3e}/s, jit={int(plan.specialized)})")
+        del m, dm
+    print(os.environ.get("CLOUDY_HIP_LIB", "default").split("/")[-1], "|", " | ".join(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
