@@ -215,7 +215,7 @@ struct FixedGrid {
     __device__ __forceinline__ double node_x(int j) const { return nd[kNodeStride * j]; }
     // running-abscissa interface shared with MovingGrid (a table needs none)
     __device__ __forceinline__ double first_x() const { return 0.0; }
-    __device__ __forceinline__ double next_x(double, int) const { return 0.0; }
+    __device__ __forceinline__ double next_x(double, int, int) const { return 0.0; }
     __device__ __forceinline__ double node_x(int j, double) const { return nd[kNodeStride * j]; }
     __device__ __forceinline__ SimpsonNode node(int j, double, bool late) const { return node(j, late); }
     __device__ __forceinline__ SimpsonNode node(int j, bool /*late*/) const {
@@ -242,8 +242,10 @@ struct MovingGrid {
     // x_{j-1} e^{dx} and re-anchored with a true exp() every 16th node: at most 15 roundings of drift (< 2e-15), one
     // multiplication instead of ~31 instructions for the others.
     __device__ __forceinline__ double first_x() const { return exp(x_min); }
-    __device__ __forceinline__ double next_x(double x_run, int j_next) const {
-        return (j_next & 15) == 0 ? exp(x_min + double(j_next) * dx) : x_run * ratio;
+    // `phase` is a wave-uniform iteration counter: lanes sit at different nodes j of their own grids, and an anchor keyed
+    // on j would make every lane's exp() run (masked) in almost every iteration of the wave
+    __device__ __forceinline__ double next_x(double x_run, int j_next, int phase) const {
+        return (phase & 15) == 15 ? exp(x_min + double(j_next) * dx) : x_run * ratio;
     }
     __device__ __forceinline__ double node_x(int, double x_run) const { return x_run; }
     __device__ __forceinline__ SimpsonNode node(int j, double x_run, bool late) const {
@@ -303,24 +305,56 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double n, 
 #pragma unroll
         for (int q = 0; q < NS; ++q) U[q] = 0.0;
         const double inv_xt = 1.0 / xt;
+        if constexpr (Grid::kHasPowers) {
 #pragma unroll 1
-        for (; j < nb; ++j) {
-            if (!(grid.node_x(j, xr) <= x_early)) break;
-            const SimpsonNode nd = grid.node(j, xr, false);
-            xr = grid.next_x(xr, j + 1);
-            const double t = nd.x * inv_th;
-            double e = nd.wdx * exp(fma(k, nd.lx - lnth, -t));
-            if (Grid::kHasPowers) {
+            for (; j < nb; ++j) {
+                if (!(grid.node_x(j, xr) <= x_early)) break;
+                const SimpsonNode nd = grid.node(j, xr, false);
+                xr = grid.next_x(xr, j + 1, j);
+                const double t = nd.x * inv_th;
+                const double e = nd.wdx * exp(fma(k, nd.lx - lnth, -t));
 #pragma unroll
                 for (int q = 0; q < NS; ++q) U[q] = fma(e, grid.upow(j, q), U[q]);  // tabulated powers: SGPR operand
-            } else {
-                const double u = nd.x * inv_xt;
-#pragma unroll
-                for (int q = 0; q < NS; ++q) {
-                    U[q] += e;
-                    e *= u;
-                }
             }
+        } else {
+            // Per-parcel grid: no table of node powers.  The nodes are geometric, u_j = u_0 rho^j, so
+            //   U_q = u_0^q sum_j e_j (rho^q)^j
+            // is a polynomial in rho^q with coefficients e_j: Horner from the LAST early node down, one FMA per sum and
+            // node with the per-parcel constants rho^q (the forward form needs a multiplication and an addition each).
+            // The number of early nodes follows from the grid directly (x_j = exp(x_min + j dx) <= x_early); a node on
+            // the boundary may fall either side, both evaluations are valid.
+            int J = 0;
+            const double x_first = xr;  // = grid.first_x()
+            if (x_early >= x_first) {
+                const double jf = floor((log_pos(x_early) - grid.x_min) / grid.dx) + 1.0;
+                J = jf < double(nb) ? (int)jf : nb;
+            }
+            double Rq[NS], H[NS];
+            Rq[0] = 1.0;
+#pragma unroll
+            for (int q = 1; q < NS; ++q) Rq[q] = Rq[q - 1] * grid.ratio;
+#pragma unroll
+            for (int q = 0; q < NS; ++q) H[q] = 0.0;
+            const double inv_ratio = 1.0 / grid.ratio;
+            double x = 0.0;
+#pragma unroll 1
+            for (int jj = J - 1, it = 0; jj >= 0; --jj, ++it) {
+                const double lx = fma(double(jj), grid.dx, grid.x_min);
+                x = (it & 15) == 0 ? exp(lx) : x * inv_ratio;  // re-anchored every 16th iteration (wave-uniform phase)
+                const double t = x * inv_th;
+                const double e = simpson_weight_node(jj + 1, nb) * grid.dx * exp(fma(k, lx - lnth, -t));
+#pragma unroll
+                for (int q = 0; q < NS; ++q) H[q] = fma(H[q], Rq[q], e);
+            }
+            double pw = 1.0;
+            const double u0 = x_first * inv_xt;
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                U[q] = H[q] * pw;
+                pw *= u0;
+            }
+            j = J;
+            xr = J < nb ? exp(fma(double(J), grid.dx, grid.x_min)) : 0.0;
         }
         if (j > 0) {
             // P(a, z0) and g_a = dP/dz at z0 for the M orders a = k + p2 (downward from a_top)
@@ -365,9 +399,9 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double n, 
     j = nb;
 #endif
 #pragma unroll 1
-    for (; j < nb; ++j) {
+    for (int it = 0; j < nb; ++j, ++it) {
         const SimpsonNode nd = grid.node(j, xr, true);
-        xr = grid.next_x(xr, j + 1);
+        xr = grid.next_x(xr, j + 1, it);
         const double t = nd.x * inv_th, zr = nd.xmx * inv_th;
         const bool zpos = zr > 0.0;  // P(a, z <= 0) = 0: such a node (never on the reference grid) contributes nothing
         const double z = zpos ? zr : 1.0;
@@ -435,7 +469,7 @@ __device__ __forceinline__ void msh_grid_f32(const Grid &grid, double xt, double
         for (; j < nb; ++j) {
             if (!(grid.node_x(j, xr) <= x_early)) break;
             const SimpsonNode nd = grid.node(j, xr, false);
-            xr = grid.next_x(xr, j + 1);
+            xr = grid.next_x(xr, j + 1, j);
             const double td = nd.x * inv_th;
             const float u = (float)(nd.x * inv_xt);
             float e = (float)nd.wdx * __expf((float)fma(k, nd.lx - lnth, -td));
@@ -480,9 +514,9 @@ __device__ __forceinline__ void msh_grid_f32(const Grid &grid, double xt, double
         }
     }
 #pragma unroll 1
-    for (; j < nb; ++j) {
+    for (int it = 0; j < nb; ++j, ++it) {
         const SimpsonNode nd = grid.node(j, xr, true);
-        xr = grid.next_x(xr, j + 1);
+        xr = grid.next_x(xr, j + 1, it);
         const double td = nd.x * inv_th, zd = nd.xmx * inv_th;
         if (!(zd > 0.0)) continue;
         const float z = (float)zd, xf = (float)nd.x;
