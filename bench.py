@@ -401,6 +401,21 @@ def _cpu_baseline(name, target_seconds=12.0):
                                              "1 CPU of the reference's CI; upper bounds, not measurements)")
 
 
+def _valu_roofline(measured, key, n_items, kernel_ms):
+    """fp64-VALU roofline block of a compute-bound variant: useful fp64 flops per item from the committed rocprofv3
+    counters (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 x 64 x active-lane fraction, tools/summarize_profiles.py) over the kernel
+    time measured in this run; None when the committed profile does not hold the kernel."""
+    k = (measured.get("kernels") or {}).get(key)
+    if not k or not kernel_ms:
+        return None
+    tf = k["fp64_flops_per_item"] * n_items / (kernel_ms * 1e-3) / 1e12
+    return {"bound": "fp64-valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": tf / FP64_VALU_PEAK_TFLOPS, "kernel": k["kernel"], "fp64_flops_per_item": k["fp64_flops_per_item"],
+            "valu_insts_per_item": k["valu_insts_per_item"], "active_lane_fraction": k["lane_utilisation"],
+            "note": "flops per item and lane utilisation from the committed counter passes (profiles/measured_latest.json); "
+                    "kernel time from this run"}
+
+
 CFG4Q_PARCELS = 12_500_000
 
 
@@ -436,13 +451,9 @@ def _cfg4q_variant(pkg, rank, world, measured, n=CFG4Q_PARCELS, reps=3):
            "kernel": "cloudy_jit_quad_n3q10_hydro_f64" if plan.specialized else "coal_rhs_quad_kernel<3, 2, double>",
            "hbm_GBs": 2 * 9 * 8 * n / (ms * 1e-3) / 1e9,
            "mass_residual_per_parcel_max": float(np.max(np.abs(net[ok]) / np.maximum(mag[ok], 1e-300)))}
-    flops = measured.get("cfg4q_fp64_flops_per_parcel")
-    if flops:
-        tf = flops * n / (ms * 1e-3) / 1e12
-        out["roofline"] = {"bound": "fp64-valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": tf / FP64_VALU_PEAK_TFLOPS, "fp64_flops_per_parcel": flops,
-                           "note": "fp64 flops per parcel from the committed SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 counters x "
-                                   "active-lane fraction (profiles/measured_latest.json)"}
+    rl = _valu_roofline(measured, "cfg4q", n, ms)
+    if rl:
+        out["roofline"] = rl
     return out
 
 
@@ -539,7 +550,10 @@ def main():
             "mass_rate_residual": abs(v["mass_rate_sum"]) / max(v["mass_rate_gross"], 1e-300) if rank == 0 else None,
             "mass_residual_per_parcel_max": v["mass_per_parcel"],
         }
-        if measured.get("n_parcels") == n_local and measured.get("cfg3b_fp64_flops_per_launch"):
+        rl = _valu_roofline(measured, "cfg3b", n_local, v["event_ms"])
+        if rl:
+            variants["cfg3b"]["roofline"] = rl
+        elif measured.get("n_parcels") == n_local and measured.get("cfg3b_fp64_flops_per_launch"):
             tf = measured["cfg3b_fp64_flops_per_launch"] / (v["event_ms"] * 1e-3) / 1e12
             variants["cfg3b"]["roofline"] = {
                 "bound": "fp64-valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -570,6 +584,9 @@ def main():
             "value": 3 * n_steps * n_local * world / dts, "unit": "parcel-RHS/s", "ms_per_call": 1e3 * dts,
             "hbm_GBs": bytes_per_eval * n_local / dts / 1e9,
         }
+        rl = _valu_roofline(measured, "cfg3a_fused_ssprk33", n_local, 1e3 * dts)   # flops per parcel per CALL (12 evaluations)
+        if rl:
+            variants["cfg3a_fused_ssprk33"]["roofline"] = rl
 
     if not args.no_variants and args.workload == "cfg3a":
         # the same launches with the ahead-of-time kernels (desc.specialize = -1): plan constants from kernel arguments,
@@ -636,6 +653,9 @@ def main():
                 "value": vn * world / (msv * 1e-3), "unit": "parcel-RHS/s", "kernel_ms": msv,
                 "hbm_GBs": 2 * planv.nmom * 8 * vn / (msv * 1e-3) / 1e9,
             }
+            rl = _valu_roofline(measured, vname, vn, msv)
+            if rl:
+                variants[vname]["roofline"] = rl
             del mv, dmv
 
     if not args.no_variants and args.workload == "cfg3a":
@@ -689,6 +709,9 @@ def main():
                         f"+ sedimentation vel={vel}, {nst} SSPRK33 steps (3 RHS evaluations each) in one launch, fp64",
             "value": 3 * nst * nz * ncol * world / (msr * 1e-3), "unit": "cell-RHS/s", "ms_per_call": msr,
         }
+        rl = _valu_roofline(measured, "rainshaft_ssprk33_columns", nz * ncol, msr)   # flops per cell per CALL (6 evaluations)
+        if rl:
+            variants["rainshaft_ssprk33_columns"]["roofline"] = rl
         z = (np.arange(nz) + 0.5) * 150.0
         at = ((z >= 0.5 * z.max() - 75.0) & (z < 0.75 * z.max() - 75.0)).astype(float)
         kg = np.array([[2.220446049250313e-16 / 1e6, 5.0], [5.0, 0.0]])   # CoalescenceTensor(LinearKernelFunction(5), 1)

@@ -62,5 +62,29 @@ for row in rows:
         latest["cfg3b_valu_lane_utilisation"] = util
         latest["cfg3b_valu_insts_per_parcel"] = row["SQ_INSTS_VALU"] * 64.0 / latest["n_parcels"]
         latest["cfg3b_kernel"] = row["kernel"]
+# fp64-VALU figures of the compute-bound variants of bench.py: useful flops / VALU instructions per item (parcel, or cell
+# for the column integrator; per CALL for the fused integrators) and the active-lane fraction
+VARIANTS = {   # bench variant -> (kernel name prefix, items per launch in the bench)
+    "cfg3b": ("cloudy_jit_sorted_n2p3_f64", 10_000_000),
+    "cfg4": ("cloudy_jit_sorted_n3p5_f64", 12_500_000),
+    "moving4": ("cloudy_jit_sorted_n4p2_f64", 2_500_000),
+    "cfg4q": ("cloudy_jit_quad_n3q10_hydro_f64", 12_500_000),
+    "cfg3a_fused_ssprk33": ("cloudy_jit_ssprk33_n2p3_f64", 10_000_000),
+    "rainshaft_ssprk33_columns": ("rainshaft_ssprk33_kernel<2, 3, 1, double>", 10_000_000),
+}
+kern = {}
+for name, (prefix, items) in VARIANTS.items():
+    cands = [r for r in rows if r["kernel"].startswith(prefix) and "SQ_INSTS_VALU_FMA_F64" in r and r["grid_size"] >= 0.9 * items]
+    if not cands:
+        continue
+    r = max(cands, key=lambda x: x["grid_size"])
+    util = r["SQ_THREAD_CYCLES_VALU"] / (r["SQ_ACTIVE_INST_VALU"] * 64.0)
+    flops = (2 * r["SQ_INSTS_VALU_FMA_F64"] + r["SQ_INSTS_VALU_MUL_F64"] + r["SQ_INSTS_VALU_ADD_F64"]) * 64.0 * util
+    kern[name] = {"kernel": r["kernel"], "grid_size": r["grid_size"], "fp64_flops_per_item": flops / items,
+                  "valu_insts_per_item": r["SQ_INSTS_VALU"] * 64.0 / items, "lane_utilisation": util}
+    t = traffic.get(f'{r["kernel"]}@{r["grid_size"]}')
+    if t:
+        kern[name]["hbm_bytes_per_launch"] = t["hbm_bytes_per_launch"]
+latest["kernels"] = kern
 json.dump(latest, open(os.path.join(dst, "measured_latest.json"), "w"), indent=1)
 print(json.dumps(latest, indent=1))

@@ -16,11 +16,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--parcels", type=int, default=0)
+    ap.add_argument("--degenerate", type=float, default=0.01, help="fraction of degenerate parcels in the synthetic batch")
     ap.add_argument("workloads", nargs="+")
     a = ap.parse_args()
     pkg = load_package()
     L = pkg.lib()
     out = []
+    if a.degenerate != 0.01:
+        import functools
+
+        bench.synth_moments = functools.partial(bench.synth_moments, degenerate_frac=a.degenerate)
     for name in a.workloads:
         n = a.parcels or bench.workload_spec(name)["default_parcels"]
         wl = bench.make_workload(name, n)
