@@ -32,8 +32,8 @@ struct cloudy_plan {
     JitKernels jit;
     std::string jit_log;   // why not, when jit_on is false
     // thresholded plans compile their fused integrator on the first cloudy_ssprk33_steps call
-    mutable std::once_flag int_once, rs_once;
-    mutable hipFunction_t int_ssprk33 = nullptr, rs_coal = nullptr;
+    mutable std::once_flag int_once, rs_once, rsint_once;
+    mutable hipFunction_t int_ssprk33 = nullptr, rs_coal = nullptr, rs_int = nullptr;
     mutable std::string int_log;
 };
 
@@ -112,6 +112,16 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
     const void *in = r.in;
     void *out = r.out;
     const unsigned g1 = (unsigned)((n + kBlock - 1) / kBlock);
+    if (r.op == OP_RAINSHAFT_SSPRK33) {  // as launch_int_io() in launch_int_impl.hpp: whole columns per workgroup
+        const double *nodes = h.nodes_dev;
+        int nz = (int)r.nz, n_steps = r.n_steps;
+        size_t n_columns = r.n / r.nz;
+        double dt = r.dt, dz = r.dz;
+        const size_t cpb = kBlock / r.nz;
+        void *args[] = {&nodes, &nz, &n_columns, &ld, &in, &out, &dt, &dz, &n_steps};
+        return hipModuleLaunchKernel(plan->rs_int, (unsigned)((n_columns + cpb - 1) / cpb), 1, 1, kBlock, 1, 1, 0, r.stream,
+                                     args, nullptr);
+    }
     if (h.coal_style == CLOUDY_NUMERICAL_COAL) {
         void *args[] = {&n, &ld, &in, &out};
         const unsigned qb = (unsigned)quad_block(h.q.nq);
@@ -164,7 +174,12 @@ int run(const cloudy_plan *plan, const LaunchReq &r) {
     DeviceGuard guard(plan->h.device);
     if (guard.err != hipSuccess) return fail_hip(guard.err, "selecting the plan's device");
     bool use_jit = plan->jit_on && r.input_kind == IN_MOMENTS && r.physical_out &&
-                   (r.op == OP_COAL || (r.op == OP_SSPRK33 && !r.rainshaft));
+                   (r.op == OP_COAL || (r.op == OP_SSPRK33 && !r.rainshaft) || r.op == OP_RAINSHAFT_SSPRK33);
+    if (use_jit && r.op == OP_RAINSHAFT_SSPRK33) {
+        std::call_once(plan->rsint_once,
+                       [&] { (void)jit_get_rainshaft_integrator(plan->h, plan->rs_int, plan->int_log); });
+        use_jit = plan->rs_int != nullptr && plan->h.mode != MODE_MOVING;  // otherwise the ahead-of-time integrator
+    }
     if (use_jit && r.op == OP_COAL && r.rainshaft) {
         std::call_once(plan->rs_once, [&] { (void)jit_get_rainshaft(plan->h, plan->rs_coal, plan->int_log); });
         use_jit = plan->rs_coal != nullptr;
@@ -551,6 +566,8 @@ int cloudy_jit_selfcheck(const cloudy_plan_desc *d, const char *arch) {
     bool ok = jit_compile(jit_source(p->h, 0), a, !numerical && p->h.mode == MODE_ALLINF, code, log);
     if (ok && !numerical && p->h.mode != MODE_ALLINF) ok = jit_compile(jit_source(p->h, 1), a, true, code, log);
     if (ok && !numerical) ok = jit_compile(jit_source(p->h, 2), a, false, code, log);  // rainshaft cell body
+    if (ok && !numerical && p->h.n_vel > 0 && p->h.mode != MODE_MOVING)
+        ok = jit_compile(jit_source(p->h, 3), a, true, code, log);                     // fused column integrator
     delete p;
     if (!ok) return fail(CLOUDY_EUNSUPPORTED, "plan-time compilation failed: %.440s", log.c_str());
     return CLOUDY_OK;

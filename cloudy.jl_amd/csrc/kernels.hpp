@@ -1226,11 +1226,12 @@ __global__ void __launch_bounds__(kBlock)
 // all stages and steps, and the only cross-cell coupling -- the upwind flux of the cell above -- goes through LDS.
 // Every RHS evaluation first clamps negative moments of its argument to zero IN PLACE (rainshaft_helpers.jl:52 mutates
 // the array the integrator passed), which includes the FSAL evaluation on the final state of each step.
-template <int N, int P, int MODE, typename TIO>
-__global__ void __launch_bounds__(kBlock)
-    rainshaft_ssprk33_kernel(const KArgs<N, P> *__restrict__ Ag, const double *__restrict__ nodes, int nz,
-                             size_t n_columns, size_t ld, const TIO *u_in, TIO *u_out, double dt, double dz,
-                             int n_steps) {
+// (SPEC: the plan constants Ag / Sg are compile-time objects of a kernel compiled for the plan, jit.hpp)
+template <int N, int P, int MODE, typename TIO, bool SPEC = false>
+__device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__restrict__ Ag, const SediArgs *__restrict__ Sg,
+                                                       const double *__restrict__ nodes, int nz, size_t n_columns,
+                                                       size_t ld, const TIO *u_in, TIO *u_out, double dt, double dz,
+                                                       int n_steps) {
     __shared__ double sh_flux[N * 3][kBlock];
     constexpr bool kStash = (MODE != MODE_ALLINF) && (N <= 2);  // larger N: the LDS footprint would cost more occupancy than it buys
     __shared__ double sh_keep[kStash ? 3 * N * 3 : 1][kBlock];
@@ -1294,9 +1295,9 @@ __global__ void __launch_bounds__(kBlock)
             // flux exchange are the tensors loaded for the coalescence integrals -- otherwise all of them are live in
             // SGPRs at once and spill into VGPR lanes.
             size_t opaque_zero = 0;
-            asm volatile("" : "+s"(opaque_zero));
+            if (!SPEC) asm volatile("" : "+s"(opaque_zero));
             const KArgs<N, P> &As = *(Ag + opaque_zero);
-            const SediArgs &S = *reinterpret_cast<const SediArgs *>(Ag + opaque_zero + 1);
+            const SediArgs &S = *(Sg + opaque_zero);
             double f[N][3], nn[N], th[N], kk[N];
             bool all_small = true;
             if (active) {
@@ -1343,10 +1344,10 @@ __global__ void __launch_bounds__(kBlock)
                         }
                 }
                 size_t opaque_zero2 = 0;
-                asm volatile("" : "+s"(opaque_zero2));
+                if (!SPEC) asm volatile("" : "+s"(opaque_zero2));
                 const KArgs<N, P> &Ac = *(Ag + opaque_zero2);
                 double acc[N][3];
-                coal_ints_parcel<N, P, MODE>(Ac, nodes, nn, th, kk, acc);
+                coal_ints_parcel<N, P, MODE, false, SPEC>(Ac, nodes, nn, th, kk, acc);
                 if (kStash) {
                     asm volatile("" ::: "memory");  // reload, do not forward the stored registers
 #pragma unroll
@@ -1399,6 +1400,16 @@ __global__ void __launch_bounds__(kBlock)
                     u_out[(size_t)(A.off[m] + q) * ld + i] = (TIO)v;
                 }
     }
+}
+
+template <int N, int P, int MODE, typename TIO>
+__global__ void __launch_bounds__(kBlock)
+    rainshaft_ssprk33_kernel(const KArgs<N, P> *__restrict__ Ag, const double *__restrict__ nodes, int nz,
+                             size_t n_columns, size_t ld, const TIO *u_in, TIO *u_out, double dt, double dz,
+                             int n_steps) {
+    // SediArgs sits directly behind KArgs in the plan's constant block (launch_impl.hpp, OP_PREPARE)
+    rainshaft_ssprk33_body<N, P, MODE, TIO, false>(Ag, reinterpret_cast<const SediArgs *>(Ag + 1), nodes, nz, n_columns, ld,
+                                                   u_in, u_out, dt, dz, n_steps);
 }
 
 // get_cond_evap, src/Sources/Condensation.jl:22-37, behind rhs_condensation! (box_model_helpers.jl:55-67):

@@ -1101,6 +1101,31 @@ def test_code_object_cache_on_disk(gpu_cloudy, tmp_path, monkeypatch):
     assert plan2.specialized and len(list(d.glob("*.co"))) == 1
 
 
+def test_damaged_cache_entry_is_recompiled(gpu_cloudy, tmp_path):
+    """A cached code object that the runtime cannot load (another ROCm patch level, a damaged file) must not drop the plan
+    to the ahead-of-time kernels for ever: the entry is removed, compiled again and rewritten.  A second process (the
+    in-process module cache would hide it) finds the damaged file."""
+    import subprocess
+    import sys
+
+    d = tmp_path / "cc"
+    script = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as ge\n"
+        "cl = ge.load_package()\n"
+        "p = cl.Plan([1], [[0.0, 3.75], [3.75, 0.0]], (float('inf'),), (1e6, 1e-9), 0, specialize=1)\n"
+        "print('specialized', p.specialized)\n" % ROOT)
+    env = dict(os.environ, CLOUDY_HIP_CACHE_DIR=str(d))
+    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "specialized True" in r.stdout, r.stdout + r.stderr
+    (f,) = list(d.glob("*.co"))
+    good = f.read_bytes()
+    f.write_bytes(good[:64] + b"\0" * (len(good) - 64))        # ELF magic intact, everything else zeroed
+    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "specialized True" in r.stdout, r.stdout + r.stderr
+    assert f.read_bytes() == good or f.read_bytes()[:4] == b"\x7fELF" and f.read_bytes() != good[:64] + b"\0" * (len(good) - 64)
+
+
 def test_more_than_2_to_32_elements_per_array(gpu_cloudy):
     """Sizing for 288 GB: 8e8 parcels x 6 planes = 4.8e9 elements per array (38 GB in, 38 GB out) in one launch; the
     batch repeats a 2^20-parcel tile, so every tile of the output must equal the first (tools/big_batch_check.py)."""

@@ -70,11 +70,12 @@ VARIANTS = {   # bench variant -> (kernel name prefix, items per launch in the b
     "moving4": ("cloudy_jit_sorted_n4p2_f64", 2_500_000),
     "cfg4q": ("cloudy_jit_quad_n3q10_hydro_f64", 12_500_000),
     "cfg3a_fused_ssprk33": ("cloudy_jit_ssprk33_n2p3_f64", 10_000_000),
-    "rainshaft_ssprk33_columns": ("rainshaft_ssprk33_kernel<2, 3, 1, double>", 10_000_000),
+    "rainshaft_ssprk33_columns": (("cloudy_jit_rainshaft_ssprk33_n2p3_f64", "rainshaft_ssprk33_kernel<2, 3, 1, double>"), 10_000_000),
 }
 kern = {}
 for name, (prefix, items) in VARIANTS.items():
-    cands = [r for r in rows if r["kernel"].startswith(prefix) and "SQ_INSTS_VALU_FMA_F64" in r and r["grid_size"] >= 0.9 * items]
+    prefixes = (prefix,) if isinstance(prefix, str) else prefix
+    cands = [r for r in rows if r["kernel"].startswith(prefixes) and "SQ_INSTS_VALU_FMA_F64" in r and r["grid_size"] >= 0.9 * items]
     if not cands:
         continue
     r = max(cands, key=lambda x: x["grid_size"])
