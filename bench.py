@@ -457,6 +457,31 @@ def _cfg4q_variant(pkg, rank, world, measured, n=CFG4Q_PARCELS, reps=3):
     return out
 
 
+def _cpu_baseline_cfg4q(n_threads, target_seconds=6.0):
+    """The same-rule C oracle (oracle/cloudy_oracle_quad.c) on a bounded sample of the cfg4q batch, on the team size the
+    headline baseline found fastest."""
+    from oracle import cloudy_oracle as O
+
+    p = O.make_params([O.GAMMA] * 3, np.zeros((1, 1)), (INF, INF, INF), norms=NORMS)
+    kf = O.get_normalized_kernel_func(O.kernel_func(O.KF_HYDRODYNAMIC, 1e2 * np.pi), NORMS)
+    probe = synth_moments(3, 2000 * n_threads, SEED)
+    out = np.zeros_like(probe)
+    O.rhs_coal_numerical_batch(p, kf, 10, probe, n_threads=n_threads, out=out)
+    t0 = time.perf_counter()
+    O.rhs_coal_numerical_batch(p, kf, 10, probe, n_threads=n_threads, out=out)
+    per = max((time.perf_counter() - t0) / probe.shape[1], 1e-9)
+    n = int(min(max(target_seconds / per, 2000), 20_000_000))
+    mom = synth_moments(3, n, SEED)
+    out = np.zeros_like(mom)
+    t0 = time.perf_counter()
+    O.rhs_coal_numerical_batch(p, kf, 10, mom, n_threads=n_threads, out=out)
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="parcel-RHS/s", cores=n_threads, kind="port",
+                sample=f"{n} parcels of the cfg4q batch, oracle/cloudy_oracle_quad.c (the reference's NumericalCoalStyle "
+                       f"structure with the same fixed 10-point rule; the reference's adaptive quadgk is ~1e3 x more "
+                       f"density evaluations), OpenMP x{n_threads}, {dt:.1f} s")
+
+
 def _kernel_label(plan, n_modes, P):
     """Name of the kernel behind cloudy_coal_rhs for this plan, as rocprofv3 shows it (jit.hpp: jit_suffix)."""
     sfx = f"_n{n_modes}p{P}_f64"
@@ -742,6 +767,7 @@ def main():
         cpu = _cpu_baseline(args.workload)
         if variants:
             variants["cfg3b"]["cpu_baseline"] = _cpu_baseline("cfg3b", target_seconds=10.0)
+            variants["cfg4q"]["cpu_baseline"] = _cpu_baseline_cfg4q(cpu["cores"], target_seconds=6.0)
 
     if rank == 0:
         out = {

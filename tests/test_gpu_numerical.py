@@ -112,6 +112,20 @@ def test_numerical_families_vs_same_rule_oracle(gpu_cloudy, oracle, dist_types, 
     print(f"{dist_types} {kname} nq={nq}: {worst:.2e}")
 
 
+def test_numerical_plan_with_other_shape_clamp(gpu_cloudy, oracle):
+    """param_range k <= 5 (test_ParticleDistributions_correctness.jl:128-132) and k <= 30: the plan stages a start-value
+    table for its own k range; closures clamped at the bounds sit on the table's end points"""
+    cloudy = gpu_cloudy
+    for k_range in ((float(np.finfo(np.float64).eps), 5.0), (0.5, 30.0)):
+        par, op, okf = numerical_case(cloudy, oracle, [1, 1], "hydro", 10, k_range=k_range)
+        mom = bench.synth_moments(2, 3000, seed=77)
+        got = run_numerical(cloudy, par, mom)
+        want, scale, noise = oracle.rhs_coal_numerical_batch(op, okf, 10, mom, with_noise=True)
+        prm = oracle.update_dist_batch(op, mom)
+        assert prm[2].max() <= k_range[1] and (prm[2] == k_range[1]).any()
+        assert_same_rule(got, want, scale, noise, f"k_range {k_range}")
+
+
 @pytest.mark.parametrize("kname,kc", [("constant", [[1e-4]]), ("linear", [[0.0, 5.0], [5.0, 0.0]])])
 def test_polynomial_kernels_match_the_analytic_path_on_the_device(gpu_cloudy, oracle, kname, kc):
     """one mode: weighting_fn == 1, the Numerical and Analytical closures coincide, and the rule integrates polynomial
