@@ -232,9 +232,9 @@ struct MovingGrid {
     __device__ __forceinline__ MovingGrid(double xt_, int nbpl) : xt(xt_) {
         const double x_lb = fmin(1e-5, 1e-5 * xt_);
         nb = (int)floor(double(nbpl) * log10(xt_ / x_lb));
-        x_min = log(x_lb);
-        dx = (log(xt_) - x_min) / double(nb);
-        ratio = exp(dx);
+        x_min = log_pos(x_lb);
+        dx = (log_pos(xt_) - x_min) / double(nb);
+        ratio = exp_fin(dx);
     }
     __device__ __forceinline__ int n_bins() const { return nb; }
     __device__ __forceinline__ double node_x(int j) const { return exp(x_min + double(j) * dx); }
@@ -245,7 +245,7 @@ struct MovingGrid {
     // `phase` is a wave-uniform iteration counter: lanes sit at different nodes j of their own grids, and an anchor keyed
     // on j would make every lane's exp() run (masked) in almost every iteration of the wave
     __device__ __forceinline__ double next_x(double x_run, int j_next, int phase) const {
-        return (phase & 15) == 15 ? exp(x_min + double(j_next) * dx) : x_run * ratio;
+        return (phase & 15) == 15 ? exp_fin(x_min + double(j_next) * dx) : x_run * ratio;
     }
     __device__ __forceinline__ double node_x(int, double x_run) const { return x_run; }
     __device__ __forceinline__ SimpsonNode node(int j, double x_run, bool late) const {
@@ -312,7 +312,7 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double n, 
                 const SimpsonNode nd = grid.node(j, xr, false);
                 xr = grid.next_x(xr, j + 1, j);
                 const double t = nd.x * inv_th;
-                const double e = nd.wdx * exp(fma(k, nd.lx - lnth, -t));
+                const double e = nd.wdx * exp_fin(fma(k, nd.lx - lnth, -t));
 #pragma unroll
                 for (int q = 0; q < NS; ++q) U[q] = fma(e, grid.upow(j, q), U[q]);  // tabulated powers: SGPR operand
             }
@@ -340,9 +340,9 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double n, 
 #pragma unroll 1
             for (int jj = J - 1, it = 0; jj >= 0; --jj, ++it) {
                 const double lx = fma(double(jj), grid.dx, grid.x_min);
-                x = (it & 15) == 0 ? exp(lx) : x * inv_ratio;  // re-anchored every 16th iteration (wave-uniform phase)
+                x = (it & 15) == 0 ? exp_fin(lx) : x * inv_ratio;  // re-anchored every 16th iteration (wave-uniform phase)
                 const double t = x * inv_th;
-                const double e = simpson_weight_node(jj + 1, nb) * grid.dx * exp(fma(k, lx - lnth, -t));
+                const double e = simpson_weight_node(jj + 1, nb) * grid.dx * exp_fin(fma(k, lx - lnth, -t));
 #pragma unroll
                 for (int q = 0; q < NS; ++q) H[q] = fma(H[q], Rq[q], e);
             }
@@ -354,12 +354,12 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double n, 
                 pw *= u0;
             }
             j = J;
-            xr = J < nb ? exp(fma(double(J), grid.dx, grid.x_min)) : 0.0;
+            xr = J < nb ? exp_fin(fma(double(J), grid.dx, grid.x_min)) : 0.0;
         }
         if (j > 0) {
             // P(a, z0) and g_a = dP/dz at z0 for the M orders a = k + p2 (downward from a_top)
             const double invz0 = 1.0 / z0;
-            double E = exp(fma(a_top, log_pos(xt) - lnth, -z0) - lg_top);  // E(a_top, z0) = z0^a e^-z0 / Gamma(a+1)
+            double E = exp_fin(fma(a_top, log_pos(xt) - lnth, -z0) - lg_top);  // E(a_top, z0) = z0^a e^-z0 / Gamma(a+1)
             double Pv = inc_gamma_p_from_E(a_top, z0, E, nullptr);
             double a = a_top;
             double xtp[M];  // x_t^p1
@@ -405,8 +405,8 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double n, 
         const double t = nd.x * inv_th, zr = nd.xmx * inv_th;
         const bool zpos = zr > 0.0;  // P(a, z <= 0) = 0: such a node (never on the reference grid) contributes nothing
         const double z = zpos ? zr : 1.0;
-        const double h0 = zpos ? nd.wdx * exp(fma(k, nd.lx - lnth, -t)) : 0.0;
-        const double E0 = exp(fma(a_top, nd.lxmx - lnth, -z) - lg_top);
+        const double h0 = zpos ? nd.wdx * exp_fin(fma(k, nd.lx - lnth, -t)) : 0.0;
+        const double E0 = exp_fin(fma(a_top, nd.lxmx - lnth, -z) - lg_top);
         double Pz[M];
         Pz[M - 1] = inc_gamma_p_from_E(a_top, z, E0, nullptr);
         const double invz = recip_fast(z);
@@ -562,7 +562,7 @@ __device__ __forceinline__ double moving_threshold(const KArgs<N, P> &A, int i, 
         double y = A.inv_tab[i][0];
 #pragma unroll
         for (int d = 1; d < kInvTerms; ++d) y = fma(y, t, A.inv_tab[i][d]);
-        x0 = exp(y);
+        x0 = exp_fin(y);
     }
     return fmax(th * inc_gamma_inv(k, percentile, 1.0 - percentile, x0), minx);
 }
@@ -1175,13 +1175,13 @@ __device__ __forceinline__ void sedi_flux_parcel(const int32_t (&dist_type)[N], 
     for (int m = 0; m < N; ++m) {
         const int dtp = dist_type[m];
         const bool gam = (dtp == DIST_GAMMA || dtp == DIST_EXP);
-        const double lnth = (dtp == DIST_LOGNORMAL) ? th[m] : log(th[m]);
+        const double lnth = (dtp == DIST_LOGNORMAL) ? th[m] : log_pos(th[m]);
         double s[3] = {0.0, 0.0, 0.0};
         for (int v = 0; v < S.n_vel; ++v) {
             const double qv = S.vel[v][1];
             if (gam) {
                 // M_qv from the log-gamma ratio once, the higher orders by M_{q+1} = M_q theta (k + q)
-                double mom = nn[m] * (qv == 0.0 ? 1.0 : exp(fma(qv, lnth, log_gamma_ratio(kk[m], qv))));
+                double mom = nn[m] * (qv == 0.0 ? 1.0 : exp_fin(fma(qv, lnth, log_gamma_ratio(kk[m], qv))));
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     s[j] = fma(-S.vel[v][0], mom, s[j]);

@@ -58,7 +58,7 @@ __device__ __forceinline__ void coal_rhs_quad_body(const KArgs<N, 1> &A, const Q
             const double s2 = 1.4142135623730951 * kk[m];
 #pragma unroll
             for (int a = 0; a < nq; ++a) {
-                X[m][a] = kf_aux<KIND>(exp(fma(s2, gh[a], th[m])));
+                X[m][a] = kf_aux<KIND>(exp_fin(fma(s2, gh[a], th[m])));
                 V[m][a] = nn[m] * gh[nq + a];
             }
         } else {
@@ -130,7 +130,7 @@ __device__ __forceinline__ void coal_rhs_quad_body(const KArgs<N, 1> &A, const Q
 #pragma unroll
                         for (int m = 0; m < N; ++m) {
                             if (m == j) continue;
-                            const double rho = exp(fmin(lg[m](xs, lx) - own, 700.0));
+                            const double rho = exp_fin(fmin(lg[m](xs, lx) - own, 700.0));
                             den += rho;
                             if (m > j) up += rho;
                         }
