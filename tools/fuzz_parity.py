@@ -222,18 +222,84 @@ def check_callers(pkg, cfg, cd, op, mom, plan, k_range, scale):
     assert np.allclose(dm.to_numpy()[okc], wc[okc], rtol=1e-10, atol=0), "rhs_condensation"
 
 
+def random_numerical_config(rng, wild=False):
+    """NumericalCoalStyle plans: random N, closure families (Exponential / Gamma / Lognormal), kernel function family with
+    random parameters, rule order, plane type."""
+    N = int(rng.integers(1, 5))
+    dist = [int(rng.choice([0, 1, 1, 1, 3])) for _ in range(N)]
+    kind = int(rng.integers(0, 4))
+    params = {0: (float(10.0 ** rng.uniform(-6, -2)),), 1: (float(10.0 ** rng.uniform(-1, 1.5)),),
+              2: (float(10.0 ** rng.uniform(1, 3)),),
+              3: (float(10.0 ** rng.uniform(-10.5, -8.0)), float(10.0 ** rng.uniform(9, 10.5)), float(10.0 ** rng.uniform(0, 1.5)))}[kind]
+    nq = int(rng.choice([2, 3, 4, 6, 8, 10, 10, 10, 12, 16, 20, 32]))
+    norms, k_range = bench.NORMS, (float(np.finfo(np.float64).eps), 10.0)
+    if wild:
+        norms = (float(10.0 ** rng.uniform(3, 9)), float(10.0 ** rng.uniform(-12, -7)))
+        k_range = (float(rng.choice([np.finfo(np.float64).eps, 1e-3, 0.1])), float(rng.choice([5.0, 10.0, 25.0])))
+    return dict(N=N, dist=dist, kind=kind, params=params, nq=nq, dtype=int(rng.choice([0, 0, 0, 1])), norms=norms,
+                k_range=k_range)
+
+
+def check_numerical_config(pkg, cfg, n, seed):
+    """-> (worst excess of |hip - oracle| over the oracle's own (1 - w) rounding noise, in units of scale; |jit - aot|)"""
+    kf_cls = [pkg.ConstantKernelFunction, pkg.LinearKernelFunction, pkg.HydrodynamicKernelFunction, pkg.LongKernelFunction]
+    kfn = pkg.get_normalized_kernel_func(kf_cls[cfg["kind"]](*cfg["params"]), cfg["norms"])
+    okf = O.get_normalized_kernel_func(O.kernel_func(cfg["kind"], *cfg["params"]), cfg["norms"])
+    op = O.make_params(cfg["dist"], np.zeros((1, 1)), (INF,) * cfg["N"], norms=cfg["norms"], k_range=cfg["k_range"])
+    mom = moments_for(cfg["dist"], n, seed)
+    tio = np.float64 if cfg["dtype"] == 0 else np.float32
+    mom_in = mom.astype(tio).astype(np.float64)
+    jit = pkg.NumericalPlan(cfg["dist"], kfn, cfg["norms"], cfg["nq"], k_range=cfg["k_range"], dtype=cfg["dtype"], specialize=1)
+    aot = pkg.NumericalPlan(cfg["dist"], kfn, cfg["norms"], cfg["nq"], k_range=cfg["k_range"], dtype=cfg["dtype"], specialize=-1)
+    a, b = run(pkg, jit, mom_in, tio), run(pkg, aot, mom_in, tio)
+    want, scale, noise = O.rhs_coal_numerical_batch(op, okf, cfg["nq"], mom_in, with_noise=True)
+    keep = np.ones(mom.shape[1], dtype=bool)
+    if 3 in cfg["dist"]:
+        # very narrow Lognormal modes (sigma -> eps clamp, or float-rounded moments): the Gauss-Hermite nodes exp(mu +
+        # sqrt(2) sigma t) coincide to within sigma, and a kernel that vanishes on the diagonal (hydrodynamic:
+        # |x^(2/3) - y^(2/3)|) amplifies the last-place difference between the device's cbrt and the host's pow by 1/sigma
+        prm = O.update_dist_batch(op, mom_in)
+        for i, t in enumerate(cfg["dist"]):
+            if t == 3:
+                keep &= prm[3 * i + 2] > 1e-3
+    with np.errstate(over="ignore", invalid="ignore"):
+        fin = np.isfinite(want) & np.isfinite(want.astype(tio)) & keep[None, :]
+        err = np.abs(a - want) - 8.0 * noise
+    bound = 1e-11 * scale if cfg["dtype"] == 0 else 6.0e-8 * np.abs(want) + 1e-11 * scale + 1.5e-45
+    bad = fin & ~(err <= bound) & (bound < 3.0e38)
+    err = np.where(bound < 3.0e38, np.maximum(err, 0.0), 0.0)
+    assert not bad.any(), f"{bad.sum()} entries beyond tolerance, worst {np.max(err[fin] / np.maximum(scale[fin], 1e-300)):.3e}"
+    both = np.isfinite(a) & np.isfinite(b) & keep[None, :]
+    dj = float(np.max(np.abs(a - b)[both] / np.maximum(scale[both], 1e-300))) if both.any() else 0.0
+    assert dj <= (1e-13 if cfg["dtype"] == 0 else 1e-6), f"plan-time compiled and ahead-of-time kernels differ by {dj:.2e} of scale"
+    return (float(np.max(err[fin] / np.maximum(scale[fin], 1e-300))) if fin.any() else 0.0), dj
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--parcels", type=int, default=400)
     ap.add_argument("--wild", action="store_true", help="also randomise norms and the k clamp range")
+    ap.add_argument("--numerical", action="store_true", help="NumericalCoalStyle (fixed Gauss rule) plans instead of tensor plans")
     a = ap.parse_args()
     pkg = load_package()
     rng = np.random.default_rng(a.seed)
     t0 = time.time()
     fails = 0
     for c in range(a.configs):
+        if a.numerical:
+            cfg = random_numerical_config(rng, a.wild)
+            tag = (f"#{c} numerical N={cfg['N']} dist={cfg['dist']} kernel={['constant', 'linear', 'hydro', 'long'][cfg['kind']]}"
+                   f"{tuple(f'{v:.3g}' for v in cfg['params'])} nq={cfg['nq']} dtype={cfg['dtype']}"
+                   + (f" norms=({cfg['norms'][0]:.1e},{cfg['norms'][1]:.1e}) k_range={cfg['k_range']}" if a.wild else ""))
+            try:
+                worst, dj = check_numerical_config(pkg, cfg, a.parcels, 3000 + c)
+                print(f"ok   {tag}: max (|hip-oracle| - noise)/scale {worst:.2e}, |jit-aot|/scale {dj:.1e}", flush=True)
+            except (AssertionError, pkg.CloudyError) as e:
+                fails += 1
+                print(f"FAIL {tag}: {e}", flush=True)
+            continue
         cfg = random_config(rng, a.wild)
         tag = (f"#{c} N={cfg['N']} P={cfg['P']} dist={cfg['dist']} {'moving' if cfg['moving'] else 'fixed'} "
                f"thr={tuple(f'{t:.2g}' for t in cfg['thr'])} dtype={cfg['dtype']}"
