@@ -214,7 +214,9 @@ struct FixedGrid {
     __device__ __forceinline__ int n_bins() const { return nb; }
     __device__ __forceinline__ double node_x(int j) const { return nd[kNodeStride * j]; }
     // running-abscissa interface shared with MovingGrid (a table needs none)
-    __device__ __forceinline__ double first_x() const { return 0.0; }
+    __device__ __forceinline__ double first_x() const { return nd[0]; }
+    __device__ __forceinline__ double first_lx() const { return nd[1]; }
+    __device__ __forceinline__ double log_step() const { return nd[kNodeStride + 1] - nd[1]; }  // dx of the log-uniform grid
     __device__ __forceinline__ double next_x(double, int, int) const { return 0.0; }
     __device__ __forceinline__ double node_x(int j, double) const { return nd[kNodeStride * j]; }
     __device__ __forceinline__ SimpsonNode node(int j, double, bool late) const { return node(j, late); }
@@ -241,7 +243,9 @@ struct MovingGrid {
     // The nodes are visited in order, so x_j = exp(x_min + j dx) (ParticleDistributions.jl:566) is carried along as
     // x_{j-1} e^{dx} and re-anchored with a true exp() every 16th node: at most 15 roundings of drift (< 2e-15), one
     // multiplication instead of ~31 instructions for the others.
-    __device__ __forceinline__ double first_x() const { return exp(x_min); }
+    __device__ __forceinline__ double first_x() const { return exp_fin(x_min); }
+    __device__ __forceinline__ double first_lx() const { return x_min; }
+    __device__ __forceinline__ double log_step() const { return dx; }
     // `phase` is a wave-uniform iteration counter: lanes sit at different nodes j of their own grids, and an anchor keyed
     // on j would make every lane's exp() run (masked) in almost every iteration of the wave
     __device__ __forceinline__ double next_x(double x_run, int j_next, int phase) const {
@@ -305,56 +309,62 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double n, 
 #pragma unroll
         for (int q = 0; q < NS; ++q) U[q] = 0.0;
         const double inv_xt = 1.0 / xt;
-        if constexpr (Grid::kHasPowers) {
-#pragma unroll 1
-            for (; j < nb; ++j) {
-                if (!(grid.node_x(j, xr) <= x_early)) break;
-                const SimpsonNode nd = grid.node(j, xr, false);
-                xr = grid.next_x(xr, j + 1, j);
-                const double t = nd.x * inv_th;
-                const double e = nd.wdx * exp_fin(fma(k, nd.lx - lnth, -t));
-#pragma unroll
-                for (int q = 0; q < NS; ++q) U[q] = fma(e, grid.upow(j, q), U[q]);  // tabulated powers: SGPR operand
-            }
-        } else {
-            // Per-parcel grid: no table of node powers.  The nodes are geometric, u_j = u_0 rho^j, so
-            //   U_q = u_0^q sum_j e_j (rho^q)^j
-            // is a polynomial in rho^q with coefficients e_j: Horner from the LAST early node down, one FMA per sum and
-            // node with the per-parcel constants rho^q (the forward form needs a multiplication and an addition each).
-            // The number of early nodes follows from the grid directly (x_j = exp(x_min + j dx) <= x_early); a node on
-            // the boundary may fall either side, both evaluations are valid.
+        // The early nodes are a geometric progression, u_j = u_0 rho^j with rho = e^dx (ParticleDistributions.jl:566,
+        // 604-610), their Simpson weights are 1 but for the first four (:698-710), and t_j = z0 u_j <= 1 there.  With
+        // e^-t expanded (19 terms: t^19/19! < 1e-17),
+        //   U_q = sum_j (w_j dx) (z0 u_j)^k e^{-z0 u_j} u_j^q = z0^k sum_m (-z0)^m/m! V_{q+m},   V_s = sum_{j<J} w_j dx u_j^(k+s),
+        // and V_s is a geometric series with a four-term end correction:
+        //   V_s = dx u_J^(k+s) [ (1 - b_s)/(r_s - 1) - b_s c(r_s) ],   r_s = rho^(k+s),  b_s = (u_0/u_J)^(k+s) = r_s^-J,
+        //   c(r) = 31/48 - 11/48 r + 5/48 r^2 - 1/48 r^3          (u_J = u_0 rho^J: the first node that is NOT early).
+        // So the J early nodes (45-110 of them) cost NS + 19 closed-form terms instead of J exponentials and J x NS
+        // multiply-adds, every lane does the same work whatever its J, and no table of node powers is read.  Everything
+        // is kept relative to u_J^k (t_J = z0 u_J ~ 1), so nothing over- or underflows for clamped closures:
+        //   U_q = t_J^k u_J^q sum_m gamma_m W_{q+m},  gamma_m = (-t_J)^m/m!,  W_s = dx [ (1 - b_s)/(r_s - 1) - b_s c(r_s) ].
+        // Same sums as the node loop to rounding: the one systematic difference is that k ln u_J is rounded once for
+        // all nodes instead of once per node (~1e-14 relative instead of ~1e-15; measured in tests).
+        {
+            constexpr int MX = 18;                         // Taylor order of e^-t on [0, ~1]
+            const double lx0 = grid.first_lx(), dxl = grid.log_step();
             int J = 0;
-            const double x_first = xr;  // = grid.first_x()
-            if (x_early >= x_first) {
-                const double jf = floor((log_pos(x_early) - grid.x_min) / grid.dx) + 1.0;
+            if (x_early >= xr) {  // xr = the first node
+                const double jf = floor((log_pos(x_early) - lx0) / dxl) + 1.0;  // nodes with x_j <= x_early
                 J = jf < double(nb) ? (int)jf : nb;
             }
-            double Rq[NS], H[NS];
-            Rq[0] = 1.0;
+            // fewer than four early nodes (the end correction assumes the first four): none; and never the last
+            // three nodes, whose weights differ (x_early <= x_t / 10 keeps 15 nodes of distance)
+            if (J < 4 || J > nb - 4) J = 0;
+            if (J > 0) {
+                const double Jd = double(J);
+                const double xJ = exp_fin(fma(Jd, dxl, lx0));      // node J itself, as the reference computes it
+                const double uJ = xJ * inv_xt, tJ = xJ * inv_th;
+                const double rho = exp_fin(dxl), rhoJinv = exp_fin(-Jd * dxl);
+                double r = exp_fin(k * dxl), b = exp_fin(-Jd * k * dxl);
+                double gam[MX + 1];
+                gam[0] = 1.0;
 #pragma unroll
-            for (int q = 1; q < NS; ++q) Rq[q] = Rq[q - 1] * grid.ratio;
+                for (int m = 1; m <= MX; ++m) gam[m] = gam[m - 1] * (-tJ) * (1.0 / double(m));
 #pragma unroll
-            for (int q = 0; q < NS; ++q) H[q] = 0.0;
-            const double inv_ratio = 1.0 / grid.ratio;
-            double x = 0.0;
-#pragma unroll 1
-            for (int jj = J - 1, it = 0; jj >= 0; --jj, ++it) {
-                const double lx = fma(double(jj), grid.dx, grid.x_min);
-                x = (it & 15) == 0 ? exp_fin(lx) : x * inv_ratio;  // re-anchored every 16th iteration (wave-uniform phase)
-                const double t = x * inv_th;
-                const double e = simpson_weight_node(jj + 1, nb) * grid.dx * exp_fin(fma(k, lx - lnth, -t));
+                for (int s = 0; s < NS + MX; ++s) {
+                    // s = 0: k dx can be tiny (clamped closures): the two differences through expm1
+                    const double omb = s == 0 ? -expm1(-Jd * k * dxl) : 1.0 - b;
+                    const double rm1 = s == 0 ? expm1(k * dxl) : r - 1.0;
+                    const double c = fma(r, fma(r, fma(r, -1.0 / 48.0, 5.0 / 48.0), -11.0 / 48.0), 31.0 / 48.0);
+                    const double W = dxl * fma(omb, recip_fast(rm1), -(b * c));
 #pragma unroll
-                for (int q = 0; q < NS; ++q) H[q] = fma(H[q], Rq[q], e);
+                    for (int q = 0; q < NS; ++q)
+                        if (s - q >= 0 && s - q <= MX) U[q] = fma(W, gam[s - q], U[q]);
+                    r *= rho;
+                    b *= rhoJinv;
+                }
+                double f = exp_fin(k * log_pos(tJ));  // t_J^k
+#pragma unroll
+                for (int q = 0; q < NS; ++q) {
+                    U[q] *= f;
+                    f *= uJ;
+                }
+                j = J;
+                xr = xJ;
             }
-            double pw = 1.0;
-            const double u0 = x_first * inv_xt;
-#pragma unroll
-            for (int q = 0; q < NS; ++q) {
-                U[q] = H[q] * pw;
-                pw *= u0;
-            }
-            j = J;
-            xr = J < nb ? exp_fin(fma(double(J), grid.dx, grid.x_min)) : 0.0;
         }
         if (j > 0) {
             // P(a, z0) and g_a = dP/dz at z0 for the M orders a = k + p2 (downward from a_top)
