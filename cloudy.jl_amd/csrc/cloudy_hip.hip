@@ -413,11 +413,6 @@ int build_host_plan(const cloudy_plan_desc *d, cloudy_plan **out, std::vector<do
                 nodes.push_back(xt - x);
                 nodes.push_back(std::log(xt - x));
                 nodes.push_back(simpson_weight(j, n_bins) * dx);
-                double up = 1.0;  // (x / x_t)^q for the early-node power sums
-                for (int q = 0; q < kNodePowers; ++q) {
-                    nodes.push_back(up);
-                    up *= x / xt;
-                }
             }
         }
         h.mode = any_finite ? MODE_FIXED : MODE_ALLINF;

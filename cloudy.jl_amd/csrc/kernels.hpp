@@ -26,8 +26,7 @@ enum { IN_MOMENTS = 0, IN_PARAMS = 1 };
 enum { MODE_ALLINF = 0, MODE_FIXED = 1, MODE_MOVING = 2 };
 enum { DIST_EXP = 0, DIST_GAMMA = 1, DIST_MONO = 2, DIST_LOGNORMAL = 3 };
 constexpr int kEarlyTerms = 16;  // Taylor terms of the early-node expansion (see msh_grid for the radius)
-constexpr int kNodePowers = 7 + kEarlyTerms;  // (x/x_t)^q, q = 0..M+kEarlyTerms-1, M <= 7
-constexpr int kNodeStride = 5 + kNodePowers;  // x, ln x, x_t - x, ln(x_t - x), w * dx, then the powers of x/x_t
+constexpr int kNodeStride = 5;  // x, ln x, x_t - x, ln(x_t - x), w * dx  (the early nodes need no table: msh_grid)
 constexpr int kBlock = 256;
 constexpr int kInvTerms = 16;  // coefficients of the start-value polynomial of the percentile threshold (moving_threshold)
 
@@ -209,8 +208,6 @@ struct SimpsonNode {
 struct FixedGrid {
     const double *__restrict__ nd;
     int nb;
-    static constexpr bool kHasPowers = true;  // (x_j/x_t)^q tabulated: the early-node power sums are one FMA each
-    __device__ __forceinline__ double upow(int j, int q) const { return nd[kNodeStride * j + 5 + q]; }
     __device__ __forceinline__ int n_bins() const { return nb; }
     __device__ __forceinline__ double node_x(int j) const { return nd[kNodeStride * j]; }
     // running-abscissa interface shared with MovingGrid (a table needs none)
@@ -229,8 +226,6 @@ struct FixedGrid {
 struct MovingGrid {
     double xt, x_min, dx, ratio;
     int nb;
-    static constexpr bool kHasPowers = false;
-    __device__ __forceinline__ double upow(int, int) const { return 0.0; }
     __device__ __forceinline__ MovingGrid(double xt_, int nbpl) : xt(xt_) {
         const double x_lb = fmin(1e-5, 1e-5 * xt_);
         nb = (int)floor(double(nbpl) * log10(xt_ / x_lb));
