@@ -273,8 +273,8 @@ struct MovingGrid {
 // so the nodes only feed the power sums S_q = sum_j (w_j dx) t_j^(k+q) e^{-t_j} (one exp per node), and the
 // incomplete gamma is evaluated once, at z0, for the whole group.
 template <int P, typename Grid>
-__device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double n, double th, double k, bool is_gamma,
-                                         const double (&Mk)[P + 2], double (&msh)[(P + 2) * (P + 3) / 2]) {
+__device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double th, double k, bool is_gamma,
+                                         double (&msh)[(P + 2) * (P + 3) / 2]) {  // WITHOUT msh_pref(n, k) M_p2: the caller applies them
     constexpr int M = P + 2;
     constexpr int T = M * (M + 1) / 2;
     constexpr int NS = M + kEarlyTerms;
@@ -430,11 +430,8 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double n, 
             h *= nd.x;
         }
     }
-    const double pref = is_gamma ? n / tgamma(k) : n;
 #pragma unroll
-    for (int p1 = 0; p1 < M; ++p1)
-#pragma unroll
-        for (int p2 = p1; p2 < M; ++p2) msh[tri<M>(p1, p2)] = pref * Mk[p2] * acc[tri<M>(p1, p2)];
+    for (int t = 0; t < T; ++t) msh[t] = acc[t];
 }
 
 // CLOUDY_F32_FAST plans: the same Simpson pass with single-precision arithmetic for everything that is done per
@@ -444,8 +441,8 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double n, 
 // outside this function (closure inversion, moments, F/min, Q/R/S) stays fp64.  Expected accuracy of the msh
 // entries ~1e-6 relative; tests report the error against the fp64 oracle.
 template <int P, typename Grid>
-__device__ __forceinline__ void msh_grid_f32(const Grid &grid, double xt, double n, double th, double k, bool is_gamma,
-                                             const double (&Mk)[P + 2], double (&msh)[(P + 2) * (P + 3) / 2]) {
+__device__ __forceinline__ void msh_grid_f32(const Grid &grid, double xt, double th, double k, bool is_gamma,
+                                             double (&msh)[(P + 2) * (P + 3) / 2]) {  // WITHOUT the factor M_p2
     constexpr int M = P + 2;
     constexpr int T = M * (M + 1) / 2;
     constexpr int NT = 10;
@@ -545,11 +542,8 @@ __device__ __forceinline__ void msh_grid_f32(const Grid &grid, double xt, double
             h *= xf;
         }
     }
-    const double pref = is_gamma ? n / tgamma(k) : n;
 #pragma unroll
-    for (int p1 = 0; p1 < M; ++p1)
-#pragma unroll
-        for (int p2 = p1; p2 < M; ++p2) msh[tri<M>(p1, p2)] = pref * Mk[p2] * (double)acc[tri<M>(p1, p2)];
+    for (int t = 0; t < T; ++t) msh[t] = (double)acc[t];
 }
 
 // compute_threshold, ParticleDistributions.jl:747-761.  The percentile is a plan constant, so gamma_inc_inv(k, p, 1 - p)
@@ -637,19 +631,23 @@ __device__ __forceinline__ int regime_bucket(float key) {
 template <int BS = kBlock>
 __device__ __forceinline__ void regime_rank(bool valid, int bucket_if_valid, unsigned int *sh_cnt,
                                             unsigned short *sh_perm) {
-    const int t = threadIdx.x;
+    // (the lane index through an opaque copy, and the scan through ds_bpermute on addresses derived from it rather than
+    // __shfl_up: otherwise the shuffle addresses and LDS addresses of one ranking are kept -- spilled to scratch in the
+    // P = 5 families -- across a whole Simpson pass just to be reused by the next ranking)
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
     const int bucket = valid ? bucket_if_valid : BS - 1;
     sh_cnt[t] = 0u;
     __syncthreads();
     const unsigned int pos = atomicAdd(&sh_cnt[bucket], 1u);
     __syncthreads();
-    // exclusive prefix sum of the 256 counters: inclusive scan inside each wave, wave totals through LDS
+    // exclusive prefix sum of the counters: inclusive scan inside each wave, wave totals through LDS
     const unsigned int c = sh_cnt[t];
     unsigned int incl = c;
     const int lane = t & 63;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        const unsigned int up = __shfl_up(incl, d, 64);
+        const unsigned int up = (unsigned int)__builtin_amdgcn_ds_bpermute(((lane - d) & 63) << 2, (int)incl);
         if (lane >= d) incl += up;
     }
     __shared__ unsigned int sh_wave_tot[BS / 64];
@@ -685,59 +683,89 @@ __device__ __forceinline__ bool mode_has_pass(const KArgs<N, P> &A, int k) {
     return false;
 }
 
+// Split in two so that the regime-sorted kernel can drop every register it does not need across the Simpson pass:
+// promoted_pass is the pass itself (needs theta, k and whether n > 0), promoted_finish forms the products and the
+// contraction from the mode's moments (needs n).
+// the factor n / Gamma(k) (Gamma mode) or n (Exponential) that msh_grid leaves out
+__device__ __forceinline__ double msh_pref(bool is_gamma, double n, double k) { return is_gamma ? n / tgamma(k) : n; }
+
+struct PromotedFlags {
+    bool thresholded, mono, mono_below;
+};
+
 template <int N, int P, int MODE, bool FAST = false>
-__device__ __forceinline__ void promoted_mode(const KArgs<N, P> &A, const double *__restrict__ nodes, int k, double n,
-                                              double th, double kk, const double (&Mk)[P + 2], double &T0, double &T1,
-                                              double &T2) {
+__device__ __forceinline__ PromotedFlags promoted_pass(const KArgs<N, P> &A, const double *__restrict__ nodes, int k,
+                                                       bool n_pos, double th, double kk,
+                                                       double (&msh)[(P + 2) * (P + 3) / 2]) {
     constexpr int M = P + 2;
     constexpr int T = M * (M + 1) / 2;
-    T0 = T1 = T2 = 0.0;
-    bool thresholded = false;
-    double msh[T];
+    PromotedFlags f{false, false, false};
 #pragma unroll
-    for (int t = 0; t < T; ++t) msh[t] = 0.0;
+    for (int t = 0; t < T; ++t) msh[t] = 0.0;  // moment_source_helper / M_p2 (Simpson branches)
     if (MODE == MODE_FIXED) {
         if (k < N - 1 && A.finite[k]) {  // wave-uniform
-            thresholded = true;
+            f.thresholded = true;
             if (A.dist_type[k] == DIST_MONO) {
                 // moment_source_helper, ParticleDistributions.jl:557-564: n^2 theta^(p1+p2) if theta < x_t/2, else 0
-                const bool below = th < 0.5 * A.thr[k];
-#pragma unroll
-                for (int p1 = 0; p1 < M; ++p1)
-#pragma unroll
-                    for (int p2 = p1; p2 < M; ++p2) msh[tri<M>(p1, p2)] = below ? Mk[p1] * Mk[p2] : 0.0;
-            } else if (n > 0.0) {
+                f.mono = true;
+                f.mono_below = th < 0.5 * A.thr[k];
+            } else if (n_pos) {
                 const FixedGrid grid{nodes + (size_t)A.node_off[k] * kNodeStride, A.n_bins[k]};
                 if (FAST)
-                    msh_grid_f32<P>(grid, A.thr[k], n, th, kk, A.dist_type[k] == DIST_GAMMA, Mk, msh);
+                    msh_grid_f32<P>(grid, A.thr[k], th, kk, A.dist_type[k] == DIST_GAMMA, msh);
                 else
-                    msh_grid<P>(grid, A.thr[k], n, th, kk, A.dist_type[k] == DIST_GAMMA, Mk, msh);
+                    msh_grid<P>(grid, A.thr[k], th, kk, A.dist_type[k] == DIST_GAMMA, msh);
             }
         }
     } else if (MODE == MODE_MOVING) {
         if (k < N - 1) {
             const bool is_gamma = A.dist_type[k] == DIST_GAMMA;
             const double xt = moving_threshold<N, P>(A, k, is_gamma, th, kk);
-            thresholded = !(xt == INFINITY);
-            if (thresholded && n > 0.0) {
+            f.thresholded = !(xt == INFINITY);
+            if (f.thresholded && n_pos) {
                 if (FAST)
-                    msh_grid_f32<P>(MovingGrid(xt, A.nbpl), xt, n, th, kk, is_gamma, Mk, msh);
+                    msh_grid_f32<P>(MovingGrid(xt, A.nbpl), xt, th, kk, is_gamma, msh);
                 else
-                    msh_grid<P>(MovingGrid(xt, A.nbpl), xt, n, th, kk, is_gamma, Mk, msh);
+                    msh_grid<P>(MovingGrid(xt, A.nbpl), xt, th, kk, is_gamma, msh);
             }
         }
     }
+    return f;
+}
+
+template <int N, int P>
+__device__ __forceinline__ void promoted_finish(const KArgs<N, P> &A, int k, double n, double kk, const double (&Mk)[P + 2],
+                                                PromotedFlags f, double (&msh)[(P + 2) * (P + 3) / 2], double &T0,
+                                                double &T1, double &T2) {
+    constexpr int M = P + 2;
+    constexpr int T = M * (M + 1) / 2;
+    T0 = T1 = T2 = 0.0;
+    const double pref = msh_pref(A.dist_type[k] == DIST_GAMMA, n, kk);
+#pragma unroll
+    for (int p1 = 0; p1 < M; ++p1)
+#pragma unroll
+        for (int p2 = p1; p2 < M; ++p2)
+            msh[tri<M>(p1, p2)] = f.mono ? (f.mono_below ? Mk[p1] * Mk[p2] : 0.0) : (pref * msh[tri<M>(p1, p2)]) * Mk[p2];
     // without a threshold D is non-zero only where M_p M_q < eps: impossible when every moment >= 2^-26
     double mn = Mk[0];
 #pragma unroll
     for (int q = 1; q < M; ++q)
         if (q < A.n_mom_max) mn = fmin(mn, Mk[q]);
-    const bool need = (n > 0.0) && (thresholded || mn < kSqrtEps);
+    const bool need = (n > 0.0) && (f.thresholded || mn < kSqrtEps);
     if (need) {
         double F[T], D[T];
-        finite_2d_and_promoted<P>(Mk, thresholded, msh, F, D);
+        finite_2d_and_promoted<P>(Mk, f.thresholded, msh, F, D);
         contract_promoted<P>(A.c[k][k], D, T0, T1, T2);
     }
+}
+
+template <int N, int P, int MODE, bool FAST = false>
+__device__ __forceinline__ void promoted_mode(const KArgs<N, P> &A, const double *__restrict__ nodes, int k, double n,
+                                              double th, double kk, const double (&Mk)[P + 2], double &T0, double &T1,
+                                              double &T2) {
+    double msh[(P + 2) * (P + 3) / 2];
+    const PromotedFlags f = promoted_pass<N, P, MODE, FAST>(A, nodes, k, n > 0.0, th, kk, msh);
+    promoted_finish<N, P>(A, k, n, kk, Mk, f, msh, T0, T1, T2);
 }
 
 // ---- pair terms: Q - R for j < k, -R for j > k, S_1(full products) - R for j == k, with the
@@ -1132,19 +1160,26 @@ __global__ void __launch_bounds__(kBlock)
 #pragma unroll
                             for (int p2 = p1; p2 < M; ++p2) msh[tri<M>(p1, p2)] = below ? Mk[p1] * Mk[p2] : 0.0;
                     } else if (nn[k] > 0.0)
-                        msh_grid<P>(FixedGrid{nodes + (size_t)A.node_off[k] * kNodeStride, A.n_bins[k]}, A.thr[k], nn[k],
-                                    th[k], kk[k], is_gamma, Mk, msh);
+                        msh_grid<P>(FixedGrid{nodes + (size_t)A.node_off[k] * kNodeStride, A.n_bins[k]}, A.thr[k], th[k],
+                                    kk[k], is_gamma, msh);
                 }
             } else if (MODE == MODE_MOVING) {
                 if (k < N - 1) {
                     xt = moving_threshold<N, P>(A, k, is_gamma, th[k], kk[k]);
                     thresholded = !(xt == INFINITY);
                     if (thresholded && nn[k] > 0.0)
-                        msh_grid<P>(MovingGrid(xt, A.nbpl), xt, nn[k], th[k], kk[k], is_gamma, Mk, msh);
+                        msh_grid<P>(MovingGrid(xt, A.nbpl), xt, th[k], kk[k], is_gamma, msh);
                 }
             }
             if (thr_out) thr_out[(size_t)k * ld + i] = xt;
             if (F) {
+                if (!(MODE == MODE_FIXED && A.dist_type[k] == DIST_MONO)) {  // msh_grid leaves msh_pref and M_p2 to its caller
+                    const double pref = msh_pref(is_gamma, nn[k], kk[k]);
+#pragma unroll
+                    for (int p1 = 0; p1 < M; ++p1)
+#pragma unroll
+                        for (int p2 = p1; p2 < M; ++p2) msh[tri<M>(p1, p2)] = (pref * msh[tri<M>(p1, p2)]) * Mk[p2];
+                }
                 double Fm[T], D[T];
                 finite_2d_and_promoted<P>(Mk, thresholded, msh, Fm, D);
 #pragma unroll
