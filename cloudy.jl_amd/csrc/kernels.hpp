@@ -25,7 +25,8 @@ namespace cloudy {
 enum { IN_MOMENTS = 0, IN_PARAMS = 1 };
 enum { MODE_ALLINF = 0, MODE_FIXED = 1, MODE_MOVING = 2 };
 enum { DIST_EXP = 0, DIST_GAMMA = 1, DIST_MONO = 2, DIST_LOGNORMAL = 3 };
-constexpr int kEarlyTerms = 16;  // Taylor terms of the early-node expansion (see msh_grid for the radius)
+constexpr int kEarlyTerms = 16;   // Taylor terms of the early-node expansion of the single-precision pass (msh_grid_f32)
+constexpr int kEarlySeries = 24;  // terms of the early-node series of the fp64 pass (see msh_grid for the radius)
 constexpr int kNodeStride = 5;  // x, ln x, x_t - x, ln(x_t - x), w * dx  (the early nodes need no table: msh_grid)
 constexpr int kBlock = 256;
 constexpr int kInvTerms = 16;  // coefficients of the start-value polynomial of the percentile threshold (moving_threshold)
@@ -277,7 +278,6 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double th,
                                          double (&msh)[(P + 2) * (P + 3) / 2]) {  // WITHOUT msh_pref(n, k) M_p2: the caller applies them
     constexpr int M = P + 2;
     constexpr int T = M * (M + 1) / 2;
-    constexpr int NS = M + kEarlyTerms;
 #ifdef CLOUDY_ABLATE_NODES  // timing experiment only: no Simpson nodes at all
     const int nb = 0;
 #else
@@ -292,110 +292,104 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double th,
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = 0.0;
 
-    // ---- early nodes: power sums only, in u = x / x_t:
-    //   U_q = sum_j (w_j dx) t_j^k e^{-t_j} u_j^q;   P(a, z0 - z0 u) = P(a, z0) - g_a z0 sum_n b_n u^(n+1)/(n+1),
-    //   b_n = c_n z0^n:  b_{n+1} = ((z0 - a + 1 + n) b_n - z0 b_{n-1}) / (n + 1)
-    const double x_early = fmin(th, 0.2 * xt / fmax(a_top - 1.0, 2.0));
+    // ---- early nodes: no loop over them at all.  With u = x / x_t (t = z0 u) the integrand of one order a = k + p2 is
+    //   u^(k+p1) G_a(u),   G_a(u) = e^{-z0 u} P(a, z0 (1 - u)) = sum_s d_s u^s,
+    // and G_a has a two-term recurrence, because the exponentials cancel in its derivative:
+    //   G_a' = -z0 G_a - z0 C_a (1 - u)^(a-1),  C_a = z0^(a-1) e^-z0 / Gamma(a)
+    //   =>  d_0 = P(a, z0),  d_{s+1} = -z0 (d_s + C_a beta_s) / (s + 1),  (1 - u)^(a-1) = sum_s beta_s u^s,
+    // the orders are linked by P(a-1, z) = P(a, z) + z^(a-1) e^-z / Gamma(a):  G_{a-1} = G_a + C_a (1 - u)^(a-1),
+    // and the early nodes are a geometric progression u_j = u_0 rho^j, rho = e^dx (ParticleDistributions.jl:566,
+    // 604-610) with Simpson weights 1 but for the first four (:698-710), so their power sums are closed forms:
+    //   V_s = sum_{j<J} w_j dx u_j^(k+s) = u_J^(k+s) W_s,   W_s = dx [ (1 - b_s)/(r_s - 1) - b_s c(r_s) ],
+    //   r_s = rho^(k+s),  b_s = r_s^-J,  c(r) = 31/48 - 11/48 r + 5/48 r^2 - 1/48 r^3   (u_J: the first node NOT early).
+    // Hence  sum_{j<J} (w_j dx) x_j^p1 t_j^k e^{-t_j} P(a, z0 - t_j) = t_J^k x_J^p1 sum_s (d_s u_J^s) W_{p1+s}:
+    // kEarlySeries terms of ~48 operations for all orders and all p1 together, whatever J (45-110 nodes), one
+    // incomplete gamma (at z0) for the whole group, every lane the same work.  Radius t <= 2 and u (a_top - 1) <= 1
+    // (u <= 1/3): with 24 terms the truncation is below the rounding floor of the sum (~2e-14 relative, set by the
+    // roundings of k ln t_J and a ln z0; alternating e^-t terms cost e^(2t) eps), checked against mpmath over
+    // k in [1e-9, 10], z0 in [1e-3, 300].  Everything is kept relative to u_J^k (t_J ~ 1): nothing over- or underflows
+    // for clamped closures.  (Round 1 expanded P alone about z0 and summed the nodes one by one -- one exp and 21 FMAs per
+    // node; the first closed form of this round expanded e^-t and P separately: 16 x 19 + 5 x 16 x 8 operations and a
+    // fifth of the radius.)
+    const double x_early = fmin(2.0 * th, xt / fmax(a_top - 1.0, 3.0));
     int j = 0;
     double xr = grid.first_x();  // running abscissa (MovingGrid); a table (FixedGrid) ignores it
 #ifndef CLOUDY_NO_EARLY_NODES
     {
-        double U[NS];
-#pragma unroll
-        for (int q = 0; q < NS; ++q) U[q] = 0.0;
-        const double inv_xt = 1.0 / xt;
-        // The early nodes are a geometric progression, u_j = u_0 rho^j with rho = e^dx (ParticleDistributions.jl:566,
-        // 604-610), their Simpson weights are 1 but for the first four (:698-710), and t_j = z0 u_j <= 1 there.  With
-        // e^-t expanded (19 terms: t^19/19! < 1e-17),
-        //   U_q = sum_j (w_j dx) (z0 u_j)^k e^{-z0 u_j} u_j^q = z0^k sum_m (-z0)^m/m! V_{q+m},   V_s = sum_{j<J} w_j dx u_j^(k+s),
-        // and V_s is a geometric series with a four-term end correction:
-        //   V_s = dx u_J^(k+s) [ (1 - b_s)/(r_s - 1) - b_s c(r_s) ],   r_s = rho^(k+s),  b_s = (u_0/u_J)^(k+s) = r_s^-J,
-        //   c(r) = 31/48 - 11/48 r + 5/48 r^2 - 1/48 r^3          (u_J = u_0 rho^J: the first node that is NOT early).
-        // So the J early nodes (45-110 of them) cost NS + 19 closed-form terms instead of J exponentials and J x NS
-        // multiply-adds, every lane does the same work whatever its J, and no table of node powers is read.  Everything
-        // is kept relative to u_J^k (t_J = z0 u_J ~ 1), so nothing over- or underflows for clamped closures:
-        //   U_q = t_J^k u_J^q sum_m gamma_m W_{q+m},  gamma_m = (-t_J)^m/m!,  W_s = dx [ (1 - b_s)/(r_s - 1) - b_s c(r_s) ].
-        // Same sums as the node loop to rounding: the one systematic difference is that k ln u_J is rounded once for
-        // all nodes instead of once per node (~1e-14 relative instead of ~1e-15; measured in tests).
-        {
-            constexpr int MX = 18;                         // Taylor order of e^-t on [0, ~1]
-            const double lx0 = grid.first_lx(), dxl = grid.log_step();
-            int J = 0;
-            if (x_early >= xr) {  // xr = the first node
-                const double jf = floor((log_pos(x_early) - lx0) / dxl) + 1.0;  // nodes with x_j <= x_early
-                J = jf < double(nb) ? (int)jf : nb;
-            }
-            // fewer than four early nodes (the end correction assumes the first four): none; and never the last
-            // three nodes, whose weights differ (x_early <= x_t / 10 keeps 15 nodes of distance)
-            if (J < 4 || J > nb - 4) J = 0;
-            if (J > 0) {
-                const double Jd = double(J);
-                const double xJ = exp_fin(fma(Jd, dxl, lx0));      // node J itself, as the reference computes it
-                const double uJ = xJ * inv_xt, tJ = xJ * inv_th;
-                const double rho = exp_fin(dxl), rhoJinv = exp_fin(-Jd * dxl);
-                double r = exp_fin(k * dxl), b = exp_fin(-Jd * k * dxl);
-                double gam[MX + 1];
-                gam[0] = 1.0;
-#pragma unroll
-                for (int m = 1; m <= MX; ++m) gam[m] = gam[m - 1] * (-tJ) * (1.0 / double(m));
-#pragma unroll
-                for (int s = 0; s < NS + MX; ++s) {
-                    // s = 0: k dx can be tiny (clamped closures): the two differences through expm1
-                    const double omb = s == 0 ? -expm1(-Jd * k * dxl) : 1.0 - b;
-                    const double rm1 = s == 0 ? expm1(k * dxl) : r - 1.0;
-                    const double c = fma(r, fma(r, fma(r, -1.0 / 48.0, 5.0 / 48.0), -11.0 / 48.0), 31.0 / 48.0);
-                    const double W = dxl * fma(omb, recip_fast(rm1), -(b * c));
-#pragma unroll
-                    for (int q = 0; q < NS; ++q)
-                        if (s - q >= 0 && s - q <= MX) U[q] = fma(W, gam[s - q], U[q]);
-                    r *= rho;
-                    b *= rhoJinv;
-                }
-                double f = exp_fin(k * log_pos(tJ));  // t_J^k
-#pragma unroll
-                for (int q = 0; q < NS; ++q) {
-                    U[q] *= f;
-                    f *= uJ;
-                }
-                j = J;
-                xr = xJ;
-            }
+        const double lx0 = grid.first_lx(), dxl = grid.log_step();
+        int J = 0;
+        if (x_early >= xr) {  // xr = the first node
+            const double jf = floor((log_pos(x_early) - lx0) / dxl) + 1.0;  // nodes with x_j <= x_early
+            J = jf < double(nb) ? (int)jf : nb;
         }
-        if (j > 0) {
-            // P(a, z0) and g_a = dP/dz at z0 for the M orders a = k + p2 (downward from a_top)
+        // fewer than four early nodes (the end correction assumes the first four): none; and never the last three
+        // nodes, whose weights differ (u <= 1/3 keeps 7 nodes of distance on the reference's 15-per-decade grid)
+        if (J < 4 || J > nb - 4) J = 0;
+        if (J > 0) {
+            const double Jd = double(J);
+            const double xJ = exp_fin(fma(Jd, dxl, lx0));  // node J itself, as the reference computes it
+            const double uJ = xJ * (1.0 / xt), tJ = xJ * inv_th;
+            const double rho = exp_fin(dxl), rhoJinv = exp_fin(-Jd * dxl);
+            double r = exp_fin(k * dxl), b = exp_fin(-Jd * k * dxl);
+            // P(a_top, z0), and C_a B_s for the M - 1 orders a = a_top ... k + 1  (B_s = beta_s u_J^s of exponent a - 1)
             const double invz0 = 1.0 / z0;
-            double E = exp_fin(fma(a_top, log_pos(xt) - lnth, -z0) - lg_top);  // E(a_top, z0) = z0^a e^-z0 / Gamma(a+1)
-            double Pv = inc_gamma_p_from_E(a_top, z0, E, nullptr);
-            double a = a_top;
-            double xtp[M];  // x_t^p1
-            xtp[0] = 1.0;
+            const double Etop = exp_fin(fma(a_top, log_pos(xt) - lnth, -z0) - lg_top);  // z0^a e^-z0 / Gamma(a+1)
+            double e_top = inc_gamma_p_from_E(a_top, z0, Etop, nullptr);
+            double CB[M > 1 ? M - 1 : 1], al[M > 1 ? M - 1 : 1];
+            {
+                double a = a_top, g = Etop;
 #pragma unroll
-            for (int p1 = 1; p1 < M; ++p1) xtp[p1] = xtp[p1 - 1] * xt;
-#pragma unroll
-            for (int p2 = M - 1; p2 >= 0; --p2) {
-                // here: a = k + p2, Pv = P(a, z0), E = E(a, z0)
-                const double g = E * a * invz0;  // E(a-1, z0) = z0^(a-1) e^-z0 / Gamma(a)
-                double G[M];
-#pragma unroll
-                for (int p1 = 0; p1 < M; ++p1) G[p1] = 0.0;
-                double bm = 0.0, bc = 1.0;
-#pragma unroll
-                for (int nn2 = 0; nn2 < kEarlyTerms; ++nn2) {
-                    const double w = bc * (1.0 / double(nn2 + 1));
-#pragma unroll
-                    for (int p1 = 0; p1 <= p2; ++p1) G[p1] = fma(w, U[p1 + nn2 + 1], G[p1]);
-                    const double bn = ((z0 - a + 1.0 + double(nn2)) * bc - z0 * bm) * (1.0 / double(nn2 + 1));
-                    bm = bc;
-                    bc = bn;
+                for (int i = 0; i < M - 1; ++i) {
+                    g *= a * invz0;  // C_a = E(a-1, z0)
+                    CB[i] = g;
+                    al[i] = a - 1.0;
+                    a -= 1.0;
                 }
-                const double gz = g * z0;
-#pragma unroll
-                for (int p1 = 0; p1 <= p2; ++p1) acc[tri<M>(p1, p2)] = xtp[p1] * fma(Pv, U[p1], -(gz * G[p1]));
-                // step down one order
-                Pv += g;
-                E = g;
-                a -= 1.0;
             }
+            double win[M];  // W_s ... W_{s+M-1}
+            const auto next_W = [&](bool first) {
+                // s = 0: k dx can be tiny (clamped closures): the two differences through expm1
+                const double omb = first ? -expm1(-Jd * k * dxl) : 1.0 - b;
+                const double rm1 = first ? expm1(k * dxl) : r - 1.0;
+                const double c = fma(r, fma(r, fma(r, -1.0 / 48.0, 5.0 / 48.0), -11.0 / 48.0), 31.0 / 48.0);
+                const double W = dxl * fma(omb, recip_fast(rm1), -(b * c));
+                r *= rho;
+                b *= rhoJinv;
+                return W;
+            };
+#pragma unroll
+            for (int s = 0; s < M - 1; ++s) win[s] = next_W(s == 0);
+            // (unrolled for the small orders; rolled for M > 5, where the scheduler otherwise hoists the independent W
+            // chain over the whole body and spills hundreds of registers)
+            double nd = 0.0;  // n as a double
+#pragma unroll(M <= 5 ? kEarlySeries : 1)
+            for (int n = 0; n < kEarlySeries; ++n) {
+                win[M - 1] = next_W(false);  // this step adds (d_n u_J^n) W_{p1+n}
+                double e = e_top;
+#pragma unroll
+                for (int p2 = M - 1; p2 >= 0; --p2) {
+#pragma unroll
+                    for (int p1 = 0; p1 <= p2; ++p1) acc[tri<M>(p1, p2)] = fma(e, win[p1], acc[tri<M>(p1, p2)]);
+                    if (p2 > 0) e += CB[M - 1 - p2];
+                }
+                const double inv_n1 = M <= 5 ? 1.0 / double(n + 1) : recip_fast(nd + 1.0);
+                e_top = (e_top + CB[0]) * (-tJ * inv_n1);
+                const double f = uJ * inv_n1;
+#pragma unroll
+                for (int i = 0; i < M - 1; ++i) CB[i] *= (nd - al[i]) * f;
+#pragma unroll
+                for (int i = 0; i < M - 1; ++i) win[i] = win[i + 1];
+                nd += 1.0;
+            }
+            double f = exp_fin(k * log_pos(tJ));  // t_J^k x_J^p1
+#pragma unroll
+            for (int p1 = 0; p1 < M; ++p1) {
+#pragma unroll
+                for (int p2 = p1; p2 < M; ++p2) acc[tri<M>(p1, p2)] *= f;
+                f *= xJ;
+            }
+            j = J;
+            xr = xJ;
         }
     }
 #endif
