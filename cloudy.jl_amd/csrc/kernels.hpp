@@ -26,7 +26,15 @@ enum { IN_MOMENTS = 0, IN_PARAMS = 1 };
 enum { MODE_ALLINF = 0, MODE_FIXED = 1, MODE_MOVING = 2 };
 enum { DIST_EXP = 0, DIST_GAMMA = 1, DIST_MONO = 2, DIST_LOGNORMAL = 3 };
 constexpr int kEarlyTerms = 16;   // Taylor terms of the early-node expansion of the single-precision pass (msh_grid_f32)
-constexpr int kEarlySeries = 24;  // terms of the early-node series of the fp64 pass (see msh_grid for the radius)
+// terms and radius (t <= kEarlyTmax, u (a_top - 1) <= kEarlyUa) of the early-node series of the fp64 pass (see msh_grid);
+// the macros exist for timing / accuracy experiments through CLOUDY_HIP_JIT_DEFS
+#ifndef CLOUDY_EARLY_SERIES
+#define CLOUDY_EARLY_SERIES 30
+#define CLOUDY_EARLY_TMAX 3.0
+#define CLOUDY_EARLY_UA 1.5
+#endif
+constexpr int kEarlySeries = CLOUDY_EARLY_SERIES;
+constexpr double kEarlyTmax = CLOUDY_EARLY_TMAX, kEarlyUa = CLOUDY_EARLY_UA;
 constexpr int kNodeStride = 5;  // x, ln x, x_t - x, ln(x_t - x), w * dx  (the early nodes need no table: msh_grid)
 constexpr int kBlock = 256;
 constexpr int kInvTerms = 16;  // coefficients of the start-value polynomial of the percentile threshold (moving_threshold)
@@ -304,14 +312,15 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double th,
     //   r_s = rho^(k+s),  b_s = r_s^-J,  c(r) = 31/48 - 11/48 r + 5/48 r^2 - 1/48 r^3   (u_J: the first node NOT early).
     // Hence  sum_{j<J} (w_j dx) x_j^p1 t_j^k e^{-t_j} P(a, z0 - t_j) = t_J^k x_J^p1 sum_s (d_s u_J^s) W_{p1+s}:
     // kEarlySeries terms of ~48 operations for all orders and all p1 together, whatever J (45-110 nodes), one
-    // incomplete gamma (at z0) for the whole group, every lane the same work.  Radius t <= 2 and u (a_top - 1) <= 1
-    // (u <= 1/3): with 24 terms the truncation is below the rounding floor of the sum (~2e-14 relative, set by the
-    // roundings of k ln t_J and a ln z0; alternating e^-t terms cost e^(2t) eps), checked against mpmath over
-    // k in [1e-9, 10], z0 in [1e-3, 300].  Everything is kept relative to u_J^k (t_J ~ 1): nothing over- or underflows
+    // incomplete gamma (at z0) for the whole group, every lane the same work.  Radius t <= 3 and u (a_top - 1) <= 1.5
+    // (u <= 1/2): with 30 terms the truncation is below the rounding floor of the sum (~5e-14 relative to the early
+    // sum, set by the roundings of k ln t_J and a ln z0 and by the alternating e^-t terms, e^(2t) eps), checked against
+    // mpmath over k in [1e-9, 10], z0 in [1e-3, 300]; measured on the GPU: 24 terms at (2, 1) cfg3b 2.59 ms, 30 terms at
+    // (3, 1.5) 2.39 ms, 32 terms at (3.5, 1.5) 2.42 ms, same worst parity error (2.6e-14 of scale over 40 random plans).  Everything is kept relative to u_J^k (t_J ~ 1): nothing over- or underflows
     // for clamped closures.  (Round 1 expanded P alone about z0 and summed the nodes one by one -- one exp and 21 FMAs per
     // node; the first closed form of this round expanded e^-t and P separately: 16 x 19 + 5 x 16 x 8 operations and a
     // fifth of the radius.)
-    const double x_early = fmin(2.0 * th, xt / fmax(a_top - 1.0, 3.0));
+    const double x_early = fmin(kEarlyTmax * th, kEarlyUa * xt / fmax(a_top - 1.0, 3.0));
     int j = 0;
     double xr = grid.first_x();  // running abscissa (MovingGrid); a table (FixedGrid) ignores it
 #ifndef CLOUDY_NO_EARLY_NODES
@@ -323,7 +332,7 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double th,
             J = jf < double(nb) ? (int)jf : nb;
         }
         // fewer than four early nodes (the end correction assumes the first four): none; and never the last three
-        // nodes, whose weights differ (u <= 1/3 keeps 7 nodes of distance on the reference's 15-per-decade grid)
+        // nodes, whose weights differ (u <= 1/2 keeps 4.5 nodes of distance on the reference's 15-per-decade grid)
         if (J < 4 || J > nb - 4) J = 0;
         if (J > 0) {
             const double Jd = double(J);
