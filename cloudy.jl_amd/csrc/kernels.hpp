@@ -224,6 +224,8 @@ struct FixedGrid {
     __device__ __forceinline__ double first_lx() const { return nd[1]; }
     __device__ __forceinline__ double log_step() const { return nd[kNodeStride + 1] - nd[1]; }  // dx of the log-uniform grid
     __device__ __forceinline__ double next_x(double, int, int) const { return 0.0; }
+    __device__ __forceinline__ double last_x() const { return 0.0; }
+    __device__ __forceinline__ double prev_x(double, int, int) const { return 0.0; }
     __device__ __forceinline__ double node_x(int j, double) const { return nd[kNodeStride * j]; }
     __device__ __forceinline__ SimpsonNode node(int j, double, bool late) const { return node(j, late); }
     __device__ __forceinline__ SimpsonNode node(int j, bool /*late*/) const {
@@ -233,7 +235,7 @@ struct FixedGrid {
 };
 // MovingThreshold: the threshold, hence the grid, is per parcel (computed with the reference's expressions).
 struct MovingGrid {
-    double xt, x_min, dx, ratio;
+    double xt, x_min, dx, ratio, inv_ratio;
     int nb;
     __device__ __forceinline__ MovingGrid(double xt_, int nbpl) : xt(xt_) {
         const double x_lb = fmin(1e-5, 1e-5 * xt_);
@@ -241,6 +243,7 @@ struct MovingGrid {
         x_min = log_pos(x_lb);
         dx = (log_pos(xt_) - x_min) / double(nb);
         ratio = exp_fin(dx);
+        inv_ratio = exp_fin(-dx);
     }
     __device__ __forceinline__ int n_bins() const { return nb; }
     __device__ __forceinline__ double node_x(int j) const { return exp(x_min + double(j) * dx); }
@@ -254,6 +257,11 @@ struct MovingGrid {
     // on j would make every lane's exp() run (masked) in almost every iteration of the wave
     __device__ __forceinline__ double next_x(double x_run, int j_next, int phase) const {
         return (phase & 15) == 15 ? exp_fin(x_min + double(j_next) * dx) : x_run * ratio;
+    }
+    // (the late nodes are visited from the last one down)
+    __device__ __forceinline__ double last_x() const { return exp_fin(x_min + double(nb - 1) * dx); }
+    __device__ __forceinline__ double prev_x(double x_run, int j_prev, int phase) const {
+        return (phase & 15) == 15 ? exp_fin(x_min + double(j_prev) * dx) : x_run * inv_ratio;
     }
     __device__ __forceinline__ double node_x(int, double x_run) const { return x_run; }
     __device__ __forceinline__ SimpsonNode node(int j, double x_run, bool late) const {
@@ -406,10 +414,22 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double th,
 #ifdef CLOUDY_ABLATE_LATE  // timing experiment only: early nodes and their conversion, no late nodes
     j = nb;
 #endif
+    // From the LAST node down: in a regime-sorted wave every lane is then at the same node index in the same iteration
+    // (the lanes differ in where their early group ends, not in where the grid ends), so z = (x_t - x_j) / theta is as
+    // homogeneous across the wave as theta is -- and the node table of a FixedGrid is read at wave-uniform addresses.
+#ifdef CLOUDY_LATE_ASCENDING  // timing experiment only: the order of rounds 1 and 2a
 #pragma unroll 1
     for (int it = 0; j < nb; ++j, ++it) {
         const SimpsonNode nd = grid.node(j, xr, true);
         xr = grid.next_x(xr, j + 1, it);
+#else
+    const int j_first = j;
+    xr = grid.last_x();
+#pragma unroll 1
+    for (int it = 0, jj = nb - 1; jj >= j_first; --jj, ++it) {
+        const SimpsonNode nd = grid.node(jj, xr, true);
+        xr = grid.prev_x(xr, jj - 1, it);
+#endif
         const double t = nd.x * inv_th, zr = nd.xmx * inv_th;
         const bool zpos = zr > 0.0;  // P(a, z <= 0) = 0: such a node (never on the reference grid) contributes nothing
         const double z = zpos ? zr : 1.0;
@@ -518,10 +538,22 @@ __device__ __forceinline__ void msh_grid_f32(const Grid &grid, double xt, double
             }
         }
     }
+    // From the LAST node down: in a regime-sorted wave every lane is then at the same node index in the same iteration
+    // (the lanes differ in where their early group ends, not in where the grid ends), so z = (x_t - x_j) / theta is as
+    // homogeneous across the wave as theta is -- and the node table of a FixedGrid is read at wave-uniform addresses.
+#ifdef CLOUDY_LATE_ASCENDING  // timing experiment only: the order of rounds 1 and 2a
 #pragma unroll 1
     for (int it = 0; j < nb; ++j, ++it) {
         const SimpsonNode nd = grid.node(j, xr, true);
         xr = grid.next_x(xr, j + 1, it);
+#else
+    const int j_first = j;
+    xr = grid.last_x();
+#pragma unroll 1
+    for (int it = 0, jj = nb - 1; jj >= j_first; --jj, ++it) {
+        const SimpsonNode nd = grid.node(jj, xr, true);
+        xr = grid.prev_x(xr, jj - 1, it);
+#endif
         const double td = nd.x * inv_th, zd = nd.xmx * inv_th;
         if (!(zd > 0.0)) continue;
         const float z = (float)zd, xf = (float)nd.x;
