@@ -897,6 +897,91 @@ __device__ __forceinline__ void coal_ints_parcel(const KArgs<N, P> &A, const dou
     pair_terms<N, P, SPEC>(A, Mm, acc);
 }
 
+// get_coal_ints for the parcel of every lane of a workgroup of BS threads, computed cooperatively: phases 1 and 2 of
+// coal_rhs_sorted_body.inc for parcels that are already in registers (the fused integrators call this once per RHS
+// evaluation, so their lanes are re-ranked on the CURRENT state of every stage, per thresholded mode; round 1 ranked them
+// once, on the initial state and the first thresholded mode only: 64 % active lanes in the rainshaft integrator).
+// Every lane of the workgroup must call it (barriers); `valid` = the lane holds a parcel.
+template <int N, int P, int MODE, bool SPEC, int BS>
+__device__ __forceinline__ void coal_ints_ranked(const KArgs<N, P> &A, const double *__restrict__ nodes, bool valid,
+                                                 const double (&nn)[N], const double (&th)[N], const double (&kk)[N],
+                                                 double (&acc)[N][3]) {
+    constexpr int M_ = P + 2;
+    __shared__ double sh_par[3 * N][BS];
+    __shared__ double sh_T[(N > 1 ? N - 1 : 1) * 3][BS];
+    __shared__ unsigned int sh_cnt[BS];
+    __shared__ unsigned short sh_perm[BS];
+    {
+        const int t0 = threadIdx.x;
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+            sh_par[3 * m + 0][t0] = valid ? nn[m] : 0.0;
+            sh_par[3 * m + 1][t0] = valid ? th[m] : 1.0;
+            sh_par[3 * m + 2][t0] = valid ? kk[m] : 1.0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < N - 1; ++k) {
+        if (!mode_has_pass<N, P, MODE>(A, k)) continue;  // wave-uniform
+        // (as in coal_rhs_sorted_body.inc: nothing but the pass's operands stays in registers across it)
+        int tk = threadIdx.x;
+        asm volatile("" : "+v"(tk));
+        const double th_own = sh_par[3 * k + 1][tk], kk_own = sh_par[3 * k + 2][tk], nn_own = sh_par[3 * k + 0][tk];
+        const float r = (MODE == MODE_FIXED) ? (float)(A.thr[k] / th_own) : (float)kk_own;
+        regime_rank<BS>(nn_own > 0.0 && r == r, regime_bucket<BS>(r), sh_cnt, sh_perm);
+        double msh[M_ * (M_ + 1) / 2];
+        PromotedFlags pf;
+        {
+            const int src = sh_perm[tk];
+            pf = promoted_pass<N, P, MODE, false>(A, nodes, k, sh_par[3 * k + 0][src] > 0.0, sh_par[3 * k + 1][src],
+                                                  sh_par[3 * k + 2][src], msh);
+        }
+        int tf = threadIdx.x;
+        asm volatile("" : "+v"(tf));
+        const int src = sh_perm[tf];
+        const double n_s = sh_par[3 * k + 0][src], th_s = sh_par[3 * k + 1][src], kk_s = sh_par[3 * k + 2][src];
+        double Mk[M_], T0, T1, T2;
+        moment_row<M_>(A.dist_type[k], n_s, th_s, kk_s, A.n_mom_max, Mk);
+        promoted_finish<N, P>(A, k, n_s, kk_s, Mk, pf, msh, T0, T1, T2);
+        sh_T[3 * k + 0][src] = T0;
+        sh_T[3 * k + 1][src] = T1;
+        sh_T[3 * k + 2][src] = T2;
+        __syncthreads();
+    }
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    double nn2[N], th2[N], kk2[N], Mm[N][M_];
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        nn2[m] = sh_par[3 * m + 0][t];
+        th2[m] = sh_par[3 * m + 1][t];
+        kk2[m] = sh_par[3 * m + 2][t];
+        moment_row<M_>(A.dist_type[m], nn2[m], th2[m], kk2[m], A.n_mom_max, Mm[m]);
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double T0, T1, T2;
+        if (k < N - 1 && mode_has_pass<N, P, MODE>(A, k)) {
+            T0 = sh_T[3 * k + 0][t];
+            T1 = sh_T[3 * k + 1][t];
+            T2 = sh_T[3 * k + 2][t];
+        } else {  // no threshold on this mode: only the (rare) M_p M_q < eps rule can promote anything
+            promoted_mode<N, P, MODE, false>(A, nodes, k, nn2[k], th2[k], kk2[k], Mm[k], T0, T1, T2);
+        }
+        acc[k][0] -= T0;
+        acc[k][1] -= T1;
+        acc[k][2] -= T2;
+        if (k + 1 < N) {
+            acc[k + 1][0] += T0;
+            acc[k + 1][1] += T1;
+            acc[k + 1][2] += T2;
+        }
+    }
+    pair_terms<N, P, SPEC>(A, Mm, acc);
+}
+
 // load one parcel (moments -> normalise -> invert, or parameters as given)
 template <int N, int P, typename TIO = double>
 __device__ __forceinline__ bool load_parcel(const KArgs<N, P> &A, size_t i, size_t ld, const TIO *__restrict__ in,
@@ -1020,8 +1105,9 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(CLOUDY_
 // 3 RHS evaluations per step, each a full pass over the state in OrdinaryDiffEq).  Here a lane keeps its parcel's
 // moments in registers across all stages and steps: HBM traffic is one read and one write of the state per CALL
 // (n_steps steps), and there are no per-stage launches.
-template <int N, int P, int MODE, bool SPEC = false>
-__device__ __forceinline__ void rhs_physical(const KArgs<N, P> &A, const double *__restrict__ nodes,
+// (thresholded plans: every lane of the workgroup calls this, `valid` = the lane holds a parcel; see coal_ints_ranked)
+template <int N, int P, int MODE, bool SPEC = false, int BS = kBlock>
+__device__ __forceinline__ void rhs_physical(const KArgs<N, P> &A, const double *__restrict__ nodes, bool valid,
                                              const double (&u)[N][3], double (&f)[N][3]) {
     double nn[N], th[N], kk[N], acc[N][3];
 #pragma unroll
@@ -1031,7 +1117,10 @@ __device__ __forceinline__ void rhs_physical(const KArgs<N, P> &A, const double 
         const double m2 = div_by_const(u[m][2], A.norm[3 * m + 2], A.inv_norm[3 * m + 2]);
         invert_closure(A.dist_type[m], m0, m1, m2, A.kmin, A.kmax, nn[m], th[m], kk[m]);
     }
-    coal_ints_parcel<N, P, MODE, false, SPEC>(A, nodes, nn, th, kk, acc);
+    if (MODE == MODE_ALLINF)
+        coal_ints_parcel<N, P, MODE, false, SPEC>(A, nodes, nn, th, kk, acc);
+    else
+        coal_ints_ranked<N, P, MODE, SPEC, BS>(A, nodes, valid, nn, th, kk, acc);
 #pragma unroll
     for (int m = 0; m < N; ++m) {
         f[m][0] = acc[m][0] * A.out_scale[3 * m + 0];
@@ -1048,47 +1137,18 @@ __device__ __forceinline__ void ssprk33_body(const KArgs<N, P> *__restrict__ Ag,
     // loops and then spills ~170 SGPRs into VGPR lanes (348 v_readlane per pass measured); re-deriving the pointer
     // keeps those s_loads inside the stage, where they hit the scalar cache.
     const KArgs<N, P> &A = *Ag;
-    size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
-    if (MODE != MODE_ALLINF) {
-        // regime sort of the workgroup's parcels on the initial state (see coal_rhs_sorted_kernel)
-        __shared__ unsigned int sh_cnt[BS];
-        __shared__ unsigned short sh_perm[BS];
-        const int t = threadIdx.x;
-        bool valid = false;
-        float rkey = 0.0f;
-        if (i < n) {
-            double nn[N], th[N], kk[N];
-            load_parcel<N, P, TIO>(A, i, ld, u_in, nn, th, kk);
-            int f = 0;
-            if (MODE == MODE_FIXED) {
-#pragma unroll
-                for (int m = N - 2; m >= 0; --m)
-                    if (A.finite[m]) f = m;
-            }
-            double nf = nn[0], thf = th[0], kf = kk[0], xtf = A.thr[0];
-#pragma unroll
-            for (int m = 1; m < N; ++m)
-                if (m == f) {
-                    nf = nn[m];
-                    thf = th[m];
-                    kf = kk[m];
-                    xtf = A.thr[m];
-                }
-            const float r = (MODE == MODE_FIXED) ? (float)(xtf / thf) : (float)kf;  // z0 (see coal_rhs_sorted_body.inc) or k
-            valid = nf > 0.0 && r == r;
-            rkey = r;
-        }
-        regime_rank<BS>(valid, regime_bucket<BS>(rkey), sh_cnt, sh_perm);
-        i = (size_t)blockIdx.x * BS + sh_perm[t];
-    }
-    if (i >= n) return;
+    const size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
+    // Thresholded plans: the workgroup re-ranks its parcels in every RHS evaluation (coal_ints_ranked), so lanes without
+    // a parcel stay for the barriers; the lane -> parcel map is the natural one (coalesced loads and stores).
+    const bool valid = i < n;
+    if (MODE == MODE_ALLINF && !valid) return;
     double u[N][3], up[N][3], f[N][3];
 #pragma unroll
     for (int m = 0; m < N; ++m) {
         const int off = A.off[m];
-        u[m][0] = (double)u_in[(size_t)(off + 0) * ld + i];
-        u[m][1] = (double)u_in[(size_t)(off + 1) * ld + i];
-        u[m][2] = (A.np[m] == 3) ? (double)u_in[(size_t)(off + 2) * ld + i] : 0.0;
+        u[m][0] = valid ? (double)u_in[(size_t)(off + 0) * ld + i] : 0.0;
+        u[m][1] = valid ? (double)u_in[(size_t)(off + 1) * ld + i] : 0.0;
+        u[m][2] = (valid && A.np[m] == 3) ? (double)u_in[(size_t)(off + 2) * ld + i] : 0.0;
     }
 #pragma unroll 1
     for (int step = 0; step < n_steps; ++step) {
@@ -1101,7 +1161,7 @@ __device__ __forceinline__ void ssprk33_body(const KArgs<N, P> *__restrict__ Ag,
             size_t opaque_zero = 0;  // launder an OFFSET, not the pointer: the pointer keeps its global address space
             if (!SPEC) asm volatile("" : "+s"(opaque_zero));  // (compile-time plan constants need no loads at all)
             const KArgs<N, P> *Ap = Ag + opaque_zero;
-            rhs_physical<N, P, MODE, SPEC>(*Ap, nodes, u, f);
+            rhs_physical<N, P, MODE, SPEC, BS>(*Ap, nodes, valid, u, f);
             // OrdinaryDiffEq SSPRK33: u = uprev + dt k;  u = (3 uprev + u + dt k)/4;  u = (uprev + 2u + 2dt k)/3
             // (wave-uniform branch on the stage OUTSIDE the element loops: selects per element would triple the work)
             if (stage == 0) {
@@ -1124,6 +1184,7 @@ __device__ __forceinline__ void ssprk33_body(const KArgs<N, P> *__restrict__ Ag,
             }
         }
     }
+    if (!valid) return;
 #pragma unroll
     for (int m = 0; m < N; ++m) {
         const int off = A.off[m];
@@ -1308,49 +1369,11 @@ __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__rest
                                                        size_t ld, const TIO *u_in, TIO *u_out, double dt, double dz,
                                                        int n_steps) {
     __shared__ double sh_flux[N * 3][kBlock];
-    constexpr bool kStash = (MODE != MODE_ALLINF) && (N <= 2);  // larger N: the LDS footprint would cost more occupancy than it buys
-    __shared__ double sh_keep[kStash ? 3 * N * 3 : 1][kBlock];
     const KArgs<N, P> &A = *Ag;
-    const int t = threadIdx.x;
-    const int cpb = kBlock / nz;  // whole columns per workgroup
-    int pos = t;                  // cell slot of the workgroup this lane integrates: column pos / nz, level pos % nz
-    if (MODE != MODE_ALLINF) {
-        // regime sort of the workgroup's cells on the initial state (see coal_rhs_sorted_kernel): lanes of a wave get
-        // cells of similar x_t / theta, so their Simpson passes take the same branches; the flux exchange below is
-        // indexed by cell slot, not by lane, so any permutation works.
-        __shared__ unsigned int sh_cnt[kBlock];
-        __shared__ unsigned short sh_perm[kBlock];
-        bool valid = false;
-        float rkey = 0.0f;
-        {
-            const int c0 = t / nz;
-            const size_t col0 = (size_t)blockIdx.x * cpb + c0;
-            if (c0 < cpb && col0 < n_columns) {
-                double nn[N], th[N], kk[N];
-                load_parcel<N, P, TIO>(A, col0 * (size_t)nz + (t - c0 * nz), ld, u_in, nn, th, kk);
-                int f = 0;
-#pragma unroll
-                for (int m = N - 2; m >= 0; --m)
-                    if (A.finite[m]) f = m;
-                double nf = nn[0], thf = th[0], xtf = A.thr[0];
-#pragma unroll
-                for (int m = 1; m < N; ++m)
-                    if (m == f) {
-                        nf = nn[m];
-                        thf = th[m];
-                        xtf = A.thr[m];
-                    }
-                const float r = (float)(xtf / thf);  // z0: see coal_rhs_sorted_body.inc
-                valid = nf > 0.0 && r == r;  // (empty cells and idle slots rank last)
-                rkey = r;
-            }
-        }
-        regime_rank(valid, regime_bucket(rkey), sh_cnt, sh_perm);
-        // The per-stage barrier makes a workgroup as slow as its most expensive wave.  Odd workgroups hand the sorted
-        // cells to their waves in reverse order, so that a SIMD holding waves of two workgroups does not get the two
-        // expensive ends.
-        pos = sh_perm[(blockIdx.x & 1) ? (kBlock - 1 - t) : t];
-    }
+    const int cpb = kBlock / nz;   // whole columns per workgroup
+    const int pos = threadIdx.x;   // cell slot of the workgroup this lane integrates: column pos / nz, level pos % nz
+    // (With a finite threshold the Simpson passes of every stage run on cells re-ranked on that stage's state, per
+    // thresholded mode: coal_ints_ranked.  Round 1 permuted the lanes once, on the initial state.)
     const int cl = pos / nz, iz = pos - cl * nz;
     const size_t col = (size_t)blockIdx.x * cpb + cl;
     const bool active = (cl < cpb) && (col < n_columns);
@@ -1375,6 +1398,12 @@ __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__rest
             const SediArgs &S = *(Sg + opaque_zero);
             double f[N][3], nn[N], th[N], kk[N];
             bool all_small = true;
+#pragma unroll
+            for (int m = 0; m < N; ++m) {
+                nn[m] = 0.0;
+                th[m] = 1.0;
+                kk[m] = 1.0;
+            }
             if (active) {
                 double fl[N][3];
 #pragma unroll
@@ -1395,6 +1424,12 @@ __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__rest
                         f[m][q] = (q < As.np[m]) ? fl[m][q] * As.out_scale[3 * m + q] : 0.0;
                         sh_flux[3 * m + q][pos] = f[m][q];
                     }
+                if (stage == 0) {
+#pragma unroll
+                    for (int m = 0; m < N; ++m)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) up[m][q] = u[m][q];  // uprev (clamped)
+                }
             }
             CLOUDY_STAGE_BARRIER();
             if (active) {
@@ -1406,39 +1441,17 @@ __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__rest
                         const double f_up = top ? 0.0 : sh_flux[3 * m + q][pos + 1];
                         f[m][q] = -(f_up - f[m][q]) / dz;  // :83-85
                     }
-                // With a finite threshold the Simpson pass needs the registers: the stage input, the step input and the
-                // flux divergence wait in the lane's own LDS slots meanwhile (36 fewer VGPRs at N = 2).
-                if (kStash) {
-#pragma unroll
-                    for (int m = 0; m < N; ++m)
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) {
-                            sh_keep[0 * N * 3 + 3 * m + q][t] = u[m][q];
-                            if (stage == 0) sh_keep[1 * N * 3 + 3 * m + q][t] = u[m][q];  // uprev (clamped)
-                            sh_keep[2 * N * 3 + 3 * m + q][t] = f[m][q];
-                        }
-                }
-                size_t opaque_zero2 = 0;
-                if (!SPEC) asm volatile("" : "+s"(opaque_zero2));
-                const KArgs<N, P> &Ac = *(Ag + opaque_zero2);
-                double acc[N][3];
-                coal_ints_parcel<N, P, MODE, false, SPEC>(Ac, nodes, nn, th, kk, acc);
-                if (kStash) {
-                    asm volatile("" ::: "memory");  // reload, do not forward the stored registers
-#pragma unroll
-                    for (int m = 0; m < N; ++m)
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) {
-                            u[m][q] = sh_keep[0 * N * 3 + 3 * m + q][t];
-                            up[m][q] = sh_keep[1 * N * 3 + 3 * m + q][t];
-                            f[m][q] = sh_keep[2 * N * 3 + 3 * m + q][t];
-                        }
-                } else if (stage == 0) {
-#pragma unroll
-                    for (int m = 0; m < N; ++m)
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) up[m][q] = u[m][q];
-                }
+            }
+            size_t opaque_zero2 = 0;
+            if (!SPEC) asm volatile("" : "+s"(opaque_zero2));
+            const KArgs<N, P> &Ac = *(Ag + opaque_zero2);
+            double acc[N][3];
+            if (MODE == MODE_ALLINF) {
+                if (active) coal_ints_parcel<N, P, MODE, false, SPEC>(Ac, nodes, nn, th, kk, acc);
+            } else {  // every lane of the workgroup: barriers inside
+                coal_ints_ranked<N, P, MODE, SPEC, kBlock>(Ac, nodes, active, nn, th, kk, acc);
+            }
+            if (active) {
 #pragma unroll
                 for (int m = 0; m < N; ++m)
 #pragma unroll

@@ -40,8 +40,9 @@ def main():
             keep = None
         else:
             spec = bench.workload_spec(name)
+            # (one sedimentation velocity term, so that the fused column integrator is compiled as well)
             d, keep = pkg.Plan.make_desc([1] * spec["n_modes"], bench.kernel_matrix(spec), spec["thresholds"], bench.NORMS,
-                                         1 if spec.get("moving") else 0)
+                                         1 if spec.get("moving") else 0, vel=((50.0, 1.0 / 6),))
         if L.cloudy_jit_selfcheck(C.byref(d), b"gfx950") != 0:
             raise SystemExit(f"{name}: " + L.cloudy_last_error().decode())
         for co in sorted(set(glob.glob(os.path.join(dump, "*.co"))) - before):
