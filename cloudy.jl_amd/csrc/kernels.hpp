@@ -377,7 +377,7 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double th,
 #pragma unroll
             for (int s = 0; s < M - 1; ++s) win[s] = next_W(s == 0);
             // (unrolled for the small orders; rolled for M > 5, where the scheduler otherwise hoists the independent W
-            // chain over the whole body and spills hundreds of registers)
+            // chain over the whole body and spills hundreds of registers -- 480 fully unrolled, 76 / 122 unrolled by 2 / 3)
             double nd = 0.0;  // n as a double
 #pragma unroll(M <= 5 ? kEarlySeries : 1)
             for (int n = 0; n < kEarlySeries; ++n) {
