@@ -25,7 +25,6 @@ namespace cloudy {
 enum { IN_MOMENTS = 0, IN_PARAMS = 1 };
 enum { MODE_ALLINF = 0, MODE_FIXED = 1, MODE_MOVING = 2 };
 enum { DIST_EXP = 0, DIST_GAMMA = 1, DIST_MONO = 2, DIST_LOGNORMAL = 3 };
-constexpr int kEarlyTerms = 16;   // Taylor terms of the early-node expansion of the single-precision pass (msh_grid_f32)
 // terms and radius (t <= kEarlyTmax, u (a_top - 1) <= kEarlyUa) of the early-node series of the fp64 pass (see msh_grid);
 // the macros exist for timing / accuracy experiments through CLOUDY_HIP_JIT_DEFS
 #ifndef CLOUDY_EARLY_SERIES
@@ -275,62 +274,35 @@ struct MovingGrid {
     }
 };
 
-// moment_source_helper for all (p1 <= p2) of one mode in ONE pass over its Simpson grid:
-//   msh[p1][p2] = n M_p2 / Gamma(k) * sum_j (w_j dx) x_j^p1 t_j^k e^{-t_j} P(k + p2, z_j),
-//   t_j = x_j / theta,  z_j = (x_t - x_j) / theta = z0 - t_j,  z0 = x_t / theta
-// which is ParticleDistributions.jl:589-612 (Gamma) / :567-587 (Exponential, k = 1) regrouped.
-//
-// Late nodes: one incomplete-gamma evaluation at the top order a_top = k + M - 1 per node, every lower order
-// by the stable downward recurrence P(a-1, z) = P(a, z) + z^(a-1) e^-z / Gamma(a).
-//
-// Early nodes (t_j <= 1 and t_j max(a_top-1, 2)/z0 <= 0.2; the log grid puts 45-55 of the 75 nodes there; with
-// 16 terms the truncation error is < 2e-15 relative over k in (0, 10], z0 in [1e-3, 200], checked against mpmath):
-// P(a, z0 - t) is expanded about z0,  P(a, z0 - t) = P(a, z0) - g_a sum_n c_n t^(n+1)/(n+1),  g_a = z0^(a-1) e^-z0 / Gamma(a),
-// c_{n+1} = ((z0 - a + 1 + n) c_n - c_{n-1}) / (z0 (n+1))  (Taylor coefficients of e^u (1 - u/z0)^(a-1)),
-// so the nodes only feed the power sums S_q = sum_j (w_j dx) t_j^(k+q) e^{-t_j} (one exp per node), and the
-// incomplete gamma is evaluated once, at z0, for the whole group.
+// ---- The early nodes of one Simpson grid: no loop over them at all.
+// With u = x / x_t (t = z0 u) the integrand of one order a = k + p2 is
+//   u^(k+p1) G_a(u),   G_a(u) = e^{-z0 u} P(a, z0 (1 - u)) = sum_s d_s u^s,
+// and G_a has a two-term recurrence, because the exponentials cancel in its derivative:
+//   G_a' = -z0 G_a - z0 C_a (1 - u)^(a-1),  C_a = z0^(a-1) e^-z0 / Gamma(a)
+//   =>  d_0 = P(a, z0),  d_{s+1} = -z0 (d_s + C_a beta_s) / (s + 1),  (1 - u)^(a-1) = sum_s beta_s u^s,
+// the orders are linked by P(a-1, z) = P(a, z) + z^(a-1) e^-z / Gamma(a):  G_{a-1} = G_a + C_a (1 - u)^(a-1),
+// and the early nodes are a geometric progression u_j = u_0 rho^j, rho = e^dx (ParticleDistributions.jl:566,
+// 604-610) with Simpson weights 1 but for the first four (:698-710), so their power sums are closed forms:
+//   V_s = sum_{j<J} w_j dx u_j^(k+s) = u_J^(k+s) W_s,   W_s = dx [ (1 - b_s)/(r_s - 1) - b_s c(r_s) ],
+//   r_s = rho^(k+s),  b_s = r_s^-J,  c(r) = 31/48 - 11/48 r + 5/48 r^2 - 1/48 r^3   (u_J: the first node NOT early).
+// Hence  sum_{j<J} (w_j dx) x_j^p1 t_j^k e^{-t_j} P(a, z0 - t_j) = t_J^k x_J^p1 sum_s (d_s u_J^s) W_{p1+s}:
+// kEarlySeries terms of ~48 operations for all orders and all p1 together, whatever J (45-110 nodes), one
+// incomplete gamma (at z0) for the whole group, every lane the same work.  Radius t <= 3 and u (a_top - 1) <= 1.5
+// (u <= 1/2): with 30 terms the truncation is below the rounding floor of the sum (~5e-14 relative to the early
+// sum, set by the roundings of k ln t_J and a ln z0 and by the alternating e^-t terms, e^(2t) eps), checked against
+// mpmath over k in [1e-9, 10], z0 in [1e-3, 300]; measured on the GPU: 24 terms at (2, 1) cfg3b 2.59 ms, 30 terms at
+// (3, 1.5) 2.39 ms, 32 terms at (3.5, 1.5) 2.42 ms, same worst parity error (2.6e-14 of scale over 40 random plans).
+// Everything is kept relative to u_J^k (t_J ~ 1): nothing over- or underflows for clamped closures.  (Round 1 expanded P alone about z0 and summed the nodes one by one -- one exp and 21 FMAs per
+// node; the first closed form of this round expanded e^-t and P separately: 16 x 19 + 5 x 16 x 8 operations and a
+// fifth of the radius.)
 template <int P, typename Grid>
-__device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double th, double k, bool is_gamma,
-                                         double (&msh)[(P + 2) * (P + 3) / 2]) {  // WITHOUT msh_pref(n, k) M_p2: the caller applies them
+__device__ __forceinline__ int early_series(const Grid &grid, int nb, double xt, double th, double k, double inv_th,
+                                            double lnth, double a_top, double lg_top, double z0,
+                                            double (&acc)[(P + 2) * (P + 3) / 2]) {  // returns J: nodes 0 .. J-1 are done
     constexpr int M = P + 2;
-    constexpr int T = M * (M + 1) / 2;
-#ifdef CLOUDY_ABLATE_NODES  // timing experiment only: no Simpson nodes at all
-    const int nb = 0;
-#else
-    const int nb = grid.n_bins();
-#endif
-    // (log_pos / lgamma_pos of device_math.hpp: branch-free, a third of the library routines' instructions)
-    const double inv_th = 1.0 / th, lnth = log_pos(th);
-    const double a_top = k + double(M - 1);
-    const double lg_top = lgamma_pos(a_top + 1.0);
-    const double z0 = xt * inv_th;
-    double acc[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) acc[t] = 0.0;
-
-    // ---- early nodes: no loop over them at all.  With u = x / x_t (t = z0 u) the integrand of one order a = k + p2 is
-    //   u^(k+p1) G_a(u),   G_a(u) = e^{-z0 u} P(a, z0 (1 - u)) = sum_s d_s u^s,
-    // and G_a has a two-term recurrence, because the exponentials cancel in its derivative:
-    //   G_a' = -z0 G_a - z0 C_a (1 - u)^(a-1),  C_a = z0^(a-1) e^-z0 / Gamma(a)
-    //   =>  d_0 = P(a, z0),  d_{s+1} = -z0 (d_s + C_a beta_s) / (s + 1),  (1 - u)^(a-1) = sum_s beta_s u^s,
-    // the orders are linked by P(a-1, z) = P(a, z) + z^(a-1) e^-z / Gamma(a):  G_{a-1} = G_a + C_a (1 - u)^(a-1),
-    // and the early nodes are a geometric progression u_j = u_0 rho^j, rho = e^dx (ParticleDistributions.jl:566,
-    // 604-610) with Simpson weights 1 but for the first four (:698-710), so their power sums are closed forms:
-    //   V_s = sum_{j<J} w_j dx u_j^(k+s) = u_J^(k+s) W_s,   W_s = dx [ (1 - b_s)/(r_s - 1) - b_s c(r_s) ],
-    //   r_s = rho^(k+s),  b_s = r_s^-J,  c(r) = 31/48 - 11/48 r + 5/48 r^2 - 1/48 r^3   (u_J: the first node NOT early).
-    // Hence  sum_{j<J} (w_j dx) x_j^p1 t_j^k e^{-t_j} P(a, z0 - t_j) = t_J^k x_J^p1 sum_s (d_s u_J^s) W_{p1+s}:
-    // kEarlySeries terms of ~48 operations for all orders and all p1 together, whatever J (45-110 nodes), one
-    // incomplete gamma (at z0) for the whole group, every lane the same work.  Radius t <= 3 and u (a_top - 1) <= 1.5
-    // (u <= 1/2): with 30 terms the truncation is below the rounding floor of the sum (~5e-14 relative to the early
-    // sum, set by the roundings of k ln t_J and a ln z0 and by the alternating e^-t terms, e^(2t) eps), checked against
-    // mpmath over k in [1e-9, 10], z0 in [1e-3, 300]; measured on the GPU: 24 terms at (2, 1) cfg3b 2.59 ms, 30 terms at
-    // (3, 1.5) 2.39 ms, 32 terms at (3.5, 1.5) 2.42 ms, same worst parity error (2.6e-14 of scale over 40 random plans).  Everything is kept relative to u_J^k (t_J ~ 1): nothing over- or underflows
-    // for clamped closures.  (Round 1 expanded P alone about z0 and summed the nodes one by one -- one exp and 21 FMAs per
-    // node; the first closed form of this round expanded e^-t and P separately: 16 x 19 + 5 x 16 x 8 operations and a
-    // fifth of the radius.)
     const double x_early = fmin(kEarlyTmax * th, kEarlyUa * xt / fmax(a_top - 1.0, 3.0));
     int j = 0;
-    double xr = grid.first_x();  // running abscissa (MovingGrid); a table (FixedGrid) ignores it
+    const double xr = grid.first_x();
 #ifndef CLOUDY_NO_EARLY_NODES
     {
         const double lx0 = grid.first_lx(), dxl = grid.log_step();
@@ -378,8 +350,9 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double th,
             for (int s = 0; s < M - 1; ++s) win[s] = next_W(s == 0);
             // (unrolled for the small orders; rolled for M > 5, where the scheduler otherwise hoists the independent W
             // chain over the whole body and spills hundreds of registers -- 480 fully unrolled, 76 / 122 unrolled by 2 / 3)
+            constexpr int kUnrollSeries = M <= 5 ? kEarlySeries : 1;
             double nd = 0.0;  // n as a double
-#pragma unroll(M <= 5 ? kEarlySeries : 1)
+#pragma unroll kUnrollSeries
             for (int n = 0; n < kEarlySeries; ++n) {
                 win[M - 1] = next_W(false);  // this step adds (d_n u_J^n) W_{p1+n}
                 double e = e_top;
@@ -406,10 +379,42 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double th,
                 f *= xJ;
             }
             j = J;
-            xr = xJ;
         }
     }
 #endif
+    return j;
+}
+
+// moment_source_helper for all (p1 <= p2) of one mode in ONE pass over its Simpson grid:
+//   msh[p1][p2] = n M_p2 / Gamma(k) * sum_j (w_j dx) x_j^p1 t_j^k e^{-t_j} P(k + p2, z_j),
+//   t_j = x_j / theta,  z_j = (x_t - x_j) / theta = z0 - t_j,  z0 = x_t / theta
+// which is ParticleDistributions.jl:589-612 (Gamma) / :567-587 (Exponential, k = 1) regrouped.
+//
+// Late nodes: one incomplete-gamma evaluation at the top order a_top = k + M - 1 per node, every lower order
+// by the stable downward recurrence P(a-1, z) = P(a, z) + z^(a-1) e^-z / Gamma(a).
+//
+// The early nodes go through early_series (closed form), the others get one incomplete-gamma evaluation each.
+template <int P, typename Grid>
+__device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double th, double k, bool is_gamma,
+                                         double (&msh)[(P + 2) * (P + 3) / 2]) {  // WITHOUT msh_pref(n, k) M_p2: the caller applies them
+    constexpr int M = P + 2;
+    constexpr int T = M * (M + 1) / 2;
+#ifdef CLOUDY_ABLATE_NODES  // timing experiment only: no Simpson nodes at all
+    const int nb = 0;
+#else
+    const int nb = grid.n_bins();
+#endif
+    // (log_pos / lgamma_pos of device_math.hpp: branch-free, a third of the library routines' instructions)
+    const double inv_th = 1.0 / th, lnth = log_pos(th);
+    const double a_top = k + double(M - 1);
+    const double lg_top = lgamma_pos(a_top + 1.0);
+    const double z0 = xt * inv_th;
+    double acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = 0.0;
+
+    // ---- early nodes: closed form (early_series)
+    int j = early_series<P>(grid, nb, xt, th, k, inv_th, lnth, a_top, lg_top, z0, acc);
     // ---- late nodes: one incomplete-gamma evaluation each
 #ifdef CLOUDY_ABLATE_LATE  // timing experiment only: early nodes and their conversion, no late nodes
     j = nb;
@@ -417,19 +422,12 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double th,
     // From the LAST node down: in a regime-sorted wave every lane is then at the same node index in the same iteration
     // (the lanes differ in where their early group ends, not in where the grid ends), so z = (x_t - x_j) / theta is as
     // homogeneous across the wave as theta is -- and the node table of a FixedGrid is read at wave-uniform addresses.
-#ifdef CLOUDY_LATE_ASCENDING  // timing experiment only: the order of rounds 1 and 2a
-#pragma unroll 1
-    for (int it = 0; j < nb; ++j, ++it) {
-        const SimpsonNode nd = grid.node(j, xr, true);
-        xr = grid.next_x(xr, j + 1, it);
-#else
     const int j_first = j;
-    xr = grid.last_x();
+    double xr = grid.last_x();  // running abscissa (MovingGrid); a table (FixedGrid) ignores it
 #pragma unroll 1
     for (int it = 0, jj = nb - 1; jj >= j_first; --jj, ++it) {
         const SimpsonNode nd = grid.node(jj, xr, true);
         xr = grid.prev_x(xr, jj - 1, it);
-#endif
         const double t = nd.x * inv_th, zr = nd.xmx * inv_th;
         const bool zpos = zr > 0.0;  // P(a, z <= 0) = 0: such a node (never on the reference grid) contributes nothing
         const double z = zpos ? zr : 1.0;
@@ -457,103 +455,40 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double th,
     for (int t = 0; t < T; ++t) msh[t] = acc[t];
 }
 
-// CLOUDY_F32_FAST plans: the same Simpson pass with single-precision arithmetic for everything that is done per
-// node (exp via v_exp_f32, series / continued fraction to ~1e-7, fp32 accumulators); the exponents of the two
-// exp() calls are still formed in fp64 (they are differences of O(100) terms).  Early-node expansion with 10 terms
-// and the wider radius t <= 2, t max(a-1,2)/z0 <= 0.4 (truncation < 4e-10, checked against mpmath).  Everything
-// outside this function (closure inversion, moments, F/min, Q/R/S) stays fp64.  Expected accuracy of the msh
-// entries ~1e-6 relative; tests report the error against the fp64 oracle.
+// CLOUDY_F32_FAST plans: the same Simpson pass with single-precision arithmetic for everything that is done per late
+// node (exp via v_exp_f32, series / continued fraction to ~1e-7, fp32 accumulators); the exponents of the two exp()
+// calls are still formed in fp64 (they are differences of O(100) terms).  The early nodes take the fp64 closed form
+// (early_series): it is cheaper than any loop over them.  Everything outside this function (closure inversion, moments,
+// F/min, Q/R/S) stays fp64.  Expected accuracy of the msh entries ~1e-6 relative; tests report the error against the
+// fp64 oracle.
 template <int P, typename Grid>
 __device__ __forceinline__ void msh_grid_f32(const Grid &grid, double xt, double th, double k, bool is_gamma,
                                              double (&msh)[(P + 2) * (P + 3) / 2]) {  // WITHOUT the factor M_p2
     constexpr int M = P + 2;
     constexpr int T = M * (M + 1) / 2;
-    constexpr int NT = 10;
-    constexpr int NS = M + NT;
     const int nb = grid.n_bins();
-    const double inv_th = 1.0 / th, lnth = log(th);
+    const double inv_th = 1.0 / th, lnth = log_pos(th);
     const double a_top = k + double(M - 1);
-    const double lg_top = lgamma(a_top + 1.0);
+    const double lg_top = lgamma_pos(a_top + 1.0);
     const double z0 = xt * inv_th;
     const float a_topf = (float)a_top;
+    // early nodes: the fp64 closed form (early_series) -- it costs less than a single-precision loop over the nodes
+    double acc_early[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc_early[t] = 0.0;
+    const int j = early_series<P>(grid, nb, xt, th, k, inv_th, lnth, a_top, lg_top, z0, acc_early);
     float acc[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = 0.0f;
-    const double x_early = fmin(2.0 * th, 0.4 * xt / fmax(a_top - 1.0, 2.0));
-    int j = 0;
-    double xr = grid.first_x();
-    {
-        // power sums in u = x / x_t (<= 1: no single-precision range problems even for theta ~ 1e15 of clamped
-        // closures); the expansion is then in b_n = c_n z0^n:  b_{n+1} = ((z0 - a + 1 + n) b_n - z0 b_{n-1}) / (n+1),
-        // P(a, z0 - z0 u) = P(a, z0) - g z0 sum_n b_n u^(n+1) / (n+1)
-        float U[NS];
-#pragma unroll
-        for (int q = 0; q < NS; ++q) U[q] = 0.0f;
-        const double inv_xt = 1.0 / xt;
-#pragma unroll 1
-        for (; j < nb; ++j) {
-            if (!(grid.node_x(j, xr) <= x_early)) break;
-            const SimpsonNode nd = grid.node(j, xr, false);
-            xr = grid.next_x(xr, j + 1, j);
-            const double td = nd.x * inv_th;
-            const float u = (float)(nd.x * inv_xt);
-            float e = (float)nd.wdx * __expf((float)fma(k, nd.lx - lnth, -td));
-#pragma unroll
-            for (int q = 0; q < NS; ++q) {
-                U[q] += e;
-                e *= u;
-            }
-        }
-        if (j > 0) {
-            const float z0f = (float)z0, invz0 = (float)(1.0 / z0);
-            float E = __expf((float)(fma(a_top, log(xt) - lnth, -z0) - lg_top));
-            float Pv = inc_gamma_p_from_E_f32(a_topf, z0f, E);
-            float a = a_topf;
-            float xtp[M];  // x_t^p1
-            xtp[0] = 1.0f;
-#pragma unroll
-            for (int p1 = 1; p1 < M; ++p1) xtp[p1] = xtp[p1 - 1] * (float)xt;
-#pragma unroll
-            for (int p2 = M - 1; p2 >= 0; --p2) {
-                const float g = E * a * invz0;  // dP/dz at z0
-                float G[M];
-#pragma unroll
-                for (int p1 = 0; p1 < M; ++p1) G[p1] = 0.0f;
-                float bm = 0.0f, bc = 1.0f;
-#pragma unroll
-                for (int nn2 = 0; nn2 < NT; ++nn2) {
-                    const float w = bc * (1.0f / float(nn2 + 1));
-#pragma unroll
-                    for (int p1 = 0; p1 <= p2; ++p1) G[p1] = fmaf(w, U[p1 + nn2 + 1], G[p1]);
-                    const float bn = ((z0f - a + 1.0f + float(nn2)) * bc - z0f * bm) * (1.0f / float(nn2 + 1));
-                    bm = bc;
-                    bc = bn;
-                }
-                const float gz = g * z0f;
-#pragma unroll
-                for (int p1 = 0; p1 <= p2; ++p1) acc[tri<M>(p1, p2)] = xtp[p1] * fmaf(Pv, U[p1], -(gz * G[p1]));
-                Pv += g;
-                E = g;
-                a -= 1.0f;
-            }
-        }
-    }
     // From the LAST node down: in a regime-sorted wave every lane is then at the same node index in the same iteration
     // (the lanes differ in where their early group ends, not in where the grid ends), so z = (x_t - x_j) / theta is as
     // homogeneous across the wave as theta is -- and the node table of a FixedGrid is read at wave-uniform addresses.
-#ifdef CLOUDY_LATE_ASCENDING  // timing experiment only: the order of rounds 1 and 2a
-#pragma unroll 1
-    for (int it = 0; j < nb; ++j, ++it) {
-        const SimpsonNode nd = grid.node(j, xr, true);
-        xr = grid.next_x(xr, j + 1, it);
-#else
     const int j_first = j;
-    xr = grid.last_x();
+    double xr = grid.last_x();  // running abscissa (MovingGrid); a table (FixedGrid) ignores it
 #pragma unroll 1
     for (int it = 0, jj = nb - 1; jj >= j_first; --jj, ++it) {
         const SimpsonNode nd = grid.node(jj, xr, true);
         xr = grid.prev_x(xr, jj - 1, it);
-#endif
         const double td = nd.x * inv_th, zd = nd.xmx * inv_th;
         if (!(zd > 0.0)) continue;
         const float z = (float)zd, xf = (float)nd.x;
@@ -578,7 +513,7 @@ __device__ __forceinline__ void msh_grid_f32(const Grid &grid, double xt, double
         }
     }
 #pragma unroll
-    for (int t = 0; t < T; ++t) msh[t] = (double)acc[t];
+    for (int t = 0; t < T; ++t) msh[t] = acc_early[t] + (double)acc[t];
 }
 
 // compute_threshold, ParticleDistributions.jl:747-761.  The percentile is a plan constant, so gamma_inc_inv(k, p, 1 - p)
