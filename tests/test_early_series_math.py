@@ -1,0 +1,132 @@
+"""The mathematics of early_series (cloudy.jl_amd/csrc/kernels.hpp): the early nodes of moment_source_helper's Simpson
+grid (ParticleDistributions.jl:589-612, weights :698-710) summed WITHOUT a loop over them.
+
+This is a double-precision restatement in Python of the device routine's recurrences (same terms, same radius, same
+scaling) against the direct node sum in 40-digit arithmetic (mpmath).  It pins the claims made in DESIGN.md 3.2:
+
+  * G_a(u) = e^{-z0 u} P(a, z0 (1 - u)) has the power series d_0 = P(a, z0), d_{s+1} = -z0 (d_s + C_a beta_s) / (s + 1);
+  * G_{a-1} = G_a + C_a (1 - u)^(a-1);
+  * the geometric node sums with the four-term Simpson end correction are closed forms;
+  * 30 terms at radius (t <= 3, u (a_top - 1) <= 1.5, u <= 1/2) leave the truncation below the rounding floor.
+
+The device code itself is checked against the CPU oracle (which loops over the nodes as the reference does) by the
+-m gpu parity tests; this file makes the series reproducible on a CPU box.
+"""
+import math
+
+import pytest
+
+mp = pytest.importorskip("mpmath")
+
+M = 5            # P + 2 for the order-2 tensors of cfg3b
+S_TERMS = 30     # kEarlySeries
+T_MAX, UA = 3.0, 1.5
+
+
+def _simpson_w(j):
+    return (17.0 / 48, 59.0 / 48, 43.0 / 48, 49.0 / 48)[j] if j < 4 else 1.0
+
+
+def _grid(xt):
+    x_lb = min(1e-5, 1e-5 * xt)
+    nb = int(math.floor(15 * math.log10(xt / x_lb)))
+    lx0 = math.log(x_lb)
+    return nb, lx0, (math.log(xt) - lx0) / nb
+
+
+def _direct(k, th, xt, J, lx0, dx):
+    z0 = mp.mpf(xt) / th
+    out = [[mp.mpf(0)] * M for _ in range(M)]
+    for j in range(J):
+        x = mp.exp(mp.mpf(lx0) + j * mp.mpf(dx))
+        t = x / th
+        base = _simpson_w(j) * mp.mpf(dx) * t ** k * mp.exp(-t)
+        for p2 in range(M):
+            P = mp.gammainc(k + p2, 0, z0 - t, regularized=True)
+            for p1 in range(p2 + 1):
+                out[p1][p2] += base * x ** p1 * P
+    return out
+
+
+def _series(k, th, xt, J, lx0, dx, terms=S_TERMS):
+    z0 = xt / th
+    xJ = math.exp(lx0 + J * dx)
+    uJ, tJ = xJ / xt, xJ / th
+    rho, rho_Jinv = math.exp(dx), math.exp(-J * dx)
+    r, b = math.exp(k * dx), math.exp(-J * k * dx)
+    a_top = k + M - 1
+    e_top = float(mp.gammainc(a_top, 0, z0, regularized=True))                    # d_0 of the top order
+    Etop = math.exp(a_top * math.log(z0) - z0 - math.lgamma(a_top + 1.0))
+    CB, al, g, a = [], [], Etop, a_top
+    for _ in range(M - 1):                                                        # C_a B_s, exponent a - 1
+        g *= a / z0
+        CB.append(g)
+        al.append(a - 1.0)
+        a -= 1.0
+
+    def next_W(first):
+        nonlocal r, b
+        omb = -math.expm1(-J * k * dx) if first else 1.0 - b
+        rm1 = math.expm1(k * dx) if first else r - 1.0
+        c = 31.0 / 48 + r * (-11.0 / 48 + r * (5.0 / 48 - r / 48))
+        W = dx * (omb / rm1 - b * c)
+        r *= rho
+        b *= rho_Jinv
+        return W
+
+    win = [next_W(s == 0) for s in range(M - 1)] + [0.0]
+    acc = [[0.0] * M for _ in range(M)]
+    for n in range(terms):
+        win[M - 1] = next_W(False)
+        e = e_top
+        for p2 in range(M - 1, -1, -1):
+            for p1 in range(p2 + 1):
+                acc[p1][p2] += e * win[p1]
+            if p2 > 0:
+                e += CB[M - 1 - p2]
+        e_top = (e_top + CB[0]) * (-tJ / (n + 1))
+        f = uJ / (n + 1)
+        CB = [cb * (n - al_i) * f for cb, al_i in zip(CB, al)]
+        win = win[1:] + [0.0]
+    tk = float(mp.mpf(tJ) ** mp.mpf(k))   # (the device forms exp(k ln t_J): ~|k ln t_J| eps more, covered by the GPU tests)
+    for p2 in range(M):
+        for p1 in range(p2 + 1):
+            acc[p1][p2] *= tk * xJ ** p1
+    return acc
+
+
+CASES = [  # (k, z0 = x_t / theta, x_t)
+    (1e-9, 24.7, 1.0), (0.05, 0.4, 3e-3), (0.5, 117.0, 1.0), (1.0, 190.0, 5e-4), (1.0, 2.5e-3, 1.0), (2.7, 17.8, 5e-1),
+    (4.2, 5.5, 5e-10 / 1e-9), (6.8, 3.7, 1.0), (8.2, 2e-3, 1e-2), (9.6, 2e-3, 1.0), (10.0, 15.0, 1.0), (10.0, 300.0, 7.0),
+    (3.0, 57.0, 1e-6), (7.6, 38.7, 1.0),
+]
+
+
+@pytest.mark.parametrize("k,z0,xt", CASES)
+def test_closed_form_early_nodes_match_the_node_sum(k, z0, xt):
+    th = xt / z0
+    nb, lx0, dx = _grid(xt)
+    a_top = k + M - 1
+    x_early = min(T_MAX * th, UA * xt / max(a_top - 1.0, 3.0))
+    J = min(int(math.floor((math.log(x_early) - lx0) / dx)) + 1, nb)
+    assert 4 <= J <= nb - 4, "case outside the early-series regime"
+    want = _direct(k, th, xt, J, lx0, dx)
+    got = _series(k, th, xt, J, lx0, dx)
+    err = max(abs(got[p1][p2] - want[p1][p2]) / abs(want[p1][p2]) for p2 in range(M) for p1 in range(p2 + 1))
+    assert float(err) < 1e-13, f"J = {J} of {nb} nodes: relative error {float(err):.2e}"
+
+
+def test_truncation_order_and_radius():
+    """fewer terms are NOT enough at the radius in use (the terms are not padding), more change nothing"""
+    k, z0, xt = 0.5, 117.0, 1.0
+    th = xt / z0
+    nb, lx0, dx = _grid(xt)
+    J = int(math.floor((math.log(T_MAX * th) - lx0) / dx)) + 1
+    want = _direct(k, th, xt, J, lx0, dx)
+
+    def err(terms):
+        got = _series(k, th, xt, J, lx0, dx, terms)
+        return float(max(abs(got[p1][p2] - want[p1][p2]) / abs(want[p1][p2]) for p2 in range(M) for p1 in range(p2 + 1)))
+
+    e22, e30, e38 = err(22), err(30), err(38)
+    assert e22 > 1e-11 and e30 < 1e-13 and abs(e38 - e30) < 5e-14
