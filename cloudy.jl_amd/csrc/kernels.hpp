@@ -311,9 +311,11 @@ __device__ __forceinline__ int early_series(const Grid &grid, int nb, double xt,
             const double jf = floor((log_pos(x_early) - lx0) / dxl) + 1.0;  // nodes with x_j <= x_early
             J = jf < double(nb) ? (int)jf : nb;
         }
-        // fewer than four early nodes (the end correction assumes the first four): none; and never the last three
-        // nodes, whose weights differ (u <= 1/2 keeps 4.5 nodes of distance on the reference's 15-per-decade grid)
-        if (J < 4 || J > nb - 4) J = 0;
+        // never the last three nodes, whose weights differ (u <= 1/2 keeps 4.5 nodes of distance on the reference's
+        // 15-per-decade grid; coarser grids give up a node or two of the group); fewer than four early nodes (the end
+        // correction assumes the first four): none
+        if (J > nb - 4) J = nb - 4;
+        if (J < 4) J = 0;
         if (J > 0) {
             const double Jd = double(J);
             const double xJ = exp_fin(fma(Jd, dxl, lx0));  // node J itself, as the reference computes it
@@ -1303,9 +1305,12 @@ __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__rest
                                                        const double *__restrict__ nodes, int nz, size_t n_columns,
                                                        size_t ld, const TIO *u_in, TIO *u_out, double dt, double dz,
                                                        int n_steps) {
-    __shared__ double sh_flux[N * 3][kBlock];
+    // (384-thread workgroups -- a finer ranking, 4 instead of 16 idle lanes with 20-cell columns -- measured 40 % slower:
+    // two six-wave workgroups per CU overlap their per-stage barriers worse than three four-wave ones)
+    constexpr int BS = kBlock;
+    __shared__ double sh_flux[N * 3][BS];
     const KArgs<N, P> &A = *Ag;
-    const int cpb = kBlock / nz;   // whole columns per workgroup
+    const int cpb = BS / nz;       // whole columns per workgroup
     const int pos = threadIdx.x;   // cell slot of the workgroup this lane integrates: column pos / nz, level pos % nz
     // (With a finite threshold the Simpson passes of every stage run on cells re-ranked on that stage's state, per
     // thresholded mode: coal_ints_ranked.  Round 1 permuted the lanes once, on the initial state.)
@@ -1384,7 +1389,7 @@ __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__rest
             if (MODE == MODE_ALLINF) {
                 if (active) coal_ints_parcel<N, P, MODE, false, SPEC>(Ac, nodes, nn, th, kk, acc);
             } else {  // every lane of the workgroup: barriers inside
-                coal_ints_ranked<N, P, MODE, SPEC, kBlock>(Ac, nodes, active, nn, th, kk, acc);
+                coal_ints_ranked<N, P, MODE, SPEC, BS>(Ac, nodes, active, nn, th, kk, acc);
             }
             if (active) {
 #pragma unroll

@@ -108,8 +108,8 @@ def test_closed_form_early_nodes_match_the_node_sum(k, z0, xt):
     nb, lx0, dx = _grid(xt)
     a_top = k + M - 1
     x_early = min(T_MAX * th, UA * xt / max(a_top - 1.0, 3.0))
-    J = min(int(math.floor((math.log(x_early) - lx0) / dx)) + 1, nb)
-    assert 4 <= J <= nb - 4, "case outside the early-series regime"
+    J = min(int(math.floor((math.log(x_early) - lx0) / dx)) + 1, nb - 4)
+    assert J >= 4, "case outside the early-series regime"
     want = _direct(k, th, xt, J, lx0, dx)
     got = _series(k, th, xt, J, lx0, dx)
     err = max(abs(got[p1][p2] - want[p1][p2]) / abs(want[p1][p2]) for p2 in range(M) for p1 in range(p2 + 1))
