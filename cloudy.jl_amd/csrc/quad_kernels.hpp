@@ -110,6 +110,14 @@ __device__ __forceinline__ void coal_rhs_quad_body(const KArgs<N, 1> &A, const Q
         }
         // ---- self collisions of mode j
         {
+            LogDensity dlg[N];  // parameters of ln g_m - ln g_j (Gamma family)
+#pragma unroll
+            for (int m = 0; m < N; ++m) {
+                dlg[m].a = lg[m].a - lg[j].a;
+                dlg[m].b = lg[m].b - lg[j].b;
+                dlg[m].c = lg[m].c - lg[j].c;
+                dlg[m].lognormal = false;
+            }
             double s0 = 0.0, sab = 0.0, T0 = 0.0, T1 = 0.0, T2 = 0.0;
 #pragma unroll 1
             for (int a = 0; a < nq; ++a) {
@@ -125,12 +133,17 @@ __device__ __forceinline__ void coal_rhs_quad_body(const KArgs<N, 1> &A, const Q
                     sab = fma(Kab, xa * xb, sab);
                     if (j < N - 1) {
                         const double xs = xa + xb, lx = log_pos(xs);
-                        const double own = lg[j](xs, lx);
+                        const double own = lg[j].lognormal ? lg[j](xs, lx) : 0.0;
                         double up = 0.0, den = 1.0;
 #pragma unroll
                         for (int m = 0; m < N; ++m) {
                             if (m == j) continue;
-                            const double rho = exp_fin(fmin(lg[m](xs, lx) - own, 700.0));
+                            // ln g_m - ln g_j; between two Gamma-family modes with the parameter differences formed
+                            // once per pair of modes (two FMAs per point, and no cancellation between the two logs)
+                            const double e = (lg[m].lognormal || lg[j].lognormal)
+                                                 ? lg[m](xs, lx) - (lg[j].lognormal ? own : lg[j](xs, lx))
+                                                 : fma(dlg[m].a, lx, fma(-dlg[m].b, xs, -dlg[m].c));
+                            const double rho = exp_fin(fmin(e, 700.0));
                             den += rho;
                             if (m > j) up += rho;
                         }
