@@ -309,13 +309,11 @@ __device__ __forceinline__ int early_series(const Grid &grid, int nb, double xt,
         int J = 0;
         if (x_early >= xr) {  // xr = the first node
             const double jf = floor((log_pos(x_early) - lx0) / dxl) + 1.0;  // nodes with x_j <= x_early
-            J = jf < double(nb) ? (int)jf : nb;
+            // never the last three nodes, whose weights differ (u <= 1/2 keeps 4.5 nodes of distance on the reference's
+            // 15-per-decade grid; a coarser grid gives up a node or two of the group)
+            J = jf < double(nb - 4) ? (int)jf : nb - 4;
         }
-        // never the last three nodes, whose weights differ (u <= 1/2 keeps 4.5 nodes of distance on the reference's
-        // 15-per-decade grid; coarser grids give up a node or two of the group); fewer than four early nodes (the end
-        // correction assumes the first four): none
-        if (J > nb - 4) J = nb - 4;
-        if (J < 4) J = 0;
+        if (J < 4) J = 0;  // fewer than four early nodes (the end correction assumes the first four): none
         if (J > 0) {
             const double Jd = double(J);
             const double xJ = exp_fin(fma(Jd, dxl, lx0));  // node J itself, as the reference computes it
