@@ -117,9 +117,9 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
         int nz = (int)r.nz, n_steps = r.n_steps;
         size_t n_columns = r.n / r.nz;
         double dt = r.dt, dz = r.dz;
-        const size_t cpb = kBlock / r.nz;
+        const size_t cpb = kRainshaftBlock / r.nz;
         void *args[] = {&nodes, &nz, &n_columns, &ld, &in, &out, &dt, &dz, &n_steps};
-        return hipModuleLaunchKernel(plan->rs_int, (unsigned)((n_columns + cpb - 1) / cpb), 1, 1, kBlock, 1, 1, 0, r.stream,
+        return hipModuleLaunchKernel(plan->rs_int, (unsigned)((n_columns + cpb - 1) / cpb), 1, 1, kRainshaftBlock, 1, 1, 0, r.stream,
                                      args, nullptr);
     }
     if (h.coal_style == CLOUDY_NUMERICAL_COAL) {

@@ -1232,6 +1232,11 @@ __global__ void __launch_bounds__(kBlock)
 #define CLOUDY_STAGE_BARRIER() __syncthreads()
 #endif
 
+#ifndef CLOUDY_RS_BLOCK
+#define CLOUDY_RS_BLOCK 256
+#endif
+constexpr int kRainshaftBlock = CLOUDY_RS_BLOCK;  // workgroup size of the fused column integrator
+
 struct SediArgs {
     int32_t n_vel, pad;
     double vel[4][2];  // already rescaled by norms[1]^vel[k][1] (rainshaft_helpers.jl:74-76)
@@ -1303,9 +1308,10 @@ __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__rest
                                                        const double *__restrict__ nodes, int nz, size_t n_columns,
                                                        size_t ld, const TIO *u_in, TIO *u_out, double dt, double dz,
                                                        int n_steps) {
-    // (384-thread workgroups -- a finer ranking, 4 instead of 16 idle lanes with 20-cell columns -- measured 40 % slower:
-    // two six-wave workgroups per CU overlap their per-stage barriers worse than three four-wave ones)
-    constexpr int BS = kBlock;
+    // (workgroup size, 20-cell columns: 384 threads -- a finer ranking, 4 instead of 16 idle lanes -- measured 40 % slower,
+    // two six-wave workgroups per CU overlap their per-stage barriers worse than three four-wave ones; 128 threads 8 %
+    // slower, the ranking over 128 cells is too coarse)
+    constexpr int BS = kRainshaftBlock;
     __shared__ double sh_flux[N * 3][BS];
     const KArgs<N, P> &A = *Ag;
     const int cpb = BS / nz;       // whole columns per workgroup
@@ -1429,7 +1435,7 @@ __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__rest
 }
 
 template <int N, int P, int MODE, typename TIO>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kRainshaftBlock)
     rainshaft_ssprk33_kernel(const KArgs<N, P> *__restrict__ Ag, const double *__restrict__ nodes, int nz,
                              size_t n_columns, size_t ld, const TIO *u_in, TIO *u_out, double dt, double dz,
                              int n_steps) {

@@ -39,13 +39,13 @@ hipError_t launch_int_io(const HostPlan &h, const LaunchReq &r) {
         if (!h.kargs_dev) return hipErrorNotInitialized;
         if (r.nz < 1 || r.nz > (size_t)kBlock) return hipErrorInvalidValue;
         const KArgs<N, P> *Ad = static_cast<const KArgs<N, P> *>(h.kargs_dev);
-        const size_t cpb = kBlock / r.nz, n_columns = r.n / r.nz;
+        const size_t cpb = kRainshaftBlock / r.nz, n_columns = r.n / r.nz;
         const unsigned g = (unsigned)((n_columns + cpb - 1) / cpb);
         if (h.mode == MODE_ALLINF)
-            hipLaunchKernelGGL((rainshaft_ssprk33_kernel<N, P, MODE_ALLINF, TIO>), dim3(g), dim3(kBlock), 0, r.stream,
+            hipLaunchKernelGGL((rainshaft_ssprk33_kernel<N, P, MODE_ALLINF, TIO>), dim3(g), dim3(kRainshaftBlock), 0, r.stream,
                                Ad, h.nodes_dev, (int)r.nz, n_columns, r.ld, in, out, r.dt, r.dz, r.n_steps);
         else if (h.mode == MODE_FIXED)
-            hipLaunchKernelGGL((rainshaft_ssprk33_kernel<N, P, MODE_FIXED, TIO>), dim3(g), dim3(kBlock), 0, r.stream,
+            hipLaunchKernelGGL((rainshaft_ssprk33_kernel<N, P, MODE_FIXED, TIO>), dim3(g), dim3(kRainshaftBlock), 0, r.stream,
                                Ad, h.nodes_dev, (int)r.nz, n_columns, r.ld, in, out, r.dt, r.dz, r.n_steps);
         else
             return hipErrorInvalidValue;  // make_rainshaft_rhs is FixedThreshold only (rainshaft_helpers.jl:70)
