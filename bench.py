@@ -457,6 +457,18 @@ def _cfg4q_variant(pkg, rank, world, measured, n=CFG4Q_PARCELS, reps=3):
     rl = _valu_roofline(measured, "cfg4q", n, ms)
     if rl:
         out["roofline"] = rl
+    # the Numerical drivers' time stepping fused around this RHS (cloudy_ssprk33_steps, quad_ssprk33_body): one SSPRK33
+    # step = 3 evaluations per call, state in registers
+    dt_step = 1e-3
+    pkg._lib.check(L.cloudy_ssprk33_steps(plan.handle, n, n, m.ptr, dm.ptr, C.c_double(dt_step), 1, None))
+    pkg._lib.check(L.cloudy_stream_synchronize(None))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        pkg._lib.check(L.cloudy_ssprk33_steps(plan.handle, n, n, m.ptr, dm.ptr, C.c_double(dt_step), 1, None))
+    pkg._lib.check(L.cloudy_stream_synchronize(None))
+    dts = (time.perf_counter() - t0) / reps
+    out["fused_ssprk33"] = {"workload": "cloudy_ssprk33_steps on the same plan and batch: 1 SSPRK33 step (3 RHS evaluations) per call",
+                            "value": 3 * n * world / dts, "unit": "parcel-RHS/s", "ms_per_call": 1e3 * dts}
     return out
 
 

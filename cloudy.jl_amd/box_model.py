@@ -80,11 +80,14 @@ def make_box_model_rhs(coal_type, threshold_style=None):
     return rhs
 
 
-def solve_ssprk33(par, u, dt, n_steps, out=None, stream=None):
+def solve_ssprk33(par, u, dt, n_steps, out=None, stream=None, coal_type=None):
     """solve(ODEProblem(rhs, u, tspan, par), SSPRK33(), dt = dt) for n_steps fixed steps, on the device
     (cloudy_ssprk33_steps): the final state only (the examples' `sol.u[end]`).  `u` is advanced in place unless
-    `out` is given."""
-    plan = _plan_for(par, dtype_code(u))
+    `out` is given.  `coal_type`: the style the RHS was made with (make_box_model_rhs(coal_type)); default
+    AnalyticalCoalStyle, NumericalCoalStyle() integrates get_coal_ints(::NumericalCoalStyle, p.pdists, p.kernel_func)."""
+    if coal_type is not None and not isinstance(coal_type, (AnalyticalCoalStyle, NumericalCoalStyle)):
+        raise ValueError("Invalid coal style!")
+    plan = _numerical_plan_for(par, dtype_code(u)) if isinstance(coal_type, NumericalCoalStyle) else _plan_for(par, dtype_code(u))
     uptr, planes, n, ld = as_device(u)
     o = out if out is not None else u
     optr, oplanes, on, old = as_device(o)

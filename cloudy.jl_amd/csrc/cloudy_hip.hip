@@ -72,7 +72,7 @@ hipError_t dispatch(const HostPlan &h, const LaunchReq &r) {
         {launch_n3_p1, launch_n3_p2, launch_n3_p3, launch_n3_p4, launch_n3_p5},
         {launch_n4_p1, launch_n4_p2, launch_n4_p3, launch_n4_p4, launch_n4_p5}};
     if (h.N < 1 || h.N > CLOUDY_MAX_MODES || h.P < 1 || h.P > CLOUDY_MAX_P) return hipErrorInvalidValue;
-    if (h.coal_style == CLOUDY_NUMERICAL_COAL && r.op == OP_COAL) {
+    if (h.coal_style == CLOUDY_NUMERICAL_COAL && (r.op == OP_COAL || r.op == OP_SSPRK33)) {
         static const Fn quad[CLOUDY_MAX_MODES] = {launch_quad_n1, launch_quad_n2, launch_quad_n3, launch_quad_n4};
         return quad[h.N - 1](h, r);
     }
@@ -123,8 +123,15 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
                                      args, nullptr);
     }
     if (h.coal_style == CLOUDY_NUMERICAL_COAL) {
-        void *args[] = {&n, &ld, &in, &out};
         const unsigned qb = (unsigned)quad_block(h.q.nq);
+        if (r.op == OP_SSPRK33) {
+            double dt = r.dt;
+            int n_steps = r.n_steps;
+            void *args[] = {&n, &ld, &in, &out, &dt, &n_steps};
+            return hipModuleLaunchKernel(plan->int_ssprk33, (unsigned)((n + qb - 1) / qb), 1, 1, qb, 1, 1, 0, r.stream, args,
+                                         nullptr);
+        }
+        void *args[] = {&n, &ld, &in, &out};
         return hipModuleLaunchKernel(plan->jit.quad, (unsigned)((n + qb - 1) / qb), 1, 1, qb, 1, 1, 0, r.stream, args,
                                      nullptr);
     }
@@ -166,10 +173,10 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
 
 int run(const cloudy_plan *plan, const LaunchReq &r) {
     if (plan->h.coal_style == CLOUDY_NUMERICAL_COAL &&
-        (r.op == OP_FINITE_2D || r.op == OP_SSPRK33 || r.op == OP_RAINSHAFT_SSPRK33 || r.rainshaft))
+        (r.op == OP_FINITE_2D || r.op == OP_RAINSHAFT_SSPRK33 || r.rainshaft))
         return fail(CLOUDY_EUNSUPPORTED,
-                    "NumericalCoalStyle plans serve cloudy_coal_rhs / cloudy_get_coal_ints and the per-mode diagnostics; "
-                    "thresholds, the rainshaft body and the fused integrators belong to AnalyticalCoalStyle plans");
+                    "NumericalCoalStyle plans serve cloudy_coal_rhs / cloudy_get_coal_ints / cloudy_ssprk33_steps and the "
+                    "per-mode diagnostics; thresholds and the rainshaft body belong to AnalyticalCoalStyle plans");
     if (r.n == 0) return CLOUDY_OK;
     DeviceGuard guard(plan->h.device);
     if (guard.err != hipSuccess) return fail_hip(guard.err, "selecting the plan's device");
@@ -184,7 +191,7 @@ int run(const cloudy_plan *plan, const LaunchReq &r) {
         std::call_once(plan->rs_once, [&] { (void)jit_get_rainshaft(plan->h, plan->rs_coal, plan->int_log); });
         use_jit = plan->rs_coal != nullptr;
     }
-    if (use_jit && r.op == OP_SSPRK33 && plan->h.mode != MODE_ALLINF) {
+    if (use_jit && r.op == OP_SSPRK33 && (plan->h.mode != MODE_ALLINF || plan->h.coal_style == CLOUDY_NUMERICAL_COAL)) {
         std::call_once(plan->int_once,
                        [&] { (void)jit_get_integrator(plan->h, plan->int_ssprk33, plan->int_log); });
         use_jit = plan->int_ssprk33 != nullptr;  // otherwise the ahead-of-time integrator
@@ -559,6 +566,7 @@ int cloudy_jit_selfcheck(const cloudy_plan_desc *d, const char *arch) {
     const std::string a = (arch && *arch) ? arch : "gfx950";
     const bool numerical = p->h.coal_style == CLOUDY_NUMERICAL_COAL;
     bool ok = jit_compile(jit_source(p->h, 0), a, !numerical && p->h.mode == MODE_ALLINF, code, log);
+    if (ok && numerical) ok = jit_compile(jit_source(p->h, 1), a, true, code, log);  // fused SSPRK33 of the quadrature plan
     if (ok && !numerical && p->h.mode != MODE_ALLINF) ok = jit_compile(jit_source(p->h, 1), a, true, code, log);
     if (ok && !numerical) ok = jit_compile(jit_source(p->h, 2), a, false, code, log);  // rainshaft cell body
     if (ok && !numerical && p->h.n_vel > 0 && p->h.mode != MODE_MOVING)

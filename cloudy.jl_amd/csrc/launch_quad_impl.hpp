@@ -8,6 +8,11 @@ namespace cloudy {
 
 template <int N, int KIND, typename TIO>
 hipError_t launch_quad_io(const HostPlan &h, const LaunchReq &r, const KArgs<N, 1> &A) {
+    if (r.op == OP_SSPRK33) {  // cloudy_ssprk33_steps of a NumericalCoalStyle plan (quad_ssprk33_body)
+        hipLaunchKernelGGL((quad_ssprk33_kernel<N, KIND, TIO>), dim3(grid_for(r.n, true)), dim3(kBlock), 0, r.stream, A, h.q,
+                           h.qtab_dev, r.n, r.ld, static_cast<const TIO *>(r.in), static_cast<TIO *>(r.out), r.dt, r.n_steps);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL((coal_rhs_quad_kernel<N, KIND, TIO>), dim3(grid_for(r.n, true)), dim3(kBlock), 0, r.stream, A, h.q,
                        h.qtab_dev, r.n, r.ld, static_cast<const TIO *>(r.in), static_cast<TIO *>(r.out));
     return hipGetLastError();
@@ -15,7 +20,7 @@ hipError_t launch_quad_io(const HostPlan &h, const LaunchReq &r, const KArgs<N, 
 
 template <int N>
 hipError_t launch_quad(const HostPlan &h, const LaunchReq &r) {
-    if (r.op != OP_COAL || h.P != 1 || !h.qtab_dev) return hipErrorInvalidValue;
+    if ((r.op != OP_COAL && r.op != OP_SSPRK33) || h.P != 1 || !h.qtab_dev) return hipErrorInvalidValue;
     KArgs<N, 1> A;
     fill_args<N, 1>(h, r, A);
     const bool f32 = h.dtype != CLOUDY_F64 && r.input_kind == IN_MOMENTS;  // (n, theta, k) planes are always fp64

@@ -37,18 +37,16 @@ struct LogDensity {
     }
 };
 
-template <int N, int KIND, int NQ, typename TIO>
-__device__ __forceinline__ void coal_rhs_quad_body(const KArgs<N, 1> &A, const QArgs &Q, const double *__restrict__ tab,
-                                                   size_t n, size_t ld, const TIO *__restrict__ in,
-                                                   TIO *__restrict__ out) {
+// get_coal_ints(::NumericalCoalStyle, ...) for the parcel of this lane (Coalescence.jl:470-489): acc[k][m] in normalised
+// units, WITHOUT the kernel function's constant factor kf_scale<KIND>(Q) (the caller folds it into its output scale).
+template <int N, int KIND, int NQ>
+__device__ __forceinline__ void quad_coal_ints(const KArgs<N, 1> &A, const QArgs &Q, const double *__restrict__ tab,
+                                               const double (&nn)[N], const double (&th)[N], const double (&kk)[N],
+                                               double (&acc)[N][3]) {
     constexpr int NQA = NQ ? NQ : kQuadMax;
     constexpr int QB = NQ ? quad_block(NQ) : kBlock;
     const int nq = NQ ? NQ : Q.nq;
     const int t = threadIdx.x;
-    const size_t i = (size_t)blockIdx.x * QB + t;
-    if (i >= n) return;
-    double nn[N], th[N], kk[N];
-    load_parcel<N, 1, TIO>(A, i, ld, in, nn, th, kk);
     // ---- the rule of every mode: aux (x or x^(1/3)) and v = n W
     double X[N][NQA], V[N][NQA];
 #pragma unroll
@@ -71,10 +69,8 @@ __device__ __forceinline__ void coal_rhs_quad_body(const KArgs<N, 1> &A, const Q
             }
         }
     }
-    double acc[N][3];
 #pragma unroll
     for (int k = 0; k < N; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.0;
-    const double ksc = kf_scale<KIND>(Q);
     LogDensity lg[N];
     if (N > 1) {
 #pragma unroll
@@ -191,12 +187,96 @@ __device__ __forceinline__ void coal_rhs_quad_body(const KArgs<N, 1> &A, const Q
             acc[k][2] += fma(2.0, sab, saa);
         }
     }
+}
+
+template <int N, int KIND, int NQ, typename TIO>
+__device__ __forceinline__ void coal_rhs_quad_body(const KArgs<N, 1> &A, const QArgs &Q, const double *__restrict__ tab,
+                                                   size_t n, size_t ld, const TIO *__restrict__ in,
+                                                   TIO *__restrict__ out) {
+    constexpr int QB = NQ ? quad_block(NQ) : kBlock;
+    const size_t i = (size_t)blockIdx.x * QB + threadIdx.x;
+    if (i >= n) return;
+    double nn[N], th[N], kk[N], acc[N][3];
+    load_parcel<N, 1, TIO>(A, i, ld, in, nn, th, kk);
+    quad_coal_ints<N, KIND, NQ>(A, Q, tab, nn, th, kk, acc);
+    const double ksc = kf_scale<KIND>(Q);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         const int off = A.off[k];
         st_stream(out + (size_t)(off + 0) * ld + i, acc[k][0] * (ksc * A.out_scale[3 * k + 0]));
         st_stream(out + (size_t)(off + 1) * ld + i, acc[k][1] * (ksc * A.out_scale[3 * k + 1]));
         if (A.np[k] == 3) st_stream(out + (size_t)(off + 2) * ld + i, acc[k][2] * (ksc * A.out_scale[3 * k + 2]));
+    }
+}
+
+// solve(ODEProblem(make_box_model_rhs(NumericalCoalStyle()), m, tspan, p), SSPRK33(), dt) -- the Numerical drivers
+// (test/examples/Numerical/n_particles_gamma.jl:39-40, single_particle_gamma.jl:41-42) -- with the state in registers
+// over all stages and steps, as ssprk33_body (kernels.hpp) does for the tensor plans: one read and one write of the state
+// per call, OrdinaryDiffEq's SSPRK33 update formulas ("/4" exact, "/3" correctly rounded).
+template <int N, int KIND, int NQ, typename TIO>
+__device__ __forceinline__ void quad_ssprk33_body(const KArgs<N, 1> &A, const QArgs &Q, const double *__restrict__ tab,
+                                                  size_t n, size_t ld, const TIO *u_in, TIO *u_out, double dt,
+                                                  int n_steps) {
+    constexpr int QB = NQ ? quad_block(NQ) : kBlock;
+    const size_t i = (size_t)blockIdx.x * QB + threadIdx.x;
+    if (i >= n) return;
+    double u[N][3], up[N][3];
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        const int off = A.off[m];
+        u[m][0] = (double)u_in[(size_t)(off + 0) * ld + i];
+        u[m][1] = (double)u_in[(size_t)(off + 1) * ld + i];
+        u[m][2] = (A.np[m] == 3) ? (double)u_in[(size_t)(off + 2) * ld + i] : 0.0;
+    }
+    const double ksc = kf_scale<KIND>(Q);
+#pragma unroll 1
+    for (int step = 0; step < n_steps; ++step) {
+#pragma unroll
+        for (int m = 0; m < N; ++m)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) up[m][q] = u[m][q];
+#pragma unroll 1
+        for (int stage = 0; stage < 3; ++stage) {
+            double nn[N], th[N], kk[N], acc[N][3], f[N][3];
+#pragma unroll
+            for (int m = 0; m < N; ++m) {  // mom ./ mom_norms, update_dist_from_moments (as load_parcel)
+                const double m0 = div_by_const(u[m][0], A.norm[3 * m + 0], A.inv_norm[3 * m + 0]);
+                const double m1 = div_by_const(u[m][1], A.norm[3 * m + 1], A.inv_norm[3 * m + 1]);
+                const double m2 = div_by_const(u[m][2], A.norm[3 * m + 2], A.inv_norm[3 * m + 2]);
+                invert_closure(A.dist_type[m], m0, m1, m2, A.kmin, A.kmax, nn[m], th[m], kk[m]);
+            }
+            quad_coal_ints<N, KIND, NQ>(A, Q, tab, nn, th, kk, acc);
+#pragma unroll
+            for (int m = 0; m < N; ++m) {
+                f[m][0] = acc[m][0] * (ksc * A.out_scale[3 * m + 0]);
+                f[m][1] = acc[m][1] * (ksc * A.out_scale[3 * m + 1]);
+                f[m][2] = (A.np[m] == 3) ? acc[m][2] * (ksc * A.out_scale[3 * m + 2]) : 0.0;
+            }
+            if (stage == 0) {
+#pragma unroll
+                for (int m = 0; m < N; ++m)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) u[m][q] = up[m][q] + dt * f[m][q];
+            } else if (stage == 1) {
+#pragma unroll
+                for (int m = 0; m < N; ++m)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) u[m][q] = (3.0 * up[m][q] + u[m][q] + dt * f[m][q]) * 0.25;
+            } else {
+#pragma unroll
+                for (int m = 0; m < N; ++m)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        u[m][q] = div_by_const(up[m][q] + 2.0 * u[m][q] + 2.0 * dt * f[m][q], 3.0, 1.0 / 3.0);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        const int off = A.off[m];
+        u_out[(size_t)(off + 0) * ld + i] = (TIO)u[m][0];
+        u_out[(size_t)(off + 1) * ld + i] = (TIO)u[m][1];
+        if (A.np[m] == 3) u_out[(size_t)(off + 2) * ld + i] = (TIO)u[m][2];
     }
 }
 
@@ -207,6 +287,13 @@ __global__ void __launch_bounds__(kBlock)
     coal_rhs_quad_kernel(const KArgs<N, 1> A, const QArgs Q, const double *__restrict__ tab, size_t n, size_t ld,
                          const TIO *__restrict__ in, TIO *__restrict__ out) {
     coal_rhs_quad_body<N, KIND, 0, TIO>(A, Q, tab, n, ld, in, out);
+}
+
+template <int N, int KIND, typename TIO>
+__global__ void __launch_bounds__(kBlock)
+    quad_ssprk33_kernel(const KArgs<N, 1> A, const QArgs Q, const double *__restrict__ tab, size_t n, size_t ld,
+                        const TIO *u_in, TIO *u_out, double dt, int n_steps) {
+    quad_ssprk33_body<N, KIND, 0, TIO>(A, Q, tab, n, ld, u_in, u_out, dt, n_steps);
 }
 
 }  // namespace cloudy

@@ -170,7 +170,7 @@ end
     solve_ssprk33!(u, plan, dt, n_steps; stream = nothing, sync = true)
 
 `solve(prob, SSPRK33(), dt = dt)` for `n_steps` fixed steps on the device (final state only): the state stays in
-registers over all stages, one read and one write of `u` per call.
+registers over all stages, one read and one write of `u` per call.  `plan` from `plan(...)` or `numerical_plan(...)`.
 """
 function solve_ssprk33!(u, plan, dt, n_steps; stream = nothing, sync::Bool = true)
     s = stream === nothing ? current_stream() : stream

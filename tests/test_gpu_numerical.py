@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import bench
-from test_gpu_parity import INF, assert_close_scaled, dev, mixed_moments
+from test_gpu_parity import INF, _ssprk33_host, assert_close_scaled, dev, mixed_moments
 
 pytestmark = pytest.mark.gpu
 
@@ -183,9 +183,10 @@ def test_numerical_plan_status_codes(gpu_cloudy):
     L, E = cloudy.lib(), cloudy._lib
     plan = cloudy.NumericalPlan([1, 1], cloudy.LinearKernelFunction(5e-3), NORMS, 10)
     u = cloudy.DeviceArray.zeros(6, 64)
-    assert L.cloudy_ssprk33_steps(plan.handle, 64, 64, u.ptr, u.ptr, 1.0, 1, None) == E.EUNSUPPORTED
-    assert b"NumericalCoalStyle" in L.cloudy_last_error()
+    assert L.cloudy_ssprk33_steps(plan.handle, 64, 64, u.ptr, u.ptr, 1.0, 1, None) == 0   # served (empty boxes stay empty)
+    assert L.cloudy_rainshaft_ssprk33_steps(plan.handle, 4, 16, 64, u.ptr, u.ptr, 100.0, 1.0, 1, None) == E.EINVAL  # no velocities
     assert L.cloudy_finite_2d_integrals(plan.handle, 64, 64, u.ptr, u.ptr, None) == E.EUNSUPPORTED
+    assert b"NumericalCoalStyle" in L.cloudy_last_error()
     assert L.cloudy_compute_thresholds(plan.handle, 64, 64, u.ptr, u.ptr, None) == E.EUNSUPPORTED
     assert L.cloudy_coal_rhs(plan.handle, 0, 0, None, None, None) == 0          # empty batch
     assert L.cloudy_coal_rhs(plan.handle, 64, 32, u.ptr, u.ptr, None) == E.EINVAL  # ld < n
@@ -195,6 +196,39 @@ def test_numerical_plan_status_codes(gpu_cloudy):
     with pytest.raises(cloudy.CloudyError) as ei:
         cloudy.NumericalPlan([1], cloudy.LinearKernelFunction(5e-3), NORMS, 33)
     assert ei.value.code == E.EUNSUPPORTED
+
+
+@pytest.mark.parametrize("dist_types,kname,specialize", [([1, 1, 1], "hydro", 0), ([1, 0], "long", 0), ([1, 1], "linear", -1)])
+def test_fused_ssprk33_of_numerical_plans_vs_oracle_stepping(gpu_cloudy, oracle, dist_types, kname, specialize):
+    """solve(prob, SSPRK33(), dt) of the Numerical drivers (n_particles_gamma.jl:39-40) fused on the device
+    (quad_ssprk33_body) against SSPRK33 steps of the same-rule oracle RHS on the host; plan-time compiled kernel
+    (through the host mirror) and, with specialize = -1, the ahead-of-time one (through the C ABI).  dt as in
+    test_fused_ssprk33_batch_vs_oracle_stepping."""
+    cloudy = gpu_cloudy
+    par, op, okf = numerical_case(cloudy, oracle, dist_types, kname)
+    n = 300
+    mom = mixed_moments(dist_types, n, seed=17)
+    dt, n_steps = 1e-3, 3
+    want = _ssprk33_host(lambda u: oracle.rhs_coal_numerical_batch(op, okf, 10, u), mom, dt, n_steps)
+    u = dev(cloudy, mom)
+    if specialize == 0:
+        cloudy.solve_ssprk33(par, u, dt, n_steps, coal_type=cloudy.NumericalCoalStyle())
+    else:
+        plan = cloudy.NumericalPlan(dist_types, par.kernel_func, NORMS, 10, specialize=specialize)
+        assert not plan.specialized
+        cloudy._lib.check(cloudy.lib().cloudy_ssprk33_steps(plan.handle, n, n, u.ptr, u.ptr, dt, n_steps, None))
+    got = u.to_numpy()
+    with np.errstate(all="ignore"):
+        ok = np.isfinite(want).all(axis=0) & (np.abs(want[:2]) <= 10 * np.abs(mom[:2]) + 1e-300).all(axis=0)
+    assert ok.sum() > 0.85 * n
+    ref = np.abs(mom) + np.abs(want)
+    err = np.abs(got - want)[:, ok] / np.maximum(ref[:, ok], 1e-300)
+    assert err.max() < 1e-9, err.max()
+    # and the fused call equals staged stepping with the device RHS (same arithmetic, different call structure)
+    staged = _ssprk33_host(lambda v: run_numerical(cloudy, par, v), mom, dt, n_steps)
+    err2 = np.abs(got - staged)[:, ok] / np.maximum(ref[:, ok], 1e-300)
+    assert err2.max() < 1e-12, err2.max()
+    print(f"{dist_types} {kname}: fused SSPRK33 vs oracle stepping {err.max():.2e}, vs staged device RHS {err2.max():.2e}")
 
 
 def test_cfg4q_full_size_properties(gpu_cloudy):
