@@ -272,6 +272,25 @@ def check_numerical_config(pkg, cfg, n, seed):
     both = np.isfinite(a) & np.isfinite(b) & keep[None, :]
     dj = float(np.max(np.abs(a - b)[both] / np.maximum(scale[both], 1e-300))) if both.any() else 0.0
     assert dj <= (1e-13 if cfg["dtype"] == 0 else 1e-6), f"plan-time compiled and ahead-of-time kernels differ by {dj:.2e} of scale"
+    if cfg["dtype"] == 0:
+        # cloudy_ssprk33_steps on the plan (quad_ssprk33_body), both kernels: one step against the same scheme staged on
+        # the host with the device RHS (same arithmetic, different call structure)
+        dt = 1e-3
+        u = mom_in.copy()
+        up = u
+        u = up + dt * run(pkg, jit, up, tio)
+        u = (3.0 * up + u + dt * run(pkg, jit, u, tio)) / 4.0
+        u = (up + 2.0 * u + 2.0 * dt * run(pkg, jit, u, tio)) / 3.0
+        with np.errstate(all="ignore"):
+            okp = np.all(np.isfinite(u), axis=0) & np.all(np.abs(u) < 10.0 * np.abs(mom_in) + 1e-300, axis=0) & keep
+        for plan in (jit, aot):
+            d_in, d_out = pkg.DeviceArray.from_numpy(mom_in), pkg.DeviceArray.zeros(*mom_in.shape)
+            pkg._lib.check(pkg.lib().cloudy_ssprk33_steps(plan.handle, mom_in.shape[1], mom_in.shape[1], d_in.ptr, d_out.ptr,
+                                                          dt, 1, None))
+            got = d_out.to_numpy()
+            ref = np.abs(mom_in) + np.abs(u)
+            e = np.abs(got - u)[:, okp] / np.maximum(ref[:, okp], 1e-300)
+            assert e.size == 0 or e.max() <= 1e-11, f"cloudy_ssprk33_steps vs staged device RHS: {e.max():.2e}"
     return (float(np.max(err[fin] / np.maximum(scale[fin], 1e-300))) if fin.any() else 0.0), dj
 
 
