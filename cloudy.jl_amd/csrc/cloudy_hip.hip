@@ -148,15 +148,16 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
         void *args[] = {&n, &ld, &in, &out, &dt, &n_steps};
         return hipModuleLaunchKernel(plan->jit.ssprk33, g1, 1, 1, kBlock, 1, 1, 0, r.stream, args, nullptr);
     }
+    void *out2 = r.out2;  // rainshaft cell body: the sedimentation flux planes (cloudy_rainshaft_sources), or null
     if (h.mode != MODE_ALLINF) {
         const double *nodes = h.nodes_dev;
-        void *args[] = {&nodes, &n, &ld, &in, &out};
+        void *args[] = {&nodes, &n, &ld, &in, &out, &out2};  // (the plain kernel takes the first five)
         const unsigned bs = (unsigned)jit_sorted_block_size(h);
         return hipModuleLaunchKernel(r.rainshaft ? plan->rs_coal : plan->jit.sorted, (unsigned)((n + bs - 1) / bs), 1, 1, bs, 1,
                                      1, 0, r.stream, args, nullptr);
     }
     if (r.rainshaft) {
-        void *args[] = {&n, &ld, &in, &out};
+        void *args[] = {&n, &ld, &in, &out, &out2};
         return hipModuleLaunchKernel(plan->rs_coal, g1, 1, 1, kBlock, 1, 1, 0, r.stream, args, nullptr);
     }
     const size_t esz = h.dtype != CLOUDY_F64 ? sizeof(float) : sizeof(double);
@@ -758,6 +759,15 @@ int cloudy_rainshaft_sources(const cloudy_plan *plan, size_t n, size_t ld, const
         return fail(CLOUDY_EINVAL, "make_rainshaft_rhs uses FixedThreshold (rainshaft_helpers.jl:70)");
     LaunchReq r1{OP_COAL, IN_MOMENTS, 1, 1, n, ld, mom_dev, coal_source_dev, nullptr,
                  (hipStream_t)stream};
+    // The cell-body kernel compiled for the plan writes the sedimentation flux as well (one launch, one read of the
+    // moments, one closure inversion); the ahead-of-time path is two launches.
+    if (plan->jit_on && n > 0) {
+        std::call_once(plan->rs_once, [&] { (void)jit_get_rainshaft(plan->h, plan->rs_coal, plan->int_log); });
+        if (plan->rs_coal != nullptr) {
+            r1.out2 = sedi_flux_dev;
+            return run(plan, r1);
+        }
+    }
     rc = run(plan, r1);
     if (rc) return rc;
     LaunchReq r2{OP_SEDI, IN_MOMENTS, 1, 1, n, ld, mom_dev, sedi_flux_dev, nullptr,

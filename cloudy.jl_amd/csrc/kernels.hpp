@@ -917,6 +917,46 @@ __device__ __forceinline__ void coal_ints_ranked(const KArgs<N, P> &A, const dou
     pair_terms<N, P, SPEC>(A, Mm, acc);
 }
 
+struct SediArgs {
+    int32_t n_vel, pad;
+    double vel[4][2];  // already rescaled by norms[1]^vel[k][1] (rainshaft_helpers.jl:74-76)
+};
+
+// get_sedimentation_flux, Sedimentation.jl:22-37: flux[i][j] = -sum_v vel_v0 * M^i_{j-1+vel_v1}
+// with the fractional-order moment n theta^q Gamma(q+k)/Gamma(k); normalised units.
+template <int N>
+__device__ __forceinline__ void sedi_flux_parcel(const int32_t (&dist_type)[N], const SediArgs &S, const double (&nn)[N],
+                                                 const double (&th)[N], const double (&kk)[N], double (&fl)[N][3]) {
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        const int dtp = dist_type[m];
+        const bool gam = (dtp == DIST_GAMMA || dtp == DIST_EXP);
+        const double lnth = (dtp == DIST_LOGNORMAL) ? th[m] : log_pos(th[m]);
+        double s[3] = {0.0, 0.0, 0.0};
+        for (int v = 0; v < S.n_vel; ++v) {
+            const double qv = S.vel[v][1];
+            if (gam) {
+                // M_qv from the log-gamma ratio once, the higher orders by M_{q+1} = M_q theta (k + q)
+                double mom = nn[m] * (qv == 0.0 ? 1.0 : exp_fin(fma(qv, lnth, log_gamma_ratio(kk[m], qv))));
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    s[j] = fma(-S.vel[v][0], mom, s[j]);
+                    mom *= th[m] * (kk[m] + qv + double(j));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const double q = double(j) + qv;  // log(M_q / n), ParticleDistributions.jl:193-207
+                    const double e = (dtp == DIST_MONO) ? q * lnth : fma(q, lnth, 0.5 * q * q * (kk[m] * kk[m]));
+                    s[j] = fma(-S.vel[v][0], nn[m] * exp(e), s[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) fl[m][j] = s[j];
+    }
+}
+
 // load one parcel (moments -> normalise -> invert, or parameters as given)
 template <int N, int P, typename TIO = double>
 __device__ __forceinline__ bool load_parcel(const KArgs<N, P> &A, size_t i, size_t ld, const TIO *__restrict__ in,
@@ -963,7 +1003,8 @@ __device__ __forceinline__ bool load_parcel(const KArgs<N, P> &A, size_t i, size
 // it live in SGPRs at once, 185-270 spilled-SGPR reloads in the hot path, +35 % VALU instructions measured.)
 template <int N, int P, int MODE, typename TIO, bool SPEC = false>
 __device__ __forceinline__ void coal_rhs_body(const KArgs<N, P> &A, const double *__restrict__ nodes, size_t n, size_t ld,
-                                              const TIO *__restrict__ in, TIO *__restrict__ out) {
+                                              const TIO *__restrict__ in, TIO *__restrict__ out,
+                                              const SediArgs *sedi = nullptr, TIO *__restrict__ out2 = nullptr) {
 #define CLOUDY_SPEC SPEC
 #include "coal_rhs_body.inc"
 #undef CLOUDY_SPEC
@@ -973,6 +1014,8 @@ template <int N, int P, int MODE, typename TIO>
 __global__ void __launch_bounds__(kBlock)
     coal_rhs_kernel(const KArgs<N, P> A, const double *__restrict__ nodes, size_t n, size_t ld,
                     const TIO *__restrict__ in, TIO *__restrict__ out) {
+    constexpr const SediArgs *sedi = nullptr;  // (the fused sedimentation flux exists in the plan-time compiled kernels)
+    constexpr TIO *out2 = nullptr;
 #define CLOUDY_SPEC false
 #include "coal_rhs_body.inc"
 #undef CLOUDY_SPEC
@@ -1010,7 +1053,8 @@ __global__ void __launch_bounds__(kBlock)
 // larger LDS footprint of N >= 3 it measured slower).
 template <int N, int P, int MODE, typename TIO, bool FAST = false, bool SPEC = false, int BS = kBlock>
 __device__ __forceinline__ void coal_rhs_sorted_body(const KArgs<N, P> &A, const double *__restrict__ nodes, size_t n,
-                                                     size_t ld, const TIO *__restrict__ in, TIO *__restrict__ out) {
+                                                     size_t ld, const TIO *__restrict__ in, TIO *__restrict__ out,
+                                                     const SediArgs *sedi = nullptr, TIO *__restrict__ out2 = nullptr) {
 #define CLOUDY_SPEC SPEC
 #define CLOUDY_BS BS
 #include "coal_rhs_sorted_body.inc"
@@ -1028,6 +1072,8 @@ template <int N, int P, int MODE, typename TIO, bool FAST = false, int BS = kBlo
 __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(CLOUDY_SORTED_WAVES)))
     coal_rhs_sorted_kernel(const KArgs<N, P> A, const double *__restrict__ nodes, size_t n, size_t ld,
                            const TIO *__restrict__ in, TIO *__restrict__ out) {
+    constexpr const SediArgs *sedi = nullptr;  // (the fused sedimentation flux exists in the plan-time compiled kernels)
+    constexpr TIO *out2 = nullptr;
 #define CLOUDY_SPEC false
 #define CLOUDY_BS BS
 #include "coal_rhs_sorted_body.inc"
@@ -1236,46 +1282,6 @@ __global__ void __launch_bounds__(kBlock)
 #define CLOUDY_RS_BLOCK 256
 #endif
 constexpr int kRainshaftBlock = CLOUDY_RS_BLOCK;  // workgroup size of the fused column integrator
-
-struct SediArgs {
-    int32_t n_vel, pad;
-    double vel[4][2];  // already rescaled by norms[1]^vel[k][1] (rainshaft_helpers.jl:74-76)
-};
-
-// get_sedimentation_flux, Sedimentation.jl:22-37: flux[i][j] = -sum_v vel_v0 * M^i_{j-1+vel_v1}
-// with the fractional-order moment n theta^q Gamma(q+k)/Gamma(k); normalised units.
-template <int N>
-__device__ __forceinline__ void sedi_flux_parcel(const int32_t (&dist_type)[N], const SediArgs &S, const double (&nn)[N],
-                                                 const double (&th)[N], const double (&kk)[N], double (&fl)[N][3]) {
-#pragma unroll
-    for (int m = 0; m < N; ++m) {
-        const int dtp = dist_type[m];
-        const bool gam = (dtp == DIST_GAMMA || dtp == DIST_EXP);
-        const double lnth = (dtp == DIST_LOGNORMAL) ? th[m] : log_pos(th[m]);
-        double s[3] = {0.0, 0.0, 0.0};
-        for (int v = 0; v < S.n_vel; ++v) {
-            const double qv = S.vel[v][1];
-            if (gam) {
-                // M_qv from the log-gamma ratio once, the higher orders by M_{q+1} = M_q theta (k + q)
-                double mom = nn[m] * (qv == 0.0 ? 1.0 : exp_fin(fma(qv, lnth, log_gamma_ratio(kk[m], qv))));
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    s[j] = fma(-S.vel[v][0], mom, s[j]);
-                    mom *= th[m] * (kk[m] + qv + double(j));
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const double q = double(j) + qv;  // log(M_q / n), ParticleDistributions.jl:193-207
-                    const double e = (dtp == DIST_MONO) ? q * lnth : fma(q, lnth, 0.5 * q * q * (kk[m] * kk[m]));
-                    s[j] = fma(-S.vel[v][0], nn[m] * exp(e), s[j]);
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 3; ++j) fl[m][j] = s[j];
-    }
-}
 
 template <int N, int P, typename TIO>
 __global__ void __launch_bounds__(kBlock)
