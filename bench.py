@@ -374,10 +374,9 @@ def _cpu_baseline(name, target_seconds=12.0):
         warm = np.ascontiguousarray(pool[:, :min(max(200 * c, 1000), n_c)])
         _time_oracle(O, p, warm, np.zeros_like(warm), c)   # spawns / resizes the OpenMP team outside the timed call
         probes[c] = n_c / _time_oracle(O, p, mom_c, out_c, c, reps=2)
-    # the team the baseline is quoted on: the fastest one that still runs at >= 50 % parallel efficiency (a pod throttled
-    # by a cgroup quota gets a few per cent more throughput from oversubscribing its CPUs 8x -- that is not a core count)
-    efficient = {c: v for c, v in probes.items() if v >= 0.5 * c * rate1}
-    best_c = max(efficient, key=efficient.get) if efficient else max(probes, key=probes.get)
+    # the team the baseline is quoted on: the one with the highest measured throughput (its parallel efficiency is
+    # reported beside it as metadata; an oversubscribed team that happens to win is still the fastest this host offers)
+    best_c = max(probes, key=probes.get)
     cap = 40_000_000
     try:
         import psutil

@@ -460,6 +460,7 @@ int build_host_plan(const cloudy_plan_desc *d, cloudy_plan **out, std::vector<do
         h.vel_n[v][1] = d->vel[v][1];
     }
     h.n_nodes = (int)(nodes.size() / kNodeStride);
+    h.jit_sorted_bs = jit_sorted_block_size_resolve(h);
     *out = p;
     return CLOUDY_OK;
 }

@@ -30,6 +30,7 @@ struct HostPlan {
     double inv_map[2] = {0.0, 0.0}, inv_klo = 0.0;
     double inv_tab[CLOUDY_MAX_MODES][16] = {{0}};
     int device = 0;
+    int jit_sorted_bs = 0;  // workgroup size of the plan-time compiled threshold kernels, fixed at plan creation (jit.hpp)
     int force_ppl1 = 0;  // CLOUDY_HIP_PPL1=1: always the one-parcel-per-lane ALLINF kernel (A/B timing)
     double *nodes_dev = nullptr;                        // [n_nodes][kNodeStride]
     int n_nodes = 0;

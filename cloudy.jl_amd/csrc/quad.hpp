@@ -83,6 +83,10 @@ __host__ __device__ __forceinline__ void gamma_rule(const QArgs &Q, const double
     const int nq = NQ ? NQ : Q.nq;
     const int deg = Q.deg;
     const double t = fma(k, Q.t_scale, -1.0);
+    // The start-value polynomials are a fit over k in (0, k_hi] (k_hi = max(k_range[1], 1), the range the closure
+    // inversion can produce).  Parameters handed in directly (cloudy_get_coal_ints) may lie outside: extrapolated start
+    // values converge to wrong nodes silently, so such a mode gets a NaN rule -- its tendencies are NaN, not wrong.
+    const bool k_ok = k > 0.0 && t <= 1.0;
     double Cnk = 1.0;  // Gamma(nq + k) / (Gamma(k) nq!) = prod_j (k + j) / (j + 1)
 #pragma unroll
     for (int j = 0; j < nq; ++j) Cnk *= (k + double(j)) * (1.0 / double(j + 1));
@@ -103,8 +107,8 @@ __host__ __device__ __forceinline__ void gamma_rule(const QArgs &Q, const double
         laguerre_pair<NQ>(nq, k, x, Ln, Lm);
         D = fma(double(nq), Ln, -(nk * Lm));
         const double rD = quad_recip(D);
-        W[a] = Cnk * x * (rD * rD);        // Gamma(n+k) / (Gamma(k) n! x L_n'(x)^2)
-        u[a] = fma(-x, Ln * rD, x);        // (the third Newton update comes free with the weight)
+        W[a] = k_ok ? Cnk * x * (rD * rD) : __builtin_nan("");  // Gamma(n+k) / (Gamma(k) n! x L_n'(x)^2)
+        u[a] = k_ok ? fma(-x, Ln * rD, x) : __builtin_nan("");  // (the third Newton update comes free with the weight)
         quad_sched_fence();
     }
 }

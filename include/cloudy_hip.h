@@ -138,7 +138,10 @@ typedef struct cloudy_plan_desc {
      * where the reference nests adaptive quadgk(rtol = 1e-8).  Exact for the constant and linear kernels; a
      * discretisation for the hydrodynamic and Long kernels (DESIGN.md states the measured error).  kernel_c, tensor_p,
      * dist_thresholds and threshold_style are ignored (the style has no thresholds: weighting_fn splits the self
-     * collisions, Coalescence.jl:624-642).  Monodisperse modes: CLOUDY_EINVAL (no normed_density_func method). */
+     * collisions, Coalescence.jl:624-642).  Monodisperse modes: CLOUDY_EINVAL (no normed_density_func method).
+     * Shape parameters: the per-parcel Gauss-Laguerre rules are staged for 0 < k <= max(k_range[1], 1), the range
+     * update_dist_from_moments can produce.  (n, theta, k) planes handed to cloudy_get_coal_ints with a Gamma k outside
+     * that range give NaN tendencies for the parcel (a batch cannot fail per parcel): widen k_range[1] instead. */
     int32_t coal_style;                      /* CLOUDY_ANALYTICAL_COAL (default) / CLOUDY_NUMERICAL_COAL */
     int32_t kernel_func;                     /* CLOUDY_KFUNC_* */
     int32_t kernel_func_is_normalized;       /* 0: library applies get_normalized_kernel_func(kernel, norms), :124-154 */

@@ -178,6 +178,31 @@ def test_ahead_of_time_kernels_params_input_and_float_planes(gpu_cloudy, oracle)
     assert np.all(np.abs(got32[ok] - want32[ok]) <= 1e-6 * scale32[ok] + 1e-37)
 
 
+def test_shape_parameter_outside_the_staged_rule_range_gives_nan_not_a_wrong_answer(gpu_cloudy):
+    """cloudy_get_coal_ints takes (n, theta, k) as given.  The per-parcel Gauss-Laguerre rules are staged for
+    0 < k <= max(k_range[1], 1) (include/cloudy_hip.h): a Gamma mode outside that range must yield NaN tendencies for
+    its parcel -- extrapolated start values would converge to wrong nodes silently -- and leave the others untouched;
+    with a wider k_range the same parcels are served."""
+    cloudy = gpu_cloudy
+    kf = cloudy.get_normalized_kernel_func(cloudy.HydrodynamicKernelFunction(1e2 * np.pi), NORMS)
+    n = 256
+    prm = np.zeros((6, n))
+    rng = np.random.default_rng(3)
+    prm[0], prm[1], prm[2] = 50.0, 0.3, rng.uniform(0.5, 9.5, n)
+    prm[3], prm[4], prm[5] = 2.0, 40.0, rng.uniform(1.0, 9.5, n)
+    bad1, bad2 = np.arange(n) % 7 == 3, np.arange(n) % 11 == 5
+    prm[2, bad1] = rng.uniform(10.5, 50.0, bad1.sum())      # above k_range[1] = 10
+    prm[5, bad2] = -1.0                                     # not a shape parameter at all
+    pd = cloudy.DeviceArray.from_numpy(prm)
+    got = cloudy.get_coal_ints(cloudy.NumericalCoalStyle(), ([1, 1], pd), kf).to_numpy()
+    bad = bad1 | bad2
+    assert np.all(np.isnan(got[:, bad]).any(axis=0)) and np.all(np.isfinite(got[:, ~bad]))
+    wide = cloudy.get_coal_ints(cloudy.NumericalCoalStyle(), ([1, 1], pd), kf, k_range=(2.3e-16, 50.0)).to_numpy()
+    assert np.all(np.isfinite(wide[:, ~bad2])) and np.all(np.isnan(wide[:, bad2]).any(axis=0))
+    ok = ~bad
+    assert np.allclose(wide[:, ok], got[:, ok], rtol=1e-9, atol=0.0)   # (two tables, same nodes after the Newton steps)
+
+
 def test_numerical_plan_status_codes(gpu_cloudy):
     cloudy = gpu_cloudy
     L, E = cloudy.lib(), cloudy._lib
