@@ -202,6 +202,44 @@ def _dist_setup(n_gpus):
     return rank, world, local_rank, dist, torch
 
 
+_COMM = {"comm": None, "collective": None}
+
+
+def _comm_setup(pkg, world, local_rank, dist, torch):
+    """The RCCL communicator behind the C ABI (cloudy_comm_create -> ncclCommInitRank inside libcloudy_hip.so) for the one
+    collective of the path, the all-reduce of the moment sums.  torch.distributed is only the courier of the 128-byte
+    unique id (and the barrier / max-over-ranks of the timing contract).  All ranks agree on the outcome: if any rank
+    fails to form the communicator (e.g. several ranks share ONE GPU on a test box: RCCL refuses duplicate devices),
+    every rank falls back to summing host-side partial sums through torch.distributed."""
+    if os.environ.get("CLOUDY_BENCH_NO_RCCL_ABI") == "1":
+        _COMM["collective"] = "torch.distributed (CLOUDY_BENCH_NO_RCCL_ABI=1)" if dist is not None else "none"
+        return
+    ok, why = 1, ""
+    try:
+        if dist is None:
+            _COMM["comm"] = pkg.Communicator(1, 0, pkg.Communicator.unique_id(), local_rank)
+        elif dist.get_backend() == "nccl":
+            _COMM["comm"] = pkg.Communicator.from_torch_distributed(local_rank)
+        else:
+            ok, why = 0, "ranks share a GPU (non-nccl control backend)"
+    except Exception as e:   # noqa: BLE001 -- any failure means the fallback, reported in the JSON line
+        ok, why = 0, f"{type(e).__name__}: {e}"
+    if dist is not None:
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and _COMM["comm"] is not None:
+            _COMM["comm"].close()
+            _COMM["comm"] = None
+            why = why or "another rank could not form the communicator"
+    if _COMM["comm"] is not None:
+        v = pkg.lib().cloudy_comm_rccl_version()
+        _COMM["collective"] = (f"ncclAllReduce(sum, f64, nmom) inside libcloudy_hip.so (cloudy_moment_sums_allreduce), "
+                               f"RCCL {v // 10000}.{v // 100 % 100}.{v % 100}, {world} rank(s)")
+    else:
+        _COMM["collective"] = (f"torch.distributed all_reduce of host-side sums ({dist.get_backend() if dist else 'n/a'}); "
+                               f"C-ABI RCCL communicator not formed: {why}")
+
+
 def _time_steps(pkg, plan, m, dm, steps, dist, torch):
     """EXACTLY `steps` launches between barrier+sync brackets; returns wall seconds (max over ranks)."""
     L = pkg.lib()
@@ -265,8 +303,11 @@ def _run_workload(pkg, name, n_parcels, steps, warmup, rank, dist, torch):
     wall = _time_steps(pkg, plan, m, dm, steps, dist, torch)
     ev_ms = _event_ms(pkg, plan, m, dm, steps)
     # conservation diagnostic: sum over parcels and modes of dM1 must vanish (mass is conserved)
-    sums = pkg.moment_sums(plan, dm)
-    gsums = pkg.allreduce_sums(sums) if dist is not None else sums
+    if _COMM["comm"] is not None:     # local plane sums + ncclAllReduce on the launch stream, inside the library
+        gsums = _COMM["comm"].allreduce_moment_sums(plan, dm)
+    else:
+        sums = pkg.moment_sums(plan, dm)
+        gsums = pkg.allreduce_sums(sums) if dist is not None else sums
     tot = pkg.mode_sums(gsums, wl["NProgMoms"])
     # mode 0 only loses mass (it collects nothing), so |sum_p dM1_mode0| is the gross mass-transfer rate.
     # (With ~1 % degenerate parcels in the batch, whose clamped closures give tendencies up to 1e30, the batch sum is
@@ -559,6 +600,7 @@ def main():
     if pkg.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the coalescence RHS has no CPU fallback")
     pkg._lib.check(pkg.lib().cloudy_set_device(local_rank))
+    _comm_setup(pkg, world, local_rank, dist, torch)
 
     spec = workload_spec(args.workload)
     n_local = args.parcels or spec["default_parcels"]
@@ -577,6 +619,9 @@ def main():
         traffic = measured.get("cfg3a_hbm_bytes_per_launch")  # 2 x FETCH_SIZE + WRITE_SIZE of the committed PMC passes
 
     variants = {}
+    # multi-rank runs (the driver's scaling sweep) time the headline and the threshold workload only; the other variants
+    # are single-GPU characterisations and run at N = 1
+    more_variants = not args.no_variants and args.workload == "cfg3a" and world == 1
     if not args.no_variants and args.workload == "cfg3a":
         v = _run_workload(pkg, "cfg3b", n_local, max(3, args.steps // 10), 1, rank, dist, torch)
         v_steps = max(3, args.steps // 10)
@@ -600,7 +645,7 @@ def main():
                 "note": "fp64 flops per launch from the committed SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 counters x active-lane "
                         "fraction (profiles/measured_latest.json); not HBM bound"}
 
-    if not args.no_variants and args.workload == "cfg3a":
+    if more_variants:
         # fused on-device SSPRK33 (cloudy_ssprk33_steps): 3 RHS evaluations per step, state in registers
         import ctypes as C
 
@@ -627,7 +672,7 @@ def main():
         if rl:
             variants["cfg3a_fused_ssprk33"]["roofline"] = rl
 
-    if not args.no_variants and args.workload == "cfg3a":
+    if more_variants:
         # the same launches with the ahead-of-time kernels (desc.specialize = -1): plan constants from kernel arguments,
         # dense tensors -- what every plan falls back to when hiprtc is unavailable
         wl = res["wl"]
@@ -645,7 +690,7 @@ def main():
         }
         del m_a, dm_a
 
-    if not args.no_variants and args.workload == "cfg3a":
+    if more_variants:
         # CLOUDY_F32 plan: float planes in HBM (48 B per evaluation), fp64 arithmetic in registers
         wl = res["wl"]
         plan32 = wl["coal_data"].plan(wl["dist_types"], dtype=1)
@@ -673,7 +718,7 @@ def main():
         }
         del m32, dm32
 
-    if not args.no_variants and args.workload == "cfg3a":
+    if more_variants:
         # the other BASELINE configurations, a few launches each
         for vname, vn in (("cfg2", 1_000_000), ("cfg4", 12_500_000), ("moving4", 2_500_000)):
             wlv = make_workload(vname, vn, seed=SEED + 1000 * rank)
@@ -697,7 +742,7 @@ def main():
                 variants[vname]["roofline"] = rl
             del mv, dmv
 
-    if not args.no_variants and args.workload == "cfg3a":
+    if more_variants:
         # BASELINE configs[4]: Long's kernel pieces (cfg3b thresholds) + sedimentation flux, float planes
         n5 = 12_500_000
         wl5 = make_workload("cfg3b", n5, seed=SEED + 1000 * rank)
@@ -772,15 +817,24 @@ def main():
         }
         del ur, outr
 
-    if not args.no_variants and args.workload == "cfg3a":
+    if more_variants:
         variants["cfg4q"] = _cfg4q_variant(pkg, rank, world, measured)
 
     t_variants = time.perf_counter()
+    # every collective is behind us: ranks > 0 leave now, rank 0 times the CPU baseline on the host cores alone (once, after
+    # the timed region, for any N -- a multi-GPU line carries its baseline too) and prints the line
+    if _COMM["comm"] is not None:
+        _COMM["comm"].close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
         cpu = _cpu_baseline(args.workload)
-        if variants:
+        if "cfg3b" in variants:
             variants["cfg3b"]["cpu_baseline"] = _cpu_baseline("cfg3b", target_seconds=10.0)
+        if "cfg4q" in variants:
             variants["cfg4q"]["cpu_baseline"] = _cpu_baseline_cfg4q(cpu["cores"], target_seconds=6.0)
 
     if rank == 0:
@@ -804,6 +858,7 @@ def main():
             "roofline": _headline_roofline(args.workload, res["plan"], n_local, nmom, res["event_ms"], per_rank_ms,
                                            traffic, measured),
             "cpu_baseline": cpu,
+            "collective": _COMM["collective"],
             "mass_rate_residual": abs(res["mass_rate_sum"]) / max(res["mass_rate_gross"], 1e-300),
             "mass_residual_per_parcel_max": res["mass_per_parcel"],
             "variants": variants,
@@ -814,8 +869,6 @@ def main():
                                "variants": t_variants - t_headline, "cpu_baseline": time.perf_counter() - t_variants},
         }
         print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

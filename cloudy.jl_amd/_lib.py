@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CLOUDY_HIP_LIB") or os.path.join(_HERE, "libcloudy_hip.so")
 
 MAX_MODES, MAX_P, MAX_VEL = 4, 5, 4
-OK, EINVAL, ENOTSYMMETRIC, EHIP, ENOMEM, EUNSUPPORTED, ENODEVICE = 0, -1, -2, -3, -4, -5, -6
+OK, EINVAL, ENOTSYMMETRIC, EHIP, ENOMEM, EUNSUPPORTED, ENODEVICE, ECOMM = 0, -1, -2, -3, -4, -5, -6, -7
+COMM_ID_BYTES = 128
 
 
 class CloudyError(RuntimeError):
@@ -60,6 +61,7 @@ SYMBOLS = {
     "cloudy_plan_desc_layout": (_i, [C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _i]),
     "cloudy_quad_rule_host": (_i, [_i, C.c_double, C.c_double, _dp, _dp]),
     "cloudy_plan_nmom": (_i, [_vp]),
+    "cloudy_plan_device": (_i, [_vp]),
     "cloudy_plan_nparams": (_i, [_vp]),
     "cloudy_plan_get": (_i, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _dp, _dp, _dp]),
     "cloudy_coal_rhs": (_i, [_vp, _sz, _sz, _vp, _vp, _vp]),
@@ -78,6 +80,18 @@ SYMBOLS = {
     "cloudy_moment_sums": (_i, [_vp, _sz, _sz, _i, _vp, _vp, _vp]),
     "cloudy_moment_sums_workspace_bytes": (_sz, [_i]),
     "cloudy_moment_sums_ws": (_i, [_vp, _sz, _sz, _i, _vp, _vp, _vp, _sz, _vp]),
+    "cloudy_comm_rccl_version": (_i, []),
+    "cloudy_comm_unique_id": (_i, [_vp]),
+    "cloudy_comm_create": (_i, [_i, _i, _vp, _i, C.POINTER(_vp)]),
+    "cloudy_comm_create_all": (_i, [_i, C.POINTER(C.c_int), C.POINTER(_vp)]),
+    "cloudy_comm_destroy": (None, [_vp]),
+    "cloudy_comm_rank": (_i, [_vp]),
+    "cloudy_comm_world_size": (_i, [_vp]),
+    "cloudy_comm_device": (_i, [_vp]),
+    "cloudy_comm_group_start": (_i, []),
+    "cloudy_comm_group_end": (_i, []),
+    "cloudy_allreduce_sum_f64": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "cloudy_moment_sums_allreduce": (_i, [_vp, _vp, _sz, _sz, _i, _vp, _vp, _vp]),
     "cloudy_device_count": (_i, []),
     "cloudy_set_device": (_i, [_i]),
     "cloudy_malloc": (_i, [C.POINTER(_vp), _sz]),

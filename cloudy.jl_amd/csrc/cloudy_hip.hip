@@ -211,6 +211,9 @@ int run(const cloudy_plan *plan, const LaunchReq &r) {
 
 extern "C" {
 
+// (internal: cloudy_comm.hip reports its failures through the same thread-local message)
+void cloudy_set_last_error_(const char *msg) { std::snprintf(g_err, sizeof(g_err), "%s", msg ? msg : ""); }
+
 const char *cloudy_last_error(void) { return g_err; }
 int cloudy_version(void) { return CLOUDY_HIP_VERSION; }
 
@@ -632,6 +635,7 @@ int cloudy_quad_rule_host(int quad_order, double k_hi, double k, double *u, doub
 }
 
 int cloudy_plan_nmom(const cloudy_plan *plan) { return plan ? plan->h.nmom : fail(CLOUDY_EINVAL, "plan is NULL"); }
+int cloudy_plan_device(const cloudy_plan *plan) { return plan ? plan->h.device : fail(CLOUDY_EINVAL, "plan is NULL"); }
 int cloudy_plan_nparams(const cloudy_plan *plan) { return plan ? 3 * plan->h.N : fail(CLOUDY_EINVAL, "plan is NULL"); }
 
 int cloudy_plan_get(const cloudy_plan *plan, int32_t *N_mom_max, int32_t *N_2d_ints, double *thresholds,

@@ -1,6 +1,7 @@
 """Multi-GPU: parcels are independent, so ranks own contiguous parcel ranges and exchange nothing per RHS.
 The only collective is the all-reduce of the nmom moment sums of the conservation diagnostic
-(reference analogue: moments_sum, test/examples/utils/plotting_helpers.jl:240-252)."""
+(reference analogue: moments_sum, test/examples/utils/plotting_helpers.jl:240-252): ncclAllReduce inside
+libcloudy_hip.so (cloudy_moment_sums_allreduce), reached here through `Communicator`."""
 import ctypes as C
 
 import numpy as np
@@ -27,8 +28,57 @@ def moment_sums(plan, arr, stream=None):
     return out.to_numpy().reshape(-1)
 
 
+class Communicator:
+    """An RCCL communicator behind the C ABI (cloudy_comm_create: ncclCommInitRank on this rank's GPU).  The library
+    does no rendezvous: `unique_id()` (rank 0) yields the 128 bytes every rank must pass to the constructor --
+    `from_torch_distributed` moves them over an already initialised process group of ANY backend (gloo is enough: the
+    group is only the courier, the collective itself is RCCL inside libcloudy_hip.so)."""
+
+    def __init__(self, world_size, rank, uid, device=-1):
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(uid), _lib.COMM_ID_BYTES)
+        _lib.check(_lib.lib().cloudy_comm_create(int(world_size), int(rank), buf, int(device), C.byref(h)))
+        self.handle, self.world_size, self.rank = h, int(world_size), int(rank)
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        _lib.check(_lib.lib().cloudy_comm_unique_id(buf))
+        return bytes(buf.raw)
+
+    @classmethod
+    def from_torch_distributed(cls, device=-1, group=None):
+        import torch.distributed as dist
+
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=group)
+        return cls(world, rank, box[0], device)
+
+    def allreduce_moment_sums(self, plan, arr, stream=None):
+        """cloudy_moment_sums_allreduce: plane sums of this rank's (planes, n) device array summed over all ranks."""
+        ptr, planes, n, ld = as_device(arr)
+        out = DeviceArray(planes, 1)
+        _lib.check(_lib.lib().cloudy_moment_sums_allreduce(plan.handle, self.handle, n, ld, planes, ptr, out.ptr, stream))
+        _lib.check(_lib.lib().cloudy_stream_synchronize(stream))
+        return out.to_numpy().reshape(-1)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.lib().cloudy_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def allreduce_sums(local_sums, group=None):
-    """Sum the per-rank moment sums over all ranks with torch.distributed (RCCL on GPUs, gloo on CPU tests)."""
+    """Sum per-rank moment sums that are already on the HOST over a torch.distributed group (CPU tests over gloo, and the
+    fallback of bench.py when no RCCL communicator could be formed).  The device path is
+    Communicator.allreduce_moment_sums (RCCL behind the C ABI, no torch tensor involved)."""
     import torch
     import torch.distributed as dist
 

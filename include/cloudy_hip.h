@@ -36,6 +36,8 @@
  *   cloudy_ssprk33_steps          <- solve(ODEProblem(rhs, m0, tspan, p), SSPRK33(), dt = p.dt) of the drivers,
  *                                    test/examples/Analytical/box_single_gamma.jl:35-36 (OrdinaryDiffEq stepping)
  *   cloudy_moment_sums            <- moments_sum diagnostic, test/examples/utils/plotting_helpers.jl:240-252
+ *   cloudy_moment_sums_allreduce  <- the same summed over the ranks / GPUs that share a batch (RCCL; the reference is
+ *                                    single-process, its global sum is the local one)
  *
  * Data layout (all batched calls): moment-major structure-of-arrays, element (q, parcel) at
  * base[q * ld + parcel], ld >= n_parcels -- exactly Julia's column-major m[parcel, moment]
@@ -98,7 +100,8 @@ enum {
     CLOUDY_EHIP = -3,         /* HIP runtime error (message has hipGetErrorString) */
     CLOUDY_ENOMEM = -4,
     CLOUDY_EUNSUPPORTED = -5, /* valid in the reference, outside this build */
-    CLOUDY_ENODEVICE = -6
+    CLOUDY_ENODEVICE = -6,
+    CLOUDY_ECOMM = -7         /* RCCL error (message has ncclGetErrorString) */
 };
 
 typedef struct cloudy_plan cloudy_plan;
@@ -175,6 +178,7 @@ int cloudy_plan_desc_layout(const char **names, uint32_t *offsets, uint32_t *siz
  * and hosts (no device involved, nothing batched: this is not a compute path). */
 int cloudy_quad_rule_host(int quad_order, double k_hi, double k, double *u, double *W);
 int cloudy_plan_nmom(const cloudy_plan *plan);      /* sum(NProgMoms) */
+int cloudy_plan_device(const cloudy_plan *plan);    /* HIP device ordinal the plan lives on */
 int cloudy_plan_nparams(const cloudy_plan *plan);   /* 3 * N planes of (n, theta, k) */
 /* copies of the derived CoalescenceData fields (Coalescence.jl:69-84), for tests and hosts */
 int cloudy_plan_get(const cloudy_plan *plan, int32_t *N_mom_max, int32_t *N_2d_ints /*[N]*/,
@@ -260,6 +264,38 @@ int cloudy_moment_sums(const cloudy_plan *plan, size_t n_parcels, size_t ld, int
 size_t cloudy_moment_sums_workspace_bytes(int planes);
 int cloudy_moment_sums_ws(const cloudy_plan *plan, size_t n_parcels, size_t ld, int planes, const void *arr_dev,
                           double *sums_dev, void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* ---- multi-GPU: the one collective of the path ----------------------------------------------------------
+ * Parcels are independent: ranks (one process per GPU, or one process driving several GPUs) own contiguous parcel ranges
+ * and exchange nothing per right-hand side.  The only exchange is the sum over ranks of the nmom plane sums of the
+ * conservation diagnostic (moments_sum, plotting_helpers.jl:240-252): ncclAllReduce(sum, ncclDouble, planes values) over
+ * RCCL / xGMI, issued on the caller's stream.  RCCL is bound at first use (dlopen librccl.so.1): hosts that never create a
+ * communicator do not load it.  CLOUDY_EUNSUPPORTED if RCCL is absent, CLOUDY_ECOMM on an RCCL error.
+ *
+ * One process per GPU: rank 0 calls cloudy_comm_unique_id, the host hands the 128 bytes to every rank (MPI.bcast, a
+ * file, a socket -- the library does no rendezvous of its own), every rank calls cloudy_comm_create (collective).
+ * One process, several GPUs: cloudy_comm_create_all, and bracket the per-GPU cloudy_moment_sums_allreduce calls with
+ * cloudy_comm_group_start / _end as RCCL requires for one thread driving several communicators. */
+#define CLOUDY_COMM_ID_BYTES 128
+typedef struct cloudy_comm cloudy_comm;
+int cloudy_comm_rccl_version(void);                 /* NCCL_VERSION_CODE of the RCCL bound, 0 if none */
+int cloudy_comm_unique_id(void *id_out /*[CLOUDY_COMM_ID_BYTES]*/);
+/* device: HIP ordinal the communicator binds to, -1 = current */
+int cloudy_comm_create(int world_size, int rank, const void *id /*[CLOUDY_COMM_ID_BYTES]*/, int device, cloudy_comm **out);
+/* devices: n_devices ordinals, NULL = 0 .. n_devices-1; comms_out[i] has rank i */
+int cloudy_comm_create_all(int n_devices, const int *devices, cloudy_comm **comms_out /*[n_devices]*/);
+void cloudy_comm_destroy(cloudy_comm *comm);
+int cloudy_comm_rank(const cloudy_comm *comm);
+int cloudy_comm_world_size(const cloudy_comm *comm);
+int cloudy_comm_device(const cloudy_comm *comm);
+int cloudy_comm_group_start(void);
+int cloudy_comm_group_end(void);
+/* recv_dev[i] = sum over ranks of send_dev[i], i < count; in place allowed; asynchronous on `stream` */
+int cloudy_allreduce_sum_f64(cloudy_comm *comm, const double *send_dev, double *recv_dev, size_t count, void *stream);
+/* cloudy_moment_sums of this rank's parcels followed by the all-reduce, in place in sums_dev, both on `stream`:
+ * sums_dev[q] = sum over ALL ranks' parcels of plane q.  With world_size 1 the result is cloudy_moment_sums' bit for bit. */
+int cloudy_moment_sums_allreduce(const cloudy_plan *plan, cloudy_comm *comm, size_t n_parcels, size_t ld, int planes,
+                                 const void *arr_dev, double *sums_dev, void *stream);
 
 /* thin device-memory helpers so that a host without a HIP binding can keep state device-resident */
 int cloudy_device_count(void);

@@ -92,3 +92,80 @@ def test_bench_gpus_2_spawns_two_ranks(gpu_cloudy):
     assert [r["rank"] for r in out["roofline"]["per_rank"]] == [0, 1]
     assert all(r["kernel_ms"] > 0 for r in out["roofline"]["per_rank"])
     assert out["mass_rate_residual"] is not None and out["value"] > 0
+
+
+def test_comm_entry_points_without_a_gpu(cloudy):
+    """The RCCL-backed entry points validate their arguments and report status codes without a device (no compute, no
+    communicator is formed on the CPU box); with a GPU this test only checks the argument errors."""
+    import ctypes as C
+
+    L, E = cloudy.lib(), cloudy._lib
+    h = C.c_void_p()
+    buf = C.create_string_buffer(E.COMM_ID_BYTES)
+    assert L.cloudy_comm_create(2, 5, buf, -1, C.byref(h)) == E.EINVAL and b"rank" in L.cloudy_last_error()
+    assert L.cloudy_comm_create(1, 0, None, -1, C.byref(h)) == E.EINVAL
+    assert L.cloudy_comm_unique_id(None) == E.EINVAL
+    assert L.cloudy_allreduce_sum_f64(None, None, None, 3, None) == E.EINVAL
+    assert L.cloudy_moment_sums_allreduce(None, None, 0, 0, 1, None, None, None) == E.EINVAL
+    if cloudy.device_count() == 0:
+        assert L.cloudy_comm_unique_id(buf) == E.ENODEVICE
+        assert L.cloudy_comm_create(1, 0, buf, -1, C.byref(h)) == E.ENODEVICE and not h.value
+        assert L.cloudy_comm_create_all(1, None, C.byref(h)) == E.ENODEVICE
+    L.cloudy_comm_destroy(None)   # a no-op
+
+
+@pytest.mark.gpu
+def test_rccl_communicator_behind_the_c_abi_one_rank(gpu_cloudy):
+    """cloudy_comm_create forms a REAL RCCL communicator (ncclCommInitRank, 1 rank) on the test GPU from inside
+    libcloudy_hip.so; cloudy_moment_sums_allreduce = local plane sums + ncclAllReduce(sum, f64) on the caller's stream
+    must reproduce cloudy_moment_sums bit for bit (the sum over one rank is the rank's own sum)."""
+    import ctypes as C
+
+    import bench
+
+    cloudy = gpu_cloudy
+    L = cloudy.lib()
+    assert L.cloudy_comm_rccl_version() >= 20000
+    wl = bench.make_workload("cfg3a", 300_001, seed=9)
+    plan = wl["coal_data"].plan(wl["dist_types"])
+    m = cloudy.DeviceArray.from_numpy(wl["mom"])
+    dm = cloudy.DeviceArray.zeros(*wl["mom"].shape)
+    cloudy.make_box_model_rhs(cloudy.AnalyticalCoalStyle())(dm, m, wl["par"], 0.0)
+    local = cloudy.moment_sums(plan, dm)
+    comm = cloudy.Communicator(1, 0, cloudy.Communicator.unique_id())
+    assert L.cloudy_comm_rank(comm.handle) == 0 and L.cloudy_comm_world_size(comm.handle) == 1
+    assert L.cloudy_comm_device(comm.handle) == L.cloudy_plan_device(plan.handle)
+    glob = comm.allreduce_moment_sums(plan, dm)
+    assert np.array_equal(glob, local) and np.all(np.isfinite(glob) | np.isnan(local))
+    # out of place, explicit stream-ordered use: recv = sum over ranks of send
+    send = cloudy.DeviceArray.from_numpy(np.arange(1.0, 7.0).reshape(6, 1))
+    recv = cloudy.DeviceArray.zeros(6, 1)
+    cloudy._lib.check(L.cloudy_allreduce_sum_f64(comm.handle, send.ptr, recv.ptr, 6, None))
+    cloudy._lib.check(L.cloudy_stream_synchronize(None))
+    assert np.array_equal(recv.to_numpy().ravel(), np.arange(1.0, 7.0))
+    comm.close()
+    # the single-process form (ncclCommInitAll over the visible GPUs; one here) with the group bracket
+    hs = (C.c_void_p * 1)()
+    cloudy._lib.check(L.cloudy_comm_create_all(1, None, hs))
+    out = cloudy.DeviceArray.zeros(6, 1)
+    cloudy._lib.check(L.cloudy_comm_group_start())
+    cloudy._lib.check(L.cloudy_moment_sums_allreduce(plan.handle, hs[0], 300_001, 300_001, 6, dm.ptr, out.ptr, None))
+    cloudy._lib.check(L.cloudy_comm_group_end())
+    cloudy._lib.check(L.cloudy_stream_synchronize(None))
+    assert np.array_equal(out.to_numpy().ravel(), local)
+    L.cloudy_comm_destroy(hs[0])
+
+
+@pytest.mark.gpu
+def test_bench_single_rank_line_uses_the_c_abi_collective(gpu_cloudy):
+    """`python bench.py` (N = 1) forms the 1-rank RCCL communicator through the C ABI and says so in its JSON line"""
+    import json
+
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--parcels", "400000", "--steps", "5", "--warmup", "2",
+                        "--no-variants", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert "ncclAllReduce" in out["collective"] and "libcloudy_hip.so" in out["collective"], out["collective"]
+    assert out["mass_rate_residual"] is not None
