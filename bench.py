@@ -593,6 +593,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: launch one rank per GPU")
 
     t_start = time.perf_counter()
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner to the C-level stdout when a communicator is
+    # formed (ours, or torch's nccl backend): keep a private handle on the real stdout for the line and point fd 1 at
+    # stderr for everything else this process and its libraries print.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank, world, local_rank, dist, torch = _dist_setup(args.gpus)
     import __graft_entry__ as ge
 
@@ -868,7 +874,8 @@ def main():
             "process_wall_s": {"setup_and_headline": t_headline - t_start, "timed_region": res["wall"],
                                "variants": t_variants - t_headline, "cpu_baseline": time.perf_counter() - t_variants},
         }
-        print(json.dumps(out))
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
 
 
 if __name__ == "__main__":

@@ -46,6 +46,8 @@ class PlanDesc(C.Structure):
         ("kernel_func_is_normalized", C.c_int32),
         ("quad_order", C.c_int32),
         ("kernel_func_params", C.c_double * 3),
+        ("thresholds_are_normalized", C.c_int32),
+        ("quad_mode", C.c_int32),
     ]
 
 

@@ -254,6 +254,10 @@ int build_host_plan(const cloudy_plan_desc *d, cloudy_plan **out, std::vector<do
     if (numerical) {
         if (d->kernel_func < CLOUDY_KFUNC_CONSTANT || d->kernel_func > CLOUDY_KFUNC_LONG)
             return fail(CLOUDY_EINVAL, "kernel_func %d is not a CoalescenceKernelFunction family", d->kernel_func);
+        if (d->quad_mode != CLOUDY_QUAD_FIXED && d->quad_mode != CLOUDY_QUAD_CONVERGED)
+            return fail(CLOUDY_EINVAL, "quad_mode %d is neither CLOUDY_QUAD_FIXED nor CLOUDY_QUAD_CONVERGED", d->quad_mode);
+        if (d->quad_mode == CLOUDY_QUAD_CONVERGED)
+            return fail(CLOUDY_EUNSUPPORTED, "CLOUDY_QUAD_CONVERGED is not built yet");
         if (d->quad_order < 2 || d->quad_order > CLOUDY_MAX_QUAD)
             return fail(CLOUDY_EUNSUPPORTED, "quad_order %d outside 2..%d", d->quad_order, CLOUDY_MAX_QUAD);
         if (d->dtype == CLOUDY_F32_FAST)
@@ -373,8 +377,9 @@ int build_host_plan(const cloudy_plan_desc *d, cloudy_plan **out, std::vector<do
     for (int i = 0; i < N; ++i) {
         const int nxt = (i < N - 1) ? (h.np[i] > h.np[i + 1] ? h.np[i] : h.np[i + 1]) : h.np[i];
         h.n_2d[i] = (P - 1) + nxt;
-        h.thr[i] = d->threshold_style == CLOUDY_FIXED_THRESHOLD ? d->dist_thresholds[i] / d->norms[1]
-                                                                 : d->dist_thresholds[i];
+        h.thr[i] = (d->threshold_style == CLOUDY_FIXED_THRESHOLD && !d->thresholds_are_normalized)
+                       ? d->dist_thresholds[i] / d->norms[1]
+                       : d->dist_thresholds[i];
         if (std::isnan(h.thr[i])) {
             delete p;
             return fail(CLOUDY_EINVAL, "dist_thresholds[%d] is NaN", i);
@@ -602,7 +607,8 @@ int cloudy_plan_desc_layout(const char **names, uint32_t *offsets, uint32_t *siz
         CLOUDY_FIELD(dist_thresholds), CLOUDY_FIELD(threshold_style), CLOUDY_FIELD(norms), CLOUDY_FIELD(k_range),
         CLOUDY_FIELD(n_bins_per_log_unit), CLOUDY_FIELD(dtype), CLOUDY_FIELD(n_vel), CLOUDY_FIELD(vel),
         CLOUDY_FIELD(device), CLOUDY_FIELD(specialize), CLOUDY_FIELD(coal_style), CLOUDY_FIELD(kernel_func),
-        CLOUDY_FIELD(kernel_func_is_normalized), CLOUDY_FIELD(quad_order), CLOUDY_FIELD(kernel_func_params)};
+        CLOUDY_FIELD(kernel_func_is_normalized), CLOUDY_FIELD(quad_order), CLOUDY_FIELD(kernel_func_params),
+        CLOUDY_FIELD(thresholds_are_normalized), CLOUDY_FIELD(quad_mode)};
 #undef CLOUDY_FIELD
     const int nf = (int)(sizeof(fields) / sizeof(fields[0]));
     for (int i = 0; i < nf && i < cap; ++i) {

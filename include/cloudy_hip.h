@@ -89,6 +89,11 @@ enum { CLOUDY_ANALYTICAL_COAL = 0, CLOUDY_NUMERICAL_COAL = 1 };
  * (coll_coal_rate) | (coll_coal_rate) | (coal_eff) | (x_threshold, coal_rate_below_threshold, coal_rate_above_threshold) */
 enum { CLOUDY_KFUNC_CONSTANT = 0, CLOUDY_KFUNC_LINEAR = 1, CLOUDY_KFUNC_HYDRODYNAMIC = 2, CLOUDY_KFUNC_LONG = 3 };
 #define CLOUDY_MAX_QUAD 32  /* points of the fixed Gauss rule per distribution */
+/* cloudy_plan_desc.quad_mode: how a NumericalCoalStyle plan evaluates the integrals of Coalescence.jl:503-708.
+ * FIXED: one quad_order-point Gauss rule per distribution (BASELINE configs[3] as worded: "10-pt Gauss quadrature").
+ * CONVERGED: the integrals split along the non-smooth sets of the kernel function, converged to the reference's
+ * quadgk(rtol = 1e-8) answer (DESIGN.md 3.6 states the measured error and cost). */
+enum { CLOUDY_QUAD_FIXED = 0, CLOUDY_QUAD_CONVERGED = 1 };
 /* layout of cloudy_plan_desc.kernel_c */
 enum { CLOUDY_KERNEL_SINGLE = 0 /* [P][P] shared by all pairs, Coalescence.jl:89-104 */,
        CLOUDY_KERNEL_MATRIX = 1 /* [N][N][P][P], Coalescence.jl:55-87 */ };
@@ -150,6 +155,11 @@ typedef struct cloudy_plan_desc {
     int32_t kernel_func_is_normalized;       /* 0: library applies get_normalized_kernel_func(kernel, norms), :124-154 */
     int32_t quad_order;                      /* points per distribution, 2..CLOUDY_MAX_QUAD; default 10 */
     double kernel_func_params[3];            /* physical units unless kernel_func_is_normalized */
+    int32_t thresholds_are_normalized;       /* FixedThreshold only: 1 = dist_thresholds are already divided by norms[1],
+                                                i.e. the CoalescenceData.dist_thresholds FIELD (Coalescence.jl:78-84) rather
+                                                than the constructor argument -- a host that builds the plan from an
+                                                existing CoalescenceData passes its fields through unchanged */
+    int32_t quad_mode;                       /* NumericalCoalStyle: CLOUDY_QUAD_FIXED (default) / CLOUDY_QUAD_CONVERGED */
 } cloudy_plan_desc;
 
 /* fills defaults: k_range = (eps, 10), n_bins_per_log_unit = 15, norms = (1, 1), thresholds = +Inf,
