@@ -398,13 +398,8 @@ int build_host_plan(const cloudy_plan_desc *d, cloudy_plan **out, std::vector<do
                 delete p;
                 return fail(CLOUDY_EINVAL, "dist_thresholds[%d] must be positive or +Inf", i);
             }
-            if (h.dist_type[i] == CLOUDY_DIST_LOGNORMAL) {
-                delete p;
-                return fail(CLOUDY_EUNSUPPORTED,
-                            "finite threshold on a Lognormal mode: the reference integrates it with adaptive quadgk "
-                            "(ParticleDistributions.jl:614-625), which is not built for the GPU");
-            }
-            if (h.dist_type[i] == CLOUDY_DIST_MONODISPERSE) {  // analytic, no Simpson grid (:557-564)
+            if (h.dist_type[i] == CLOUDY_DIST_MONODISPERSE ||  // analytic, no Simpson grid (:557-564)
+                h.dist_type[i] == CLOUDY_DIST_LOGNORMAL) {      // :614-625 by msh_lognormal's own rule (kernels.hpp)
                 h.finite[i] = 1;
                 any_finite = true;
                 continue;
@@ -751,10 +746,6 @@ int cloudy_standard_N_q(const cloudy_plan *plan, size_t n, size_t ld, const void
     int rc = check_batch(plan, n, ld, mom_dev, nq_dev);
     if (rc) return rc;
     if (!(size_cutoff > 0)) return fail(CLOUDY_EINVAL, "size_cutoff must be positive");
-    for (int i = 0; i < plan->h.N; ++i)
-        if (plan->h.dist_type[i] == CLOUDY_DIST_LOGNORMAL)
-            return fail(CLOUDY_EUNSUPPORTED, "partial moments of a Lognormal mode use adaptive quadgk "
-                                             "(ParticleDistributions.jl:261-269): not built for the GPU");
     LaunchReq r{OP_NQ, IN_MOMENTS, 1, 0, n, ld, mom_dev, nq_dev, nullptr, (hipStream_t)stream};
     r.s_scalar = size_cutoff;
     return run(plan, r);

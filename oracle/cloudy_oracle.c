@@ -280,7 +280,14 @@ double co_moment(const co_dist *d, double q) {
     }
 }
 
-/* partial_moment_func / partial_moment, ParticleDistributions.jl:226-285 (Lognormal uses quadgk: NaN here) */
+/* standard normal distribution function */
+static double co_norm_cdf(double z) { return 0.5 * erfc(-z * 0.70710678118654752440); }
+
+/* partial_moment_func / partial_moment, ParticleDistributions.jl:226-285.  Lognormal (:255-269): the reference
+ * integrates x^q n f(x) over (0, x_threshold) with quadgk; the integral has the closed form
+ *   n exp(q mu + q^2 sigma^2 / 2) Phi((ln x_t - mu - q sigma^2) / sigma)
+ * (x^q f(x) is a lognormal density of parameters (mu + q sigma^2, sigma) times the q-th moment), restated here;
+ * tests/golden/lognormal_adaptive.json pins it against adaptive quadrature of the reference integrand. */
 double co_partial_moment(const co_dist *d, double q, double x_threshold) {
     switch (d->type) {
     case CO_EXPONENTIAL:
@@ -289,6 +296,10 @@ double co_partial_moment(const co_dist *d, double q, double x_threshold) {
         return d->n * pow(d->theta, q) * co_gamma_inc_p(q + d->k, x_threshold / d->theta) * co_gamma(q + d->k) /
                co_gamma(d->k);
     case CO_MONODISPERSE: return (x_threshold < d->theta) ? 0.0 : d->n * pow(d->theta, q);
+    case CO_LOGNORMAL: { /* theta = mu, k = sigma */
+        const double mu = d->theta, sg = d->k;
+        return d->n * exp(q * mu + 0.5 * q * q * sg * sg) * co_norm_cdf((log(x_threshold) - mu - q * sg * sg) / sg);
+    }
     default: return NAN;
     }
 }
@@ -440,12 +451,50 @@ static double co_msh_y(int j, void *vctx) {
     return exp(lx) * f;
 }
 
+/* moment_source_helper(::Lognormal...), ParticleDistributions.jl:614-625:
+ *   int_0^xt y^p2 n f(y) [ int_0^(xt-y) x^p1 n f(x) dx ] dy      (nested adaptive quadgk in the reference).
+ * SAME-RULE restatement of what the HIP kernels evaluate (kernels.hpp, msh_lognormal): the inner integral is the closed
+ * form of co_partial_moment; the outer one is a CO_LN_NODES-point midpoint rule in v, y = xt / (1 + e^-v) -- in v the
+ * integrand is analytic and decays like a Gaussian on both sides (ln y ~ v for v << 0, ln(xt - y) ~ -v for v >> 0), so
+ * the equispaced rule converges geometrically; the range covers 8.5 sigma of the density on the left and the decay of
+ * the inner Phi (or the end of the density, whichever comes first) on the right.  With p the size-biased laws,
+ *   result = M_p1 M_p2 sum_nodes h G_p2(ln y) (1 - y/xt) Phi((ln(xt - y) - mu - p1 sigma^2) / sigma),
+ *   G_q(l) = exp(-(l - mu - q sigma^2)^2 / (2 sigma^2)) / (sigma sqrt(2 pi)).
+ * Error against adaptive quadrature of the reference integrand: <= 1e-12 M_p1 M_p2 (tests/test_oracle_kats.py,
+ * tests/golden/lognormal_adaptive.json); the reference's own KATs (test_ParticleDistributions_correctness.jl:215-218)
+ * are reproduced to their 4 digits. */
+#define CO_LN_NODES 48
+#define CO_LN_MAXORDER 7 /* M = P + 2 <= 7 orders share one range, as the kernel's single pass over the nodes does */
+static double co_softplus(double x) { return x > 0.0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
+void co_lognormal_msh_range(double mu, double sg, double lxt, int n_orders, double *vlo, double *vhi) {
+    *vlo = fmin(0.0, mu - lxt) - 8.5 * sg;
+    *vhi = fmax(0.0, lxt - mu) + 8.5 * sg;
+    const double d = (mu + (n_orders - 1) * sg * sg + 8.5 * sg) - lxt; /* upper end of the density of the top order */
+    if (d < -1e-9) *vhi = fmin(*vhi, d - log(-expm1(d)));
+}
+double co_moment_source_helper_lognormal(const co_dist *dist, double p1, double p2, double x_threshold, int n_orders) {
+    const double mu = dist->theta, sg = dist->k, lxt = log(x_threshold);
+    double vlo, vhi;
+    co_lognormal_msh_range(mu, sg, lxt, n_orders, &vlo, &vhi);
+    const double h = (vhi - vlo) / CO_LN_NODES;
+    double sum = 0.0;
+    for (int j = 0; j < CO_LN_NODES; ++j) {
+        const double v = vlo + h * (j + 0.5);
+        const double ly = lxt - co_softplus(-v), lz = lxt - co_softplus(v); /* ln y, ln(xt - y) */
+        const double u = (ly - mu - p2 * sg * sg) / sg;
+        const double G = exp(-0.5 * u * u) / (sg * 2.5066282746310002);
+        sum += G * exp(lz - lxt) * co_norm_cdf((lz - mu) / sg - p1 * sg);
+    }
+    return co_moment(dist, p1) * co_moment(dist, p2) * (h * sum);
+}
+
 /* moment_source_helper: Monodisperse ParticleDistributions.jl:557-564, Exponential :567-587,
- * Gamma :589-612.  (Lognormal :614-625 uses adaptive quadgk and is out of scope -> NaN.) */
+ * Gamma :589-612, Lognormal :614-625 (same-rule restatement above). */
 double co_moment_source_helper(const co_dist *d, double p1, double p2, double x_threshold,
                                int n_bins_per_log_unit) {
     if (d->type == CO_MONODISPERSE)
         return (d->theta < x_threshold / 2.0) ? (d->n * d->n) * pow(d->theta, p1 + p2) : 0.0;
+    if (d->type == CO_LOGNORMAL) return co_moment_source_helper_lognormal(d, p1, p2, x_threshold, CO_LN_MAXORDER);
     if (d->type != CO_EXPONENTIAL && d->type != CO_GAMMA) return NAN;
     co_msh_ctx c;
     c.type = d->type;
@@ -544,8 +593,12 @@ void co_get_finite_2d_integrals(const co_dist *pdists, int N, int M, const doubl
                 else if (i == N - 1 || isinf(thresholds[i]))
                     v = mom_times_mom;
                 else {
-                    double h = co_moment_source_helper(&pdists[i], (double)(j - 1), (double)(k - 1),
-                                                       thresholds[i], 15);
+                    /* (Lognormal: the kernel's single pass serves all M orders of the mode with one node range) */
+                    double h = pdists[i].type == CO_LOGNORMAL
+                                   ? co_moment_source_helper_lognormal(&pdists[i], (double)(j - 1), (double)(k - 1),
+                                                                       thresholds[i], M)
+                                   : co_moment_source_helper(&pdists[i], (double)(j - 1), (double)(k - 1),
+                                                             thresholds[i], 15);
                     v = (h < mom_times_mom) ? h : mom_times_mom; /* min(mom_times_mom, h) */
                     if (isnan(h)) v = NAN;
                 }

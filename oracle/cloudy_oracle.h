@@ -94,6 +94,8 @@ double co_density(const co_dist *d, double x);
 double co_normed_density(const co_dist *d, double x);
 int co_update_dist_from_moments(int dist_type, const double *moments, int n_moments,
                                 const double k_range[2], co_dist *out);
+/* Lognormal :614-625 by the rule the HIP kernels use (n_orders = P + 2: the orders that share one node range) */
+double co_moment_source_helper_lognormal(const co_dist *dist, double p1, double p2, double x_threshold, int n_orders);
 double co_moment_source_helper(const co_dist *d, double p1, double p2, double x_threshold,
                                int n_bins_per_log_unit);
 double co_integrate_simpson_even_fast(int n_bins, double dx, double (*y)(int j, void *ctx), void *ctx);

@@ -106,6 +106,8 @@ def lib():
         L.co_update_dist_from_moments.argtypes = [C.c_int, _dp, C.c_int, _dp, C.POINTER(Dist)]
         L.co_moment_source_helper.restype = C.c_double
         L.co_moment_source_helper.argtypes = [C.POINTER(Dist), C.c_double, C.c_double, C.c_double, C.c_int]
+        L.co_moment_source_helper_lognormal.restype = C.c_double
+        L.co_moment_source_helper_lognormal.argtypes = [C.POINTER(Dist), C.c_double, C.c_double, C.c_double, C.c_int]
         L.co_compute_threshold.restype = C.c_double
         L.co_compute_threshold.argtypes = [C.POINTER(Dist), C.c_double, C.c_double]
         L.co_compute_thresholds.argtypes = [C.POINTER(Dist), C.c_int, _dp, _dp]

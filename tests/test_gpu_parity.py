@@ -14,6 +14,8 @@ of large terms (e.g. the net mass tendency of a mode), so rounding is
 import math
 import os
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -640,6 +642,9 @@ def test_cfg5_long_kernel_plus_sedimentation_fp32(gpu_cloudy, oracle):
     ([3], (INF,)),                   # box_single_lognorm.jl:14-24
     ([1, 3], (5e-10, INF)),          # Gamma cloud mode + Lognormal rain mode
     ([2, 3, 1], (INF, INF, INF)),
+    ([3, 3], (5e-10, INF)),          # box_lognorm_mixture.jl:15-27: two Lognormal modes, Golovin, thr (5e-10, Inf)
+    ([3, 1, 3], (5e-10, 1e-7, INF)), # a Lognormal threshold and a Gamma threshold in one plan (two Simpson-type passes)
+    ([3, 3, 3, 0], (1e-10, 2e-9, 5e-8, INF)),
 ])
 def test_monodisperse_and_lognormal_closures_vs_oracle(gpu_cloudy, oracle, dist_types, thr):
     """the other two closure families (ParticleDistributions.jl:193-207, 483-505, 530-541,
@@ -665,12 +670,50 @@ def test_monodisperse_and_lognormal_closures_vs_oracle(gpu_cloudy, oracle, dist_
         assert np.allclose(g, [o.n, o.theta, o.k], rtol=1e-14)
 
 
+def test_lognormal_threshold_integrals_reference_kats_and_oracle(gpu_cloudy, oracle, kats):
+    """moment_source_helper(::Lognormal...) (ParticleDistributions.jl:614-625, nested quadgk in the reference) through
+    cloudy_finite_2d_integrals: the reference's own KATs (LN(1, 0.5, 2), x_t = 2.5: 2.831e-1, 1.725e-1, 8.115e-2,
+    test_ParticleDistributions_correctness.jl:215-218) and random parcels against the same-rule oracle, entry by entry
+    relative to M_p1 M_p2; order-2 tensor (M = 5 orders share the node range)."""
+    cloudy = gpu_cloudy
+    ents = [e for e in kats["moment_source_helper"] if e["dist"][0] == "lognormal"]
+    assert len(ents) == 3
+    cd = cloudy.CoalescenceData(cloudy.CoalescenceTensor(np.zeros((3, 3))), (3, 3), (2.5, INF))
+    plan = cd.plan([3, 3])
+    M = 5
+    prm = np.array([[1.0], [0.5], [2.0], [1.0], [0.0], [1.0]]).repeat(4, axis=1)
+    F = cloudy.get_finite_2d_integrals(plan, dev(cloudy, prm)).to_numpy().reshape(2, M, M, -1)
+    for e in ents:
+        got = F[0, int(e["p1"]), int(e["p2"]), 0]
+        assert got == pytest.approx(e["expected"], rel=e["rtol"]), e["cite"]
+    # random (n, mu, sigma) incl. narrow modes and thresholds far into either tail
+    rng = np.random.default_rng(12)
+    n = 1200
+    prm = np.zeros((6, n))
+    prm[0], prm[1], prm[2] = 10 ** rng.uniform(-1, 2, n), rng.uniform(-4, 3, n), 10 ** rng.uniform(-1.7, 0.3, n)
+    prm[3], prm[4], prm[5] = 1.0, 0.0, 1.0
+    F = cloudy.get_finite_2d_integrals(plan, dev(cloudy, prm)).to_numpy().reshape(2, M, M, n)
+    worst = 0.0
+    for i in range(0, n, 3):
+        d = oracle.make_dist(oracle.LOGNORMAL, prm[0, i], prm[1, i], prm[2, i])
+        Mq = [oracle.moment(d, float(q)) for q in range(M)]
+        for p1 in range(M):
+            for p2 in range(p1, M):
+                mm = Mq[p1] * Mq[p2]
+                if mm < EPS:
+                    continue
+                want = min(mm, oracle.lib().co_moment_source_helper_lognormal(C.byref(d), float(p1), float(p2), 2.5, M))
+                worst = max(worst, abs(F[0, p1, p2, i] - want) / mm)
+    print(f"lognormal moment_source_helper: max |hip - oracle| / (M_p1 M_p2) = {worst:.2e}")
+    assert worst <= 1e-12
+
+
 def test_unsupported_closure_threshold_combinations(gpu_cloudy):
     cloudy = gpu_cloudy
     kern = cloudy.CoalescenceTensor([[1.0]])
-    with pytest.raises(cloudy.CloudyError) as e:   # box_lognorm_mixture.jl:27 needs nested quadgk
-        cloudy.CoalescenceData(kern, (3, 3), (5e-10, INF), bench.NORMS).plan([3, 3])
-    assert e.value.code == cloudy._lib.EUNSUPPORTED and "quadgk" in e.value.msg
+    with pytest.raises(cloudy.CloudyError) as e:   # compute_threshold has no Lognormal method (ParticleDistributions.jl:747-761)
+        cloudy.CoalescenceData(kern, (3, 3), (0.9, 1.0), bench.NORMS, cloudy.MovingThreshold()).plan([3, 3])
+    assert e.value.code == cloudy._lib.EINVAL
     with pytest.raises(cloudy.CloudyError) as e:   # no compute_threshold method for Monodisperse
         cloudy.CoalescenceData(kern, (2, 3), (0.9, 1.0), bench.NORMS, cloudy.MovingThreshold()).plan([2, 1])
     assert e.value.code == cloudy._lib.EINVAL
@@ -838,9 +881,20 @@ def test_standard_N_q_diagnostics(gpu_cloudy, oracle, kats):
         w = oracle.get_standard_N_q(pd, 1e-9 / bench.NORMS[1]) * np.array([1e6, 1e6, 1e6 * 1e-9, 1e6 * 1e-9])
         tot = np.array([w[0] + w[1], w[0] + w[1], w[2] + w[3], w[2] + w[3]])
         assert np.all(np.abs(q[:, i] - w) <= 1e-12 * tot + 1e-300), i
-    with pytest.raises(cloudy.CloudyError):
-        cloudy.get_standard_N_q(cloudy.CoalescenceData(cloudy.CoalescenceTensor([[1.0]]), (3,), (INF,)).plan([3]),
-                                dev(cloudy, np.ones((3, 4))), 1e-6)
+    # the reference's own performance-test configuration, get_standard_N_q((mono, lognormal, gamma))
+    # (performance_tests.jl:94-99): Lognormal partial moments in closed form (the reference: quadgk, :255-269)
+    dist_types = [2, 3, 1]
+    par, op, _ = make_case(cloudy, oracle, dist_types, [[1.0]], (INF,) * 3, bench.NORMS)
+    plan = par.coal_data.plan(dist_types)
+    mom = mixed_moments(dist_types, n, seed=8)
+    prm = oracle.update_dist_batch(op, mom)
+    for cutoff in (1e-9, 3e-8):
+        q = cloudy.get_standard_N_q(plan, dev(cloudy, mom), cutoff).to_numpy()
+        for i in range(0, n, 5):
+            pd = [oracle.make_dist(dist_types[m], prm[3 * m, i], prm[3 * m + 1, i], prm[3 * m + 2, i]) for m in range(3)]
+            w = oracle.get_standard_N_q(pd, cutoff / bench.NORMS[1]) * np.array([1e6, 1e6, 1e6 * 1e-9, 1e6 * 1e-9])
+            tot = np.array([w[0] + w[1], w[0] + w[1], w[2] + w[3], w[2] + w[3]])
+            assert np.all(np.abs(q[:, i] - w) <= 1e-12 * tot + 1e-300), i
 
 
 def test_unaligned_planes_take_the_one_parcel_per_lane_kernel(gpu_cloudy, oracle):

@@ -2,9 +2,12 @@
 unit tests hold for the coalescence moment-RHS path (tests/golden/reference_kats.json; each entry
 cites test file:line in CliMA/Cloudy.jl v0.6.0).  CPU only."""
 import math
+import os
 
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 EPS = np.finfo(np.float64).eps
 TYPES = {"exponential": 0, "gamma": 1, "monodisperse": 2, "lognormal": 3}
@@ -363,3 +366,41 @@ def test_get_standard_N_q_kats(oracle, kats):
     assert q1[0] > q2[0] and q1[2] > q2[2]
     # closed form of one term: Exp(10, 1): N below 1.0 = 10 (1 - e^-1)
     assert oracle.partial_moment(pd[0], 0.0, 1.0) == pytest.approx(10.0 * (1 - math.exp(-1.0)), rel=1e-14)
+
+
+def test_lognormal_partial_moment_and_threshold_rule_vs_adaptive_quadrature(oracle):
+    """The two Lognormal integrals the reference evaluates with quadgk (ParticleDistributions.jl:255-269, :614-625):
+    the oracle's closed form / fixed 48-node rule -- the same the HIP kernels evaluate -- against adaptive quadrature of
+    the reference integrands (tests/golden/lognormal_adaptive.json, generated by oracle/lognormal_adaptive.py with
+    scipy in the build container).  Errors are stated relative to the unthresholded value (M_q, M_p1 M_p2): that is what
+    enters F = min(M_p1 M_p2, .) and the cloud / rain split."""
+    import json
+
+    with open(os.path.join(ROOT, "tests", "golden", "lognormal_adaptive.json")) as f:
+        gold = json.load(f)
+    worst_pm = worst_msh = 0.0
+    for c in gold["cases"]:
+        d = oracle.make_dist(oracle.LOGNORMAL, c["n"], c["mu"], c["sigma"])
+        for q, want in c["partial_moment"].items():
+            got = oracle.partial_moment(d, float(q), c["xt"])
+            worst_pm = max(worst_pm, abs(got - want) / oracle.moment(d, float(q)))
+        for key, want in c["moment_source_helper"].items():
+            p1, p2 = (float(v) for v in key.split(","))
+            got = oracle.moment_source_helper(d, p1, p2, c["xt"])
+            worst_msh = max(worst_msh, abs(got - want) / (oracle.moment(d, p1) * oracle.moment(d, p2)))
+    print(f"lognormal partial_moment closed form vs adaptive: {worst_pm:.2e} of M_q; "
+          f"moment_source_helper 48-node rule vs nested adaptive: {worst_msh:.2e} of M_p1 M_p2")
+    assert worst_pm <= 1e-12 and worst_msh <= 1e-11
+
+
+def test_get_standard_N_q_with_a_lognormal_mode(oracle):
+    """the reference's own performance-test configuration, get_standard_N_q((mono, lognormal, gamma))
+    (performance_tests.jl:94-99): liquid + rain recover the totals, the split moves with the cutoff"""
+    pd = [oracle.make_dist(oracle.MONODISPERSE, 1.0, 0.5), oracle.make_dist(oracle.LOGNORMAL, 1.0, 1.0, 2.0),
+          oracle.make_dist(oracle.GAMMA, 1.0, 1.0, 2.0)]
+    a, b = oracle.get_standard_N_q(pd, 1.0), oracle.get_standard_N_q(pd, 0.2)
+    n_tot = sum(oracle.moment(d, 0.0) for d in pd)
+    m_tot = sum(oracle.moment(d, 1.0) for d in pd)
+    for r in (a, b):
+        assert r[0] + r[1] == pytest.approx(n_tot, rel=1e-14) and r[2] + r[3] == pytest.approx(m_tot, rel=1e-14)
+    assert a[0] > b[0] and a[2] > b[2] and all(np.isfinite(a)) and all(np.isfinite(b))
