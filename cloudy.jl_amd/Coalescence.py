@@ -120,7 +120,7 @@ class NumericalPlan(Plan):
 
     @staticmethod
     def make_desc(dist_types, kernel_func, norms, quad_order=10, k_range=(EPS, 10.0), device=-1, dtype=0, specialize=0,
-                  kernel_func_is_normalized=True):
+                  kernel_func_is_normalized=True, quad_mode=0):
         L = _lib.lib()
         d = _lib.PlanDesc()
         L.cloudy_plan_desc_init(C.byref(d))
@@ -139,13 +139,14 @@ class NumericalPlan(Plan):
             d.kernel_func_params[i] = float(v)
         d.kernel_func_is_normalized = int(bool(kernel_func_is_normalized))
         d.quad_order = int(quad_order)
+        d.quad_mode = int(quad_mode)
         return d
 
     def __init__(self, dist_types, kernel_func, norms, quad_order=10, k_range=(EPS, 10.0), device=-1, dtype=0,
-                 specialize=0, kernel_func_is_normalized=True):
+                 specialize=0, kernel_func_is_normalized=True, quad_mode=0):
         L = _lib.lib()
         d = NumericalPlan.make_desc(dist_types, kernel_func, norms, quad_order, k_range, device, dtype, specialize,
-                                    kernel_func_is_normalized)
+                                    kernel_func_is_normalized, quad_mode)
         N = len(dist_types)
         h = C.c_void_p()
         _lib.check(L.cloudy_plan_create(C.byref(d), C.byref(h)))
@@ -154,6 +155,7 @@ class NumericalPlan(Plan):
         self.N = self.n_modes = N
         self.P = self.tensor_p = 1
         self.quad_order = int(quad_order)
+        self.quad_mode = int(quad_mode)
         self.all_inf = True
         self.numerical = True
         self.nmom = L.cloudy_plan_nmom(h)
@@ -163,13 +165,18 @@ class NumericalPlan(Plan):
 _numerical_plans = {}
 
 
-def numerical_plan(dist_types, kernel_func, norms, quad_order=10, k_range=(EPS, 10.0), dtype=0, specialize=0):
-    """Cached NumericalPlan (one per distinct configuration)."""
+QUAD_FIXED, QUAD_CONVERGED = 0, 1   # cloudy_plan_desc.quad_mode
+
+
+def numerical_plan(dist_types, kernel_func, norms, quad_order=10, k_range=(EPS, 10.0), dtype=0, specialize=0, quad_mode=0):
+    """Cached NumericalPlan (one per distinct configuration).  quad_mode: QUAD_FIXED = one quad_order-point Gauss rule
+    per distribution; QUAD_CONVERGED = the integrals split along the kernel function's non-smooth sets (closed forms +
+    one 1-D rule of quad_order points per panel per mode, csrc/quad_conv.hpp)."""
     key = (tuple(int(t) for t in dist_types), kernel_func, tuple(norms), int(quad_order), tuple(k_range), int(dtype),
-           int(specialize))
+           int(specialize), int(quad_mode))
     if key not in _numerical_plans:
         _numerical_plans[key] = NumericalPlan(key[0], kernel_func, norms, quad_order, k_range, dtype=dtype,
-                                              specialize=specialize)
+                                              specialize=specialize, quad_mode=quad_mode)
     return _numerical_plans[key]
 
 
@@ -229,7 +236,8 @@ class CoalescenceData:
         return self._plans[key]
 
 
-def get_coal_ints(cs, pdists, coal_data, ts=None, out=None, stream=None, k_range=(EPS, 10.0), quad_order=10):
+def get_coal_ints(cs, pdists, coal_data, ts=None, out=None, stream=None, k_range=(EPS, 10.0), quad_order=10,
+                  quad_mode=0):
     """get_coal_ints(::AnalyticalCoalStyle, pdists, coal_data[, ::MovingThreshold])  (Coalescence.jl:115-185) and
     get_coal_ints(::NumericalCoalStyle, pdists, kernel_func) (:470-489; third argument = the normalised kernel
     function, integrals by the fixed `quad_order`-point rule), batched: `pdists` = (dist_types, params) with params a
@@ -237,7 +245,7 @@ def get_coal_ints(cs, pdists, coal_data, ts=None, out=None, stream=None, k_range
     tendencies."""
     dist_types, params = pdists
     if isinstance(cs, NumericalCoalStyle):
-        plan = numerical_plan(dist_types, coal_data, (1.0, 1.0), quad_order, k_range)
+        plan = numerical_plan(dist_types, coal_data, (1.0, 1.0), quad_order, k_range, quad_mode=quad_mode)
     elif not isinstance(cs, AnalyticalCoalStyle):
         raise ValueError("Invalid coal style!")
     else:

@@ -32,7 +32,7 @@ def _numerical_plan_for(par, dtype=0):
         raise ValueError("NProgMoms must equal nparams of p.pdists")
     return numerical_plan([d.type_id for d in par.pdists], par.kernel_func, par.norms,
                           quad_order=getattr(par, "quad_order", 10), k_range=getattr(par, "k_range", (EPS, 10.0)),
-                          dtype=dtype)
+                          dtype=dtype, quad_mode=getattr(par, "quad_mode", 0))
 
 
 def _plan_for(par, dtype=0):

@@ -123,7 +123,7 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
                                      args, nullptr);
     }
     if (h.coal_style == CLOUDY_NUMERICAL_COAL) {
-        const unsigned qb = (unsigned)quad_block(h.q.nq);
+        const unsigned qb = h.q.mode == QUAD_CONVERGED ? (unsigned)kBlock : (unsigned)quad_block(h.q.nq);
         if (r.op == OP_SSPRK33) {
             double dt = r.dt;
             int n_steps = r.n_steps;
@@ -257,7 +257,11 @@ int build_host_plan(const cloudy_plan_desc *d, cloudy_plan **out, std::vector<do
         if (d->quad_mode != CLOUDY_QUAD_FIXED && d->quad_mode != CLOUDY_QUAD_CONVERGED)
             return fail(CLOUDY_EINVAL, "quad_mode %d is neither CLOUDY_QUAD_FIXED nor CLOUDY_QUAD_CONVERGED", d->quad_mode);
         if (d->quad_mode == CLOUDY_QUAD_CONVERGED)
-            return fail(CLOUDY_EUNSUPPORTED, "CLOUDY_QUAD_CONVERGED is not built yet");
+            for (int i = 0; i < N; ++i)
+                if (d->dist_type[i] == CLOUDY_DIST_LOGNORMAL)
+                    return fail(CLOUDY_EUNSUPPORTED,
+                                "CLOUDY_QUAD_CONVERGED serves Gamma and Exponential modes (closed forms of the region "
+                                "integrals); a Lognormal mode needs CLOUDY_QUAD_FIXED");
         if (d->quad_order < 2 || d->quad_order > CLOUDY_MAX_QUAD)
             return fail(CLOUDY_EUNSUPPORTED, "quad_order %d outside 2..%d", d->quad_order, CLOUDY_MAX_QUAD);
         if (d->dtype == CLOUDY_F32_FAST)
@@ -331,11 +335,22 @@ int build_host_plan(const cloudy_plan_desc *d, cloudy_plan **out, std::vector<do
                 delete p;
                 return fail(CLOUDY_EINVAL, "kernel_func_params[%d] is NaN", k);
             }
-        // start-value table of the per-parcel Gauss-Laguerre rules over k in (0, max(k_range[1], 1)] (Exponential: k = 1)
-        std::string msg;
-        if (!quad_host::build_table(d->quad_order, std::fmax(d->k_range[1], 1.0), h.q, h.qtab, msg)) {
-            delete p;
-            return fail(CLOUDY_EUNSUPPORTED, "%s", msg.c_str());
+        if (d->quad_mode == CLOUDY_QUAD_CONVERGED) {
+            // quad_conv.hpp: quad_order Gauss-Legendre points per panel of the one 1-D rule the mode needs
+            h.q.mode = QUAD_CONVERGED;
+            h.q.nq = d->quad_order;
+            h.q.deg = 0;
+            h.q.t_scale = 0.0;
+            h.qtab.assign((size_t)2 * d->quad_order, 0.0);
+            quad_host::legendre_rule(d->quad_order, h.qtab.data(), h.qtab.data() + d->quad_order);
+        } else {
+            // start-value table of the per-parcel Gauss-Laguerre rules over k in (0, max(k_range[1], 1)] (Exponential: k = 1)
+            std::string msg;
+            if (!quad_host::build_table(d->quad_order, std::fmax(d->k_range[1], 1.0), h.q, h.qtab, msg)) {
+                delete p;
+                return fail(CLOUDY_EUNSUPPORTED, "%s", msg.c_str());
+            }
+            h.q.mode = QUAD_FIXED;
         }
         h.n_mom_max = np_max;
         for (int i = 0; i < N; ++i) {

@@ -83,6 +83,27 @@ inline void hermite_rule(int nq, double *t, double *W) {
     }
 }
 
+// q-point Gauss-Legendre rule on [-1, 1] (converged mode, quad_conv.hpp): Newton on P_q from the Chebyshev-like start values
+inline void legendre_rule(int q, double *x, double *w) {
+    for (int i = 0; i < q; ++i) {
+        double t = std::cos(M_PI * (i + 0.75) / (q + 0.5)), dp = 1.0;
+        for (int it = 0; it < 100; ++it) {
+            double p0 = 1.0, p1 = t;
+            for (int j = 2; j <= q; ++j) {
+                const double p2 = ((2.0 * j - 1.0) * t * p1 - (j - 1.0) * p0) / j;
+                p0 = p1;
+                p1 = p2;
+            }
+            dp = q * (t * p1 - p0) / (t * t - 1.0);
+            const double dt = p1 / dp;
+            t -= dt;
+            if (std::fabs(dt) < 1e-16) break;
+        }
+        x[q - 1 - i] = t;
+        w[q - 1 - i] = 2.0 / ((1.0 - t * t) * dp * dp);
+    }
+}
+
 // Builds the table for (nq, k_hi).  Raises the degree until the start values are within `tol` of the node spacing on
 // a test grid; false (with a message) if kQuadDegMax does not reach it.
 inline bool build_table(int nq, double k_hi, QArgs &Q, std::vector<double> &tab, std::string &msg) {

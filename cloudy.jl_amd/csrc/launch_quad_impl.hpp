@@ -6,16 +6,23 @@
 
 namespace cloudy {
 
-template <int N, int KIND, typename TIO>
-hipError_t launch_quad_io(const HostPlan &h, const LaunchReq &r, const KArgs<N, 1> &A) {
+template <int N, int KIND, typename TIO, bool CONV>
+hipError_t launch_quad_io2(const HostPlan &h, const LaunchReq &r, const KArgs<N, 1> &A) {
     if (r.op == OP_SSPRK33) {  // cloudy_ssprk33_steps of a NumericalCoalStyle plan (quad_ssprk33_body)
-        hipLaunchKernelGGL((quad_ssprk33_kernel<N, KIND, TIO>), dim3(grid_for(r.n, true)), dim3(kBlock), 0, r.stream, A, h.q,
-                           h.qtab_dev, r.n, r.ld, static_cast<const TIO *>(r.in), static_cast<TIO *>(r.out), r.dt, r.n_steps);
+        hipLaunchKernelGGL((quad_ssprk33_kernel<N, KIND, TIO, CONV>), dim3(grid_for(r.n, true)), dim3(kBlock), 0, r.stream, A,
+                           h.q, h.qtab_dev, r.n, r.ld, static_cast<const TIO *>(r.in), static_cast<TIO *>(r.out), r.dt,
+                           r.n_steps);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL((coal_rhs_quad_kernel<N, KIND, TIO>), dim3(grid_for(r.n, true)), dim3(kBlock), 0, r.stream, A, h.q,
+    hipLaunchKernelGGL((coal_rhs_quad_kernel<N, KIND, TIO, CONV>), dim3(grid_for(r.n, true)), dim3(kBlock), 0, r.stream, A, h.q,
                        h.qtab_dev, r.n, r.ld, static_cast<const TIO *>(r.in), static_cast<TIO *>(r.out));
     return hipGetLastError();
+}
+
+template <int N, int KIND, typename TIO>
+hipError_t launch_quad_io(const HostPlan &h, const LaunchReq &r, const KArgs<N, 1> &A) {
+    if (h.q.mode == QUAD_CONVERGED) return launch_quad_io2<N, KIND, TIO, true>(h, r, A);
+    return launch_quad_io2<N, KIND, TIO, false>(h, r, A);
 }
 
 template <int N>

@@ -30,8 +30,11 @@ enum { KF_CONSTANT = 0, KF_LINEAR = 1, KF_HYDRODYNAMIC = 2, KF_LONG = 3 };
 constexpr int kQuadMax = 32;     // points per rule
 constexpr int kQuadDegMax = 24;  // degree of the start-value polynomials
 
+enum { QUAD_FIXED = 0, QUAD_CONVERGED = 1 };  // cloudy_plan_desc.quad_mode
 struct QArgs {  // wave-uniform constants of a NumericalCoalStyle plan
-    int32_t kind, nq, deg, pad;
+    // mode QUAD_FIXED: nq points of the per-distribution Gauss rule; QUAD_CONVERGED (quad_conv.hpp): nq Gauss-Legendre
+    // points per panel of the 1-D rule, table = nq nodes on [-1, 1] then nq weights
+    int32_t kind, nq, deg, mode;
     double kf[3];     // normalised kernel-function parameters (get_normalized_kernel_func, KernelFunctions.jl:124-154)
     double t_scale;   // t = k * t_scale - 1 maps [0, k_hi] onto [-1, 1]
 };

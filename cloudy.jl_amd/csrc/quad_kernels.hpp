@@ -19,6 +19,7 @@
 #pragma once
 #include "kernels.hpp"
 #include "quad.hpp"
+#include "quad_conv.hpp"
 
 namespace cloudy {
 
@@ -189,7 +190,8 @@ __device__ __forceinline__ void quad_coal_ints(const KArgs<N, 1> &A, const QArgs
     }
 }
 
-template <int N, int KIND, int NQ, typename TIO>
+// CONV: the converged mode of quad_conv.hpp (closed forms + one 1-D rule per mode; kernel constants included in acc)
+template <int N, int KIND, int NQ, typename TIO, bool CONV = false>
 __device__ __forceinline__ void coal_rhs_quad_body(const KArgs<N, 1> &A, const QArgs &Q, const double *__restrict__ tab,
                                                    size_t n, size_t ld, const TIO *__restrict__ in,
                                                    TIO *__restrict__ out) {
@@ -198,8 +200,11 @@ __device__ __forceinline__ void coal_rhs_quad_body(const KArgs<N, 1> &A, const Q
     if (i >= n) return;
     double nn[N], th[N], kk[N], acc[N][3];
     load_parcel<N, 1, TIO>(A, i, ld, in, nn, th, kk);
-    quad_coal_ints<N, KIND, NQ>(A, Q, tab, nn, th, kk, acc);
-    const double ksc = kf_scale<KIND>(Q);
+    if (CONV)
+        conv_coal_ints<N, KIND>(A, Q, tab, nn, th, kk, acc);
+    else
+        quad_coal_ints<N, KIND, NQ>(A, Q, tab, nn, th, kk, acc);
+    const double ksc = CONV ? 1.0 : kf_scale<KIND>(Q);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         const int off = A.off[k];
@@ -213,7 +218,7 @@ __device__ __forceinline__ void coal_rhs_quad_body(const KArgs<N, 1> &A, const Q
 // (test/examples/Numerical/n_particles_gamma.jl:39-40, single_particle_gamma.jl:41-42) -- with the state in registers
 // over all stages and steps, as ssprk33_body (kernels.hpp) does for the tensor plans: one read and one write of the state
 // per call, OrdinaryDiffEq's SSPRK33 update formulas ("/4" exact, "/3" correctly rounded).
-template <int N, int KIND, int NQ, typename TIO>
+template <int N, int KIND, int NQ, typename TIO, bool CONV = false>
 __device__ __forceinline__ void quad_ssprk33_body(const KArgs<N, 1> &A, const QArgs &Q, const double *__restrict__ tab,
                                                   size_t n, size_t ld, const TIO *u_in, TIO *u_out, double dt,
                                                   int n_steps) {
@@ -228,7 +233,7 @@ __device__ __forceinline__ void quad_ssprk33_body(const KArgs<N, 1> &A, const QA
         u[m][1] = (double)u_in[(size_t)(off + 1) * ld + i];
         u[m][2] = (A.np[m] == 3) ? (double)u_in[(size_t)(off + 2) * ld + i] : 0.0;
     }
-    const double ksc = kf_scale<KIND>(Q);
+    const double ksc = CONV ? 1.0 : kf_scale<KIND>(Q);
 #pragma unroll 1
     for (int step = 0; step < n_steps; ++step) {
 #pragma unroll
@@ -245,7 +250,10 @@ __device__ __forceinline__ void quad_ssprk33_body(const KArgs<N, 1> &A, const QA
                 const double m2 = div_by_const(u[m][2], A.norm[3 * m + 2], A.inv_norm[3 * m + 2]);
                 invert_closure(A.dist_type[m], m0, m1, m2, A.kmin, A.kmax, nn[m], th[m], kk[m]);
             }
-            quad_coal_ints<N, KIND, NQ>(A, Q, tab, nn, th, kk, acc);
+            if (CONV)
+                conv_coal_ints<N, KIND>(A, Q, tab, nn, th, kk, acc);
+            else
+                quad_coal_ints<N, KIND, NQ>(A, Q, tab, nn, th, kk, acc);
 #pragma unroll
             for (int m = 0; m < N; ++m) {
                 f[m][0] = acc[m][0] * (ksc * A.out_scale[3 * m + 0]);
@@ -282,18 +290,18 @@ __device__ __forceinline__ void quad_ssprk33_body(const KArgs<N, 1> &A, const QA
 
 // ahead-of-time instance: run-time point count, the rule arrays in scratch (the plan-time compiled kernel of jit.hpp
 // has them in registers)
-template <int N, int KIND, typename TIO>
+template <int N, int KIND, typename TIO, bool CONV = false>
 __global__ void __launch_bounds__(kBlock)
     coal_rhs_quad_kernel(const KArgs<N, 1> A, const QArgs Q, const double *__restrict__ tab, size_t n, size_t ld,
                          const TIO *__restrict__ in, TIO *__restrict__ out) {
-    coal_rhs_quad_body<N, KIND, 0, TIO>(A, Q, tab, n, ld, in, out);
+    coal_rhs_quad_body<N, KIND, 0, TIO, CONV>(A, Q, tab, n, ld, in, out);
 }
 
-template <int N, int KIND, typename TIO>
+template <int N, int KIND, typename TIO, bool CONV = false>
 __global__ void __launch_bounds__(kBlock)
     quad_ssprk33_kernel(const KArgs<N, 1> A, const QArgs Q, const double *__restrict__ tab, size_t n, size_t ld,
                         const TIO *u_in, TIO *u_out, double dt, int n_steps) {
-    quad_ssprk33_body<N, KIND, 0, TIO>(A, Q, tab, n, ld, u_in, u_out, dt, n_steps);
+    quad_ssprk33_body<N, KIND, 0, TIO, CONV>(A, Q, tab, n, ld, u_in, u_out, dt, n_steps);
 }
 
 }  // namespace cloudy

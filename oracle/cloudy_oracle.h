@@ -150,6 +150,22 @@ int co_gauss_hermite_rule(int nq, double *t, double *W);           /* weight e^(
 int co_dist_rule(const co_dist *d, int nq, double *x, double *w);
 int co_get_coal_ints_numerical_fixed(const co_dist *pdists, int N, const co_kernel_func *kf, int nq, double *out,
                                      double *scale, double *noise);
+/* cloudy_oracle_adaptive.c: the same operator by NESTED ADAPTIVE Gauss-Kronrod quadrature, as the reference evaluates it
+ * (Coalescence.jl:503-708) -- slow; generates tests/golden/numerical_adaptive.json.  Q, R: [orders][N][N]; S: [orders][2][N] */
+int co_get_coal_ints_numerical_adaptive(const co_dist *pdists, int N, const co_kernel_func *kf, double eps_outer,
+                                        double eps_inner, double *out, double *Q, double *R, double *S);
+/* cloudy_oracle_quad.c, converged mode (CLOUDY_QUAD_CONVERGED): closed forms for Q and R, one 1-D rule per mode for the
+ * weighting_fn split; q Gauss-Legendre points per panel, npan panels */
+double co_inc_beta(double a, double b, double x);
+int co_gauss_legendre_rule(int q, double *x, double *w);
+void co_conv_range(double A, double *zlo, double *zhi);
+int co_get_coal_ints_numerical_converged(const co_dist *pdists, int N, const co_kernel_func *kf, int q, int npan,
+                                         double *out, double *scale);
+int co_rhs_coal_numerical_converged(const co_params *p, const co_kernel_func *kf_normalized, int q, int npan,
+                                    const double *mom, double *dmom, double *scale);
+int co_rhs_coal_numerical_converged_batch(const co_params *p, const co_kernel_func *kf_normalized, int q, int npan,
+                                          long n_parcels, long ld, const double *mom, double *dmom, double *scale,
+                                          int n_threads);
 int co_rhs_coal_numerical(const co_params *p, const co_kernel_func *kf_normalized, int nq, const double *mom,
                           double *dmom, double *scale, double *noise);
 int co_rhs_coal_numerical_batch(const co_params *p, const co_kernel_func *kf_normalized, int nq, long n_parcels, long ld,

@@ -134,6 +134,15 @@ def lib():
         L.co_get_coal_ints_numerical_fixed.argtypes = [C.POINTER(Dist), C.c_int, C.POINTER(KernelFunc), C.c_int, _dp, _dp, _dp]
         L.co_rhs_coal_numerical_batch.argtypes = [C.POINTER(Params), C.POINTER(KernelFunc), C.c_int, C.c_long, C.c_long,
                                                   _dp, _dp, _dp, _dp, C.c_int]
+        L.co_inc_beta.restype = C.c_double
+        L.co_inc_beta.argtypes = [C.c_double, C.c_double, C.c_double]
+        L.co_gauss_legendre_rule.argtypes = [C.c_int, _dp, _dp]
+        L.co_get_coal_ints_numerical_converged.argtypes = [C.POINTER(Dist), C.c_int, C.POINTER(KernelFunc), C.c_int, C.c_int,
+                                                           _dp, _dp]
+        L.co_rhs_coal_numerical_converged_batch.argtypes = [C.POINTER(Params), C.POINTER(KernelFunc), C.c_int, C.c_int,
+                                                            C.c_long, C.c_long, _dp, _dp, _dp, C.c_int]
+        L.co_get_coal_ints_numerical_adaptive.argtypes = [C.POINTER(Dist), C.c_int, C.POINTER(KernelFunc), C.c_double,
+                                                          C.c_double, _dp, _dp, _dp, _dp]
         _lib = L
     return _lib
 
@@ -473,6 +482,36 @@ def get_coal_ints_numerical_fixed(pdists, kf, nq=10, with_scale=False):
     return (out, sc) if with_scale else out
 
 
+CONV_PANELS = 48   # panels of the converged mode's 1-D rule (kConvPanels in csrc/quad_conv.hpp)
+
+
+def get_coal_ints_numerical_converged(pdists, kf, q=8, npan=CONV_PANELS, with_scale=False):
+    """get_coal_ints(::NumericalCoalStyle, ...) in converged mode (cloudy_oracle_quad.c): closed forms for Q and R, one
+    composite Gauss-Legendre rule (npan panels x q points) per mode for the weighting_fn split."""
+    arr = (Dist * len(pdists))(*pdists)
+    nmom = sum(nparams(d.type) for d in pdists)
+    out, sc = np.zeros(nmom), np.zeros(nmom)
+    r = lib().co_get_coal_ints_numerical_converged(arr, len(pdists), C.byref(kf), int(q), int(npan), _d(out), _d(sc))
+    if r < 0:
+        raise ValueError("get_coal_ints_numerical_converged: " + ("Lognormal / Monodisperse modes are not served"
+                                                                  if r == -2 else "bad arguments"))
+    return (out, sc) if with_scale else out
+
+
+def get_coal_ints_numerical_adaptive(pdists, kf, eps_outer=1e-10, eps_inner=1e-12):
+    """get_coal_ints(::NumericalCoalStyle, ...) by nested adaptive Gauss-Kronrod quadrature (cloudy_oracle_adaptive.c):
+    (coal_ints, Q[orders, N, N], R[orders, N, N], S[orders, 2, N])."""
+    arr = (Dist * len(pdists))(*pdists)
+    N = len(pdists)
+    orders = max(nparams(d.type) for d in pdists)
+    nmom = sum(nparams(d.type) for d in pdists)
+    out, Q, R, S = np.zeros(nmom), np.zeros((orders, N, N)), np.zeros((orders, N, N)), np.zeros((orders, 2, N))
+    if lib().co_get_coal_ints_numerical_adaptive(arr, N, C.byref(kf), float(eps_outer), float(eps_inner), _d(out), _d(Q),
+                                                 _d(R), _d(S)) < 0:
+        raise ValueError("get_coal_ints_numerical_adaptive failed")
+    return out, Q, R, S
+
+
 def rhs_coal_numerical_batch(p, kf_normalized, nq, mom, with_scale=False, n_threads=0, out=None, with_noise=False):
     """rhs_coal!(NumericalCoalStyle(), ...) for a moment-major batch; p: make_params(...) (its tensors are unused).
     with_noise: also the absolute rounding error of the reference's (1 - weighting_fn) form (cloudy_oracle_quad.c)."""
@@ -488,4 +527,18 @@ def rhs_coal_numerical_batch(p, kf_normalized, nq, mom, with_scale=False, n_thre
         raise ValueError("rhs_coal_numerical_batch failed")
     if with_noise:
         return d, s, z
+    return (d, s) if with_scale else d
+
+
+def rhs_coal_numerical_converged_batch(p, kf_normalized, q, mom, npan=CONV_PANELS, with_scale=False, n_threads=0, out=None):
+    """rhs_coal!(NumericalCoalStyle(), ...) in converged mode for a moment-major batch (same-rule restatement of
+    csrc/quad_conv.hpp); p: make_params(...) (its tensors are unused)."""
+    m = _darr(mom)
+    nm, n = m.shape
+    assert nm == nmom_of(p)
+    d = out if out is not None else np.empty_like(m)
+    s = np.empty_like(m) if with_scale else None
+    if lib().co_rhs_coal_numerical_converged_batch(C.byref(p), C.byref(kf_normalized), int(q), int(npan), n, n, _d(m),
+                                                   _d(d), _d(s) if s is not None else None, int(n_threads)) < 0:
+        raise ValueError("rhs_coal_numerical_converged_batch failed (Lognormal modes are not served in converged mode)")
     return (d, s) if with_scale else d

@@ -369,3 +369,356 @@ int co_rhs_coal_numerical_batch(const co_params *p, const co_kernel_func *kf_nor
     (void)n_threads;
     return err ? -1 : nmom;
 }
+
+/* ================================================================================================================ */
+/* CONVERGED mode (CLOUDY_QUAD_CONVERGED, include/cloudy_hip.h): SAME-RULE restatement of what the HIP kernels of        */
+/* csrc/quad_conv.hpp evaluate -- the integrals of Coalescence.jl:503-708 split along the non-smooth sets of the kernel  */
+/* function, so that the result converges to the reference's quadgk answer instead of stalling at 1e-3:                  */
+/*                                                                                                                      */
+/*   Every CoalescenceKernelFunction of the reference (KernelFunctions.jl:39-116) is, on each side of its non-smooth     */
+/*   set, a short sum of SEPARABLE power terms c x^alpha y^beta:                                                         */
+/*     constant  c;   linear  c (x + y);                                                                                 */
+/*     hydrodynamic, x > y:  C (x^4/3 + 2 x y^1/3 - 2 x^1/3 y - y^4/3), C = E pi (3/4pi)^(4/3); the negative for x < y;  */
+/*     Long:  c_b (x^2 + y^2) on the square x, y < x_t;  c_a (x + y) elsewhere.                                          */
+/*   For Gamma / Exponential densities the integral of a power term over such a region is a product of moments times a   */
+/*   probability with a closed form:                                                                                     */
+/*     int int_{y < x} x^a y^b f_j(x) f_k(y) = M^j_a M^k_b I_z(k_k + b, k_j + a),  z = theta_j / (theta_j + theta_k)     */
+/*     (regularised incomplete beta: P(Y' < X') for Gamma variates), and partial moments M_q P(k + q, x_t / theta) on    */
+/*     the Long square.  So Q and R (:503-578) need NO quadrature at all.                                                 */
+/*   The self collisions split by weighting_fn (:580-622, 624-642) are integrals over s = x' + y of a function of s       */
+/*   alone: with S = X + Y ~ Gamma(2k, theta) independent of tau = Y / S ~ Beta(k, k),                                   */
+/*     T_m = S_2k^(m) = 1/2 n^2 E[ S^m (1 - w(S)) G(S) ],   G(s) = E_tau[ K(s (1 - tau), s tau) ]                        */
+/*   and G is a closed form too (homogeneous kernels: G = kbar s^gamma; Long: incomplete betas of argument x_t / s).     */
+/*   What is left is ONE 1-D integral per mode against a Gamma density of a smooth sigmoid: a composite Gauss-Legendre   */
+/*   rule in z, s / theta = ln(1 + e^z) (logarithmic near 0, linear in the tail), panels split at the kinks of G.         */
+/* Lognormal modes: see below (LN).                                                                                     */
+/* ================================================================================================================ */
+
+/* ln Gamma for x > 0 */
+static double co_lgam(double x) { return lgamma(x); }
+
+/* regularised incomplete beta I_x(a, b), a, b > 0, 0 <= x <= 1: Lentz's continued fraction (DLMF 8.17.22), evaluated on
+ * the side where it converges fast (x < (a + 1) / (a + b + 2), else through I_x(a, b) = 1 - I_{1-x}(b, a)) */
+static double co_inc_beta_cf(double a, double b, double x) {
+    const double tiny = 1e-300;
+    double c = 1.0, d = 1.0 - (a + b) * x / (a + 1.0);
+    if (fabs(d) < tiny) d = tiny;
+    d = 1.0 / d;
+    double h = d;
+    for (int m = 1; m <= 500; ++m) {
+        const double m2 = 2.0 * m;
+        double aa = m * (b - m) * x / ((a + m2 - 1.0) * (a + m2));
+        d = 1.0 + aa * d;
+        if (fabs(d) < tiny) d = tiny;
+        c = 1.0 + aa / c;
+        if (fabs(c) < tiny) c = tiny;
+        d = 1.0 / d;
+        h *= d * c;
+        aa = -(a + m) * (a + b + m) * x / ((a + m2) * (a + m2 + 1.0));
+        d = 1.0 + aa * d;
+        if (fabs(d) < tiny) d = tiny;
+        c = 1.0 + aa / c;
+        if (fabs(c) < tiny) c = tiny;
+        d = 1.0 / d;
+        const double del = d * c;
+        h *= del;
+        if (fabs(del - 1.0) < 1e-16) break;
+    }
+    return h;
+}
+/* y = 1 - x handed in by callers that know it without cancellation (x = t_j / (t_j + t_k), y = t_k / (t_j + t_k)) */
+static double co_inc_beta_xy(double a, double b, double x, double y) {
+    if (!(x > 0.0)) return 0.0;
+    if (!(y > 0.0)) return 1.0;
+    const double lbt = co_lgam(a + b) - co_lgam(a) - co_lgam(b) + a * log(x) + b * log(y);
+    if (x < (a + 1.0) / (a + b + 2.0)) return exp(lbt) * co_inc_beta_cf(a, b, x) / a;
+    return 1.0 - exp(lbt) * co_inc_beta_cf(b, a, y) / b;
+}
+double co_inc_beta(double a, double b, double x) { return co_inc_beta_xy(a, b, x, 1.0 - x); }
+
+/* q-point Gauss-Legendre rule on [-1, 1] */
+int co_gauss_legendre_rule(int q, double *x, double *w) {
+    if (q < 1 || q > CO_MAX_QUAD) return -1;
+    for (int i = 0; i < q; ++i) {
+        double t = cos(M_PI * (i + 0.75) / (q + 0.5)), dp = 1.0;
+        for (int it = 0; it < 100; ++it) {
+            double p0 = 1.0, p1 = t;
+            for (int j = 2; j <= q; ++j) {
+                const double p2 = ((2.0 * j - 1.0) * t * p1 - (j - 1.0) * p0) / j;
+                p0 = p1;
+                p1 = p2;
+            }
+            if (q == 1) {
+                p0 = 1.0;
+                p1 = t;
+            }
+            dp = q * (t * p1 - p0) / (t * t - 1.0);
+            const double dt = p1 / dp;
+            t -= dt;
+            if (fabs(dt) < 1e-16) break;
+        }
+        x[q - 1 - i] = t;
+        w[q - 1 - i] = 2.0 / ((1.0 - t * t) * dp * dp);
+    }
+    return 0;
+}
+
+/* moment of order q (real) of a Gamma-family mode: n theta^q Gamma(k + q) / Gamma(k) */
+static double co_gmom(const co_dist *d, double q) {
+    const double k = d->type == CO_EXPONENTIAL ? 1.0 : d->k;
+    return d->n * exp(q * log(d->theta) + co_lgam(k + q) - co_lgam(k));
+}
+static double co_shape(const co_dist *d) { return d->type == CO_EXPONENTIAL ? 1.0 : d->k; }
+
+/* int int x^p y^q K(x, y) f_j(x) f_k(y) dx dy over (0, inf)^2 for Gamma-family modes, in closed form */
+static double co_conv_pair(const co_kernel_func *kf, const co_dist *dj, const co_dist *dk, int p, int q, double *mag) {
+    double dummy;
+    if (!mag) mag = &dummy;
+    switch (kf->kind) {
+    case CO_KF_CONSTANT: return *mag = kf->p[0] * co_gmom(dj, p) * co_gmom(dk, q);
+    case CO_KF_LINEAR:
+        return *mag = kf->p[0] * (co_gmom(dj, p + 1.0) * co_gmom(dk, q) + co_gmom(dj, p) * co_gmom(dk, q + 1.0));
+    case CO_KF_HYDRODYNAMIC: {
+        static const double term[4][3] = {{4.0 / 3.0, 0.0, 1.0}, {1.0, 1.0 / 3.0, 2.0}, {1.0 / 3.0, 1.0, -2.0}, {0.0, 4.0 / 3.0, -1.0}};
+        const double kj = co_shape(dj), kk = co_shape(dk);
+        const double z = dj->theta / (dj->theta + dk->theta), omz = dk->theta / (dj->theta + dk->theta);
+        double tot = 0.0, m = 0.0;
+        for (int t = 0; t < 4; ++t) {
+            const double al = term[t][0], be = term[t][1];
+            const double I = co_inc_beta_xy(kk + q + be, kj + p + al, z, omz); /* P(Y' < X') */
+            const double mm = term[t][2] * co_gmom(dj, p + al) * co_gmom(dk, q + be);
+            tot += mm * (2.0 * I - 1.0);
+            m += fabs(mm);
+        }
+        *mag = kf->p[0] * 0.46526286817455001 * m;
+        return kf->p[0] * 0.46526286817455001 * tot; /* pi (3 / (4 pi))^(4/3) */
+    }
+    case CO_KF_LONG: {
+        const double xt = kf->p[0], cb = kf->p[1], ca = kf->p[2];
+        const double kj = co_shape(dj), kk = co_shape(dk);
+#define PMJ(r) (co_gmom(dj, (r)) * co_gamma_inc_p(kj + (r), xt / dj->theta))
+#define PMK(r) (co_gmom(dk, (r)) * co_gamma_inc_p(kk + (r), xt / dk->theta))
+        const double full = ca * (co_gmom(dj, p + 1.0) * co_gmom(dk, q) + co_gmom(dj, p) * co_gmom(dk, q + 1.0));
+        const double below2 = cb * (PMJ(p + 2.0) * PMK(q) + PMJ(p) * PMK(q + 2.0));
+        const double below1 = ca * (PMJ(p + 1.0) * PMK(q) + PMJ(p) * PMK(q + 1.0));
+#undef PMJ
+#undef PMK
+        *mag = full + below2 + below1;
+        return full + below2 - below1;
+    }
+    default: return NAN;
+    }
+}
+
+/* ln of the normed density of a Gamma-family or Lognormal mode at s (ls = ln s), ParticleDistributions.jl:363-388 */
+static double co_ln_normed(const co_dist *d, double s, double ls) {
+    if (d->type == CO_LOGNORMAL) {
+        const double u = (ls - d->theta) / d->k;
+        return -0.5 * u * u - ls - log(d->k * 2.5066282746310002);
+    }
+    const double k = co_shape(d);
+    return (k - 1.0) * ls - s / d->theta - (co_lgam(k) + k * log(d->theta));
+}
+/* 1 - weighting_fn(s, j + 1) (0-based j) formed from density ratios against mode j's own density (no 0/0, full
+ * relative precision where w = 1 - 1e-9) */
+static double co_one_minus_w(const co_dist *pdists, int N, int j, double s, double ls) {
+    const double own = co_ln_normed(&pdists[j], s, ls);
+    double up = 0.0, den = 1.0;
+    for (int m = 0; m < N; ++m) {
+        if (m == j) continue;
+        const double rho = exp(fmin(co_ln_normed(&pdists[m], s, ls) - own, 700.0));
+        den += rho;
+        if (m > j) up += rho;
+    }
+    return up / den;
+}
+
+static double co_softplus_q(double x) { return x > 0.0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
+
+/* E_tau[K(s (1 - tau), s tau)], tau ~ Beta(k, k), for the Long kernel */
+static double co_long_G(const co_kernel_func *kf, double k, double s) {
+    const double xt = kf->p[0], cb = kf->p[1], ca = kf->p[2];
+    if (s <= xt) return cb * s * s * (k + 1.0) / (2.0 * k + 1.0);
+    if (s >= 2.0 * xt) return ca * s;
+    const double x = xt / s;
+    const double P0 = 2.0 * co_inc_beta(k, k, x) - 1.0;
+    const double r = exp(2.0 * co_lgam(k + 1.0) - co_lgam(2.0 * k + 2.0) - 2.0 * co_lgam(k) + co_lgam(2.0 * k)); /* B(k+1,k+1)/B(k,k) */
+    const double P1 = r * (2.0 * co_inc_beta(k + 1.0, k + 1.0, x) - 1.0);
+    return ca * s + (cb * s * s - ca * s) * P0 - 2.0 * cb * s * s * P1;
+}
+
+/* The 1-D rule.  Segments of [z_lo, z_hi] (split at brk[], s-units), `npan` panels shared out in proportion to their
+ * lengths (at least one each), q Gauss-Legendre points per panel.  Calls f(s, ln s, weight) with weight = the Gamma(A,
+ * theta) density x ds.  Shared specification with csrc/quad_conv.hpp. */
+void co_conv_range(double A, double *zlo, double *zhi) {
+    const double Am = A + 2.0;
+    *zlo = fmin(-1.0, (log(1e-13) + co_lgam(A + 1.0)) / A);
+    *zhi = Am + sqrt(60.0 * Am) + 30.0;
+}
+typedef void (*co_node_fn)(double s, double ls, double wt, void *ctx);
+static void co_conv_rule(double A, double theta, const double *brk, int nbrk, int npan, int q, const double *xg,
+                         const double *wg, co_node_fn f, void *ctx) {
+    double zlo, zhi, edge[5];
+    co_conv_range(A, &zlo, &zhi);
+    int ne = 0;
+    edge[ne++] = zlo;
+    for (int i = 0; i < nbrk && i < 3; ++i) {
+        const double u = brk[i] / theta;
+        if (!(u > 1e-300) || u > 600.0) continue;
+        const double z = u > 30.0 ? u : log(expm1(u)); /* inverse of u = ln(1 + e^z) */
+        if (z > edge[ne - 1] && z < zhi) edge[ne++] = z;
+    }
+    edge[ne++] = zhi;
+    const double lgA = co_lgam(A), total = zhi - zlo;
+    for (int sgm = 0; sgm + 1 < ne; ++sgm) {
+        const double a = edge[sgm], len = edge[sgm + 1] - a;
+        int n = (int)ceil(npan * len / total);
+        if (n < 1) n = 1;
+        const double h = len / n;
+        for (int i = 0; i < n; ++i)
+            for (int g = 0; g < q; ++g) {
+                const double z = a + h * (i + 0.5) + 0.5 * h * xg[g];
+                const double u = co_softplus_q(z), lu = log(u);
+                const double wt = 0.5 * h * wg[g] * exp((A - 1.0) * lu - u - lgA) / (1.0 + exp(-z));
+                f(u * theta, lu + log(theta), wt, ctx);
+            }
+    }
+}
+
+typedef struct {
+    const co_dist *pdists;
+    int N, j;
+    const co_kernel_func *kf;
+    double k, T[3];
+} co_T_ctx;
+static void co_T_node(double s, double ls, double wt, void *v) {
+    co_T_ctx *c = (co_T_ctx *)v;
+    double h = wt * co_one_minus_w(c->pdists, c->N, c->j, s, ls);
+    if (c->kf->kind == CO_KF_LONG) h *= co_long_G(c->kf, c->k, s);
+    c->T[0] += h;
+    c->T[1] += h * s;
+    c->T[2] += h * s * s;
+}
+
+/* get_coal_ints(::NumericalCoalStyle, ...) in converged mode; Gamma / Exponential modes (Lognormal: -2).  q = points per
+ * panel, npan = panels of the 1-D rule.  out / scale as co_get_coal_ints_numerical_fixed. */
+int co_get_coal_ints_numerical_converged(const co_dist *pdists, int N, const co_kernel_func *kf, int q, int npan,
+                                         double *out, double *scale) {
+    if (N < 1 || N > CO_MAX_MODES || q < 1 || q > CO_MAX_QUAD || npan < 1) return -1;
+    int np[CO_MAX_MODES];
+    for (int i = 0; i < N; ++i) {
+        np[i] = co_nparams(pdists[i].type);
+        if (pdists[i].type != CO_GAMMA && pdists[i].type != CO_EXPONENTIAL) return -2;
+    }
+    double xg[CO_MAX_QUAD], wg[CO_MAX_QUAD];
+    co_gauss_legendre_rule(q, xg, wg);
+    double acc[CO_MAX_MODES][3], mag[CO_MAX_MODES][3];
+    memset(acc, 0, sizeof acc);
+    memset(mag, 0, sizeof mag);
+#define ADD(k_, m_, v_)            \
+    do {                           \
+        acc[k_][m_] += (v_);       \
+        mag[k_][m_] += fabs(v_);   \
+    } while (0)
+    static const double gam_of_kind[4] = {0.0, 1.0, 4.0 / 3.0, 0.0};
+    for (int j = 0; j < N; ++j) {
+        const co_dist *dj = &pdists[j];
+        const double kj = co_shape(dj);
+        /* self collisions: S_1 + S_2 - R_jj = (-s0 / 2, 0, sab); T_m moves to the next mode */
+        double m0, m1, m2, m3;
+        const double s0 = co_conv_pair(kf, dj, dj, 0, 0, &m0), sab = co_conv_pair(kf, dj, dj, 1, 1, &m1);
+#define ADDM(k_, m_, v_, mg_) \
+    do {                      \
+        acc[k_][m_] += (v_);  \
+        mag[k_][m_] += (mg_); \
+    } while (0)
+        ADDM(j, 0, -0.5 * s0, 0.5 * m0);
+        ADDM(j, 2, sab, m1);
+        if (j < N - 1 && dj->n > 0.0) {
+            co_T_ctx c = {pdists, N, j, kf, kj, {0.0, 0.0, 0.0}};
+            double pref;
+            if (kf->kind == CO_KF_LONG) {
+                const double brk[2] = {kf->p[0], 2.0 * kf->p[0]};
+                co_conv_rule(2.0 * kj, dj->theta, brk, 2, npan, q, xg, wg, co_T_node, &c);
+                pref = 0.5 * dj->n * dj->n;
+            } else { /* T_m = 1/2 s0 E_{Gamma(2k + gamma)}[s^m (1 - w)]: the kernel's homogeneity absorbed in the weight */
+                co_conv_rule(2.0 * kj + gam_of_kind[kf->kind], dj->theta, NULL, 0, npan, q, xg, wg, co_T_node, &c);
+                pref = 0.5 * s0;
+            }
+            for (int m = 0; m < 3; ++m) {
+                ADD(j, m, -pref * c.T[m]);
+                ADD(j + 1, m, pref * c.T[m]);
+            }
+        }
+        for (int k = j + 1; k < N; ++k) {
+            const co_dist *dk = &pdists[k];
+            const double p0 = co_conv_pair(kf, dj, dk, 0, 0, &m0), sa = co_conv_pair(kf, dj, dk, 1, 0, &m1),
+                         saa = co_conv_pair(kf, dj, dk, 2, 0, &m2), sab2 = co_conv_pair(kf, dj, dk, 1, 1, &m3);
+            ADDM(j, 0, -p0, m0);
+            ADDM(j, 1, -sa, m1);
+            ADDM(j, 2, -saa, m2);
+            ADDM(k, 1, sa, m1);
+            ADDM(k, 2, saa + 2.0 * sab2, m2 + 2.0 * m3);
+        }
+    }
+#undef ADDM
+#undef ADD
+    int o = 0;
+    for (int k = 0; k < N; ++k)
+        for (int m = 0; m < np[k]; ++m) {
+            out[o] = acc[k][m];
+            if (scale) scale[o] = mag[k][m];
+            ++o;
+        }
+    return o;
+}
+
+/* rhs_coal!(NumericalCoalStyle(), ...) in converged mode, one parcel / a batch (as co_rhs_coal_numerical[_batch]) */
+int co_rhs_coal_numerical_converged(const co_params *p, const co_kernel_func *kf_normalized, int q, int npan,
+                                    const double *mom, double *dmom, double *scale) {
+    double mom_norms[CO_MAX_MODES * 3], mn[CO_MAX_MODES * 3], ci[CO_MAX_MODES * 3];
+    co_dist pdists[CO_MAX_MODES];
+    int nmom = co_get_moments_normalizing_factors(p->NProgMoms, p->N, p->norms, mom_norms);
+    if (nmom < 0) return -1;
+    for (int i = 0; i < nmom; ++i) mn[i] = mom[i] / mom_norms[i];
+    int off = 0;
+    for (int i = 0; i < p->N; ++i) {
+        if (co_update_dist_from_moments(p->dist_type[i], mn + off, p->NProgMoms[i], p->k_range, &pdists[i]) < 0)
+            return -1;
+        off += p->NProgMoms[i];
+    }
+    if (co_get_coal_ints_numerical_converged(pdists, p->N, kf_normalized, q, npan, ci, scale) < 0) return -1;
+    for (int i = 0; i < nmom; ++i) {
+        dmom[i] = ci[i] * mom_norms[i];
+        if (scale) scale[i] *= mom_norms[i];
+    }
+    return nmom;
+}
+
+int co_rhs_coal_numerical_converged_batch(const co_params *p, const co_kernel_func *kf_normalized, int q, int npan,
+                                          long n_parcels, long ld, const double *mom, double *dmom, double *scale,
+                                          int n_threads) {
+    int nmom = 0;
+    for (int i = 0; i < p->N; ++i) nmom += p->NProgMoms[i];
+    int err = 0;
+#ifdef _OPENMP
+    if (n_threads < 1) n_threads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 64) num_threads(n_threads)
+#endif
+    for (long i = 0; i < n_parcels; ++i) {
+        double m[CO_MAX_MODES * 3], d[CO_MAX_MODES * 3], s[CO_MAX_MODES * 3];
+        for (int k = 0; k < nmom; ++k) m[k] = mom[(size_t)k * ld + i];
+        if (co_rhs_coal_numerical_converged(p, kf_normalized, q, npan, m, d, scale ? s : NULL) < 0) {
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+            err = 1;
+        }
+        for (int k = 0; k < nmom; ++k) {
+            dmom[(size_t)k * ld + i] = d[k];
+            if (scale) scale[(size_t)k * ld + i] = s[k];
+        }
+    }
+    (void)n_threads;
+    return err ? -1 : nmom;
+}

@@ -1,20 +1,24 @@
 #!/usr/bin/env python3
-"""Adaptive-quadrature restatement of get_coal_ints(::NumericalCoalStyle, ...) -- TEST INFRASTRUCTURE ONLY.
+"""Golden values of get_coal_ints(::NumericalCoalStyle, ...) by nested ADAPTIVE quadrature -- TEST INFRASTRUCTURE ONLY.
 
-The reference integrates the coalescence integrals of an arbitrary kernel function with nested adaptive
-Gauss-Kronrod quadrature, quadgk(...; rtol = 1e-8, maxevals = 1000) (src/Sources/Coalescence.jl:503-622, integrands
-:644-708, weighting_fn :624-642).  QuadGK.jl is not vendored and Julia is not installed, so this file restates the same
-nested integrals with scipy.integrate.quad (QUADPACK's adaptive Gauss-Kronrod, epsrel = 1e-8), function by function.
+The reference integrates the coalescence integrals of an arbitrary kernel function with nested adaptive Gauss-Kronrod
+quadrature, quadgk(...; rtol = 1e-8, maxevals = 1000) (src/Sources/Coalescence.jl:503-622, integrands :644-708,
+weighting_fn :624-642).  QuadGK.jl is not vendored and Julia is not installed; oracle/cloudy_oracle_adaptive.c restates the
+same nested integrals, integrand by integrand, with an adaptive (7, 15) Gauss-Kronrod rule run to 1e-10 (outer) / 1e-12
+(inner) and with the kernel function's break points given to the integrator.  This script runs it over the case list
+below and writes tests/golden/numerical_adaptive.json: the values every quadrature mode of the build is measured
+against (tests/test_numerical_oracle.py).  `--mpmath` additionally recomputes the cases marked `mp` with mpmath
+(30 digits, Gauss-Legendre with explicit interval splits at the same break points): an independent integrator, an
+independent special-function library, arbitrary precision -- the agreement is stored in the file (`mpmath_max_rel_diff`).
 
-It is far too slow for a batch (~1e5 density evaluations per integral, ~50 integrals per parcel) and exists for one
-purpose: to measure the DISCRETISATION error of the fixed Gauss rule that the HIP quadrature-kernel plans and
-oracle/cloudy_oracle_quad.c share.  `python oracle/numerical_adaptive.py` regenerates
-tests/golden/numerical_adaptive.json (a few parcels; runs in this build container only: scipy.integrate).
+Distributions are (type, n, theta, k) in normalised units (type 0 Exponential, 1 Gamma, 3 Lognormal with theta = mu,
+k = sigma); kernel functions (kind, params) normalised (KernelFunctions.jl:124-154).
 """
 import json
 import math
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -22,154 +26,159 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-RTOL = 1e-8
+E_HYDRO = 1e2 * math.pi * 1e6 * (1e-9) ** (4.0 / 3.0)         # coal_eff 1e2 pi with norms (1e6, 1e-9), box_gamma_mixture_hydro.jl:22
+LONG = [0.5236, 9.44e9 * 1e6 * 1e-18, 5.78 * 1e6 * 1e-9]      # box_gamma_mixture_long.jl:20, normalised
+LN2 = math.log(2.0)
+
+CASES = [
+    # the reference's own NumericalCoalStyle test configuration (test_Sources_correctness.jl:175-263)
+    dict(name="ref_test_3gamma_linear", kf=(1, [1.0]), pdists=[(1, 10.0, 10.0, 3.0), (1, 20.0, 100.0, 5.0), (1, 2.0, 500.0, 6.0)]),
+    dict(name="3gamma_hydrodynamic", kf=(2, [E_HYDRO]), pdists=[(1, 120.0, 0.02, 2.5), (1, 3.0, 4.0, 3.0), (1, 0.05, 300.0, 4.0)]),
+    dict(name="2gamma_long", kf=(3, LONG), pdists=[(1, 100.0, 0.05, 2.0), (1, 1.0, 5.0, 3.0)]),
+    dict(name="1gamma_hydrodynamic", kf=(2, [E_HYDRO]), pdists=[(1, 50.0, 0.3, 1.7)], mp=True),
+    # test/examples/Numerical/single_particle_exp.jl, n_particles_exp.jl (LinearKernelFunction, Exponential modes)
+    dict(name="1exp_linear", kf=(1, [5e-3]), pdists=[(0, 100.0, 0.1, 1.0)]),
+    dict(name="2exp_linear", kf=(1, [5e-3]), pdists=[(0, 100.0, 0.1, 1.0), (0, 1.0, 10.0, 1.0)], mp=True),
+    dict(name="1gamma_long_at_threshold", kf=(3, LONG), pdists=[(1, 30.0, 0.2, 2.0)]),
+    dict(name="2exp_hydrodynamic", kf=(2, [E_HYDRO]), pdists=[(0, 80.0, 0.1, 1.0), (0, 2.0, 6.0, 1.0)]),
+    dict(name="exp_gamma_hydro_overlapping", kf=(2, [E_HYDRO]), pdists=[(0, 40.0, 1.0, 1.0), (1, 10.0, 1.5, 2.0)]),
+    dict(name="2gamma_linear_shapes_far_apart", kf=(1, [5e-3]), pdists=[(1, 60.0, 0.4, 0.6), (1, 4.0, 1.2, 9.0)]),
+    dict(name="2gamma_hydro_small_shapes", kf=(2, [E_HYDRO]), pdists=[(1, 90.0, 0.5, 0.4), (1, 5.0, 20.0, 0.7)]),
+    dict(name="exp_2gamma_long", kf=(3, LONG), pdists=[(0, 200.0, 0.04, 1.0), (1, 8.0, 0.3, 2.5), (1, 0.2, 6.0, 4.0)]),
+    dict(name="2gamma_constant", kf=(0, [1e-4]), pdists=[(1, 100.0, 0.1, 2.0), (1, 3.0, 3.0, 3.5)]),
+    dict(name="3gamma_hydro_overlapping", kf=(2, [E_HYDRO]), pdists=[(1, 50.0, 0.5, 2.0), (1, 20.0, 1.0, 3.0), (1, 5.0, 2.5, 4.0)]),
+    dict(name="gamma_exp_long_threshold_in_rain", kf=(3, [4.0, LONG[1], LONG[2]]), pdists=[(1, 50.0, 0.3, 3.0), (0, 2.0, 5.0, 1.0)]),
+    # test/examples/Numerical/n_particles_lognorm.jl: Lognormal(n, log(mass_scale), log(2)), LinearKernelFunction
+    dict(name="1lognormal_linear", kf=(1, [5e-3]), pdists=[(3, 100.0, math.log(0.1), LN2)]),
+    dict(name="2lognormal_linear", kf=(1, [5e-3]), pdists=[(3, 100.0, math.log(0.1), LN2), (3, 1.0, math.log(10.0), LN2)]),
+    dict(name="3lognormal_linear", kf=(1, [5e-3]),
+         pdists=[(3, 100.0, math.log(0.1), LN2), (3, 10.0, math.log(1.0), LN2), (3, 1.0, math.log(10.0), LN2)]),
+    dict(name="1lognormal_hydrodynamic", kf=(2, [E_HYDRO]), pdists=[(3, 40.0, -0.5, 0.6)]),
+    dict(name="2lognormal_hydrodynamic", kf=(2, [E_HYDRO]), pdists=[(3, 40.0, -1.0, 0.5), (3, 2.0, 1.5, 0.833)]),
+    dict(name="lognormal_gamma_linear", kf=(1, [5e-3]), pdists=[(3, 80.0, -1.5, 0.7), (1, 2.0, 2.0, 3.0)]),
+    dict(name="gamma_lognormal_hydrodynamic", kf=(2, [E_HYDRO]), pdists=[(1, 60.0, 0.2, 2.0), (3, 1.5, 1.2, 0.6)]),
+    dict(name="1lognormal_long", kf=(3, LONG), pdists=[(3, 30.0, -1.0, 0.7)]),
+    dict(name="2lognormal_constant", kf=(0, [1e-4]), pdists=[(3, 100.0, -2.0, 0.833), (3, 3.0, 0.3, 0.833)]),
+    dict(name="gamma_lognormal_long", kf=(3, LONG), pdists=[(1, 100.0, 0.05, 2.0), (3, 1.0, 1.0, 0.5)]),
+    dict(name="gamma_lognormal_gamma_hydro", kf=(2, [E_HYDRO]), pdists=[(1, 100.0, 0.05, 3.0), (3, 5.0, 0.5, 0.5), (1, 0.1, 80.0, 4.0)]),
+]
 
 
-def _quad(f, a, b, points=None):
-    from scipy.integrate import quad
+# ---- mpmath cross-check of the Q, R, S matrices (the same nested integrals, another integrator and library) --------------
+def mp_matrices(case):
+    import mpmath as mp
 
-    return quad(f, a, b, epsrel=RTOL, epsabs=0.0, limit=400, points=points)[0]
-
-
-# ---- densities, ParticleDistributions.jl:323-388 (Gamma / Exponential / Lognormal) ---------------------------
-def density(d, x):
-    t, n, th, k = d
-    return n * normed_density(d, x)
-
-
-def normed_density(d, x):
-    t, n, th, k = d
-    if x <= 0.0:
-        return 0.0
-    if t == 0:    # Exponential
-        return math.exp(-x / th) / th
-    if t == 1:    # Gamma: x^(k-1) / theta^k / Gamma(k) * exp(-x/theta), evaluated in logs against overflow
-        return math.exp((k - 1.0) * math.log(x) - k * math.log(th) - math.lgamma(k) - x / th)
-    if t == 3:    # Lognormal (theta = mu, k = sigma)
-        l = math.log(x) - th
-        return math.exp(-(l * l) / (2.0 * k * k)) / (x * k * math.sqrt(2.0 * math.pi))
-    raise TypeError("no method normed_density_func for this distribution")
-
-
-def _scale(d):
-    """a length scale of the density (mean mass), to place the break points of the adaptive rule"""
-    t, n, th, k = d
-    return th if t == 0 else th * k if t == 1 else math.exp(th + 0.5 * k * k)
-
-
-# ---- KernelFunctions.jl:94-116 ----------------------------------------------------------------------------------
-def kernel(kf, x, y):
-    kind, p = kf
-    if kind == 0:
-        return p[0]
-    if kind == 1:
-        return p[0] * (x + y)
-    if kind == 2:
-        r1 = (3.0 / 4.0 / math.pi * x) ** (1.0 / 3.0)
-        r2 = (3.0 / 4.0 / math.pi * y) ** (1.0 / 3.0)
-        return p[0] * (r1 + r2) ** 2 * abs(math.pi * r1 * r1 - math.pi * r2 * r2)
-    if kind == 3:
-        if x < p[0] and y < p[0]:
-            return p[1] * (x * x + y * y)
-        return p[2] * (x + y)
-    raise ValueError(kind)
-
-
-# ---- Coalescence.jl:624-642 -------------------------------------------------------------------------------------
-def weighting_fn(x, k, pdists):
-    if k > len(pdists):
-        raise AssertionError("k out of range")
-    denom = sum(normed_density(d, x) for d in pdists)
-    num = sum(normed_density(d, x) for d in pdists[:k])
-    return 0.0 if denom == 0.0 else num / denom
-
-
-def _outer(f, scales):
-    """int_0^inf f: split at multiples of the density scales so the adaptive rule sees the structure"""
-    pts = sorted({s * m for s in scales for m in (0.05, 0.5, 2.0, 8.0, 40.0)})
-    total, a = 0.0, 0.0
-    for b in pts:
-        total += _quad(f, a, b)
-        a = b
-    from scipy.integrate import quad
-
-    total += quad(f, a, np.inf, epsrel=RTOL, epsabs=0.0, limit=400)[0]
-    return total
-
-
-# ---- integrands, Coalescence.jl:644-708 -------------------------------------------------------------------------
-def q_integrand_outer(x, j, k, kf, pdists, m):
-    inner = lambda y: 0.5 * kernel(kf, x - y, y) * (density(pdists[j], x - y) * density(pdists[k], y)
-                                                    + density(pdists[k], x - y) * density(pdists[j], y))
-    return x ** m * _quad(inner, 0.0, x, points=[0.5 * x])
-
-
-def r_integrand_outer(x, j, k, kf, pdists, m):
-    inner = lambda y: kernel(kf, x, y) * density(pdists[k], x) * density(pdists[j], y)
-    return x ** m * _outer(inner, [_scale(pdists[j]), x])
-
-
-def s_integrand_inner(x, k, kf, pdists, m):
-    inner = lambda y: 0.5 * kernel(kf, x - y, y) * density(pdists[k], x - y) * density(pdists[k], y)
-    return x ** m * _quad(inner, 0.0, x, points=[0.5 * x])
-
-
-def get_coal_ints_numerical(pdists, kf):
-    """Coalescence.jl:470-489 with the Q/R/S matrices of :503-622 (0-based indices here)."""
-    N = len(pdists)
-    np_ = [2 if d[0] in (0, 2) else 3 for d in pdists]
+    mp.mp.dps = 30
+    pd = case["pdists"]
+    kind, prm = case["kf"]
+    N = len(pd)
+    np_ = [2 if d[0] == 0 else 3 for d in pd]
     orders = max(np_)
-    sc = [_scale(d) for d in pdists]
+
+    def dens(d, x):  # ParticleDistributions.jl:323-388
+        t, n, th, k = d
+        if x <= 0:
+            return mp.mpf(0)
+        if t == 0:
+            return n * mp.exp(-x / th) / th
+        if t == 1:
+            return n * x ** (k - 1) / th ** k / mp.gamma(k) * mp.exp(-x / th)
+        return n * mp.exp(-(mp.log(x) - th) ** 2 / (2 * k * k)) / (x * k * mp.sqrt(2 * mp.pi))
+
+    def K(x, y):  # KernelFunctions.jl:94-116
+        if kind == 0:
+            return mp.mpf(prm[0])
+        if kind == 1:
+            return prm[0] * (x + y)
+        if kind == 2:
+            r1, r2 = (3 / (4 * mp.pi) * x) ** (mp.mpf(1) / 3), (3 / (4 * mp.pi) * y) ** (mp.mpf(1) / 3)
+            return prm[0] * (r1 + r2) ** 2 * abs(mp.pi * r1 ** 2 - mp.pi * r2 ** 2)
+        return prm[1] * (x * x + y * y) if (x < prm[0] and y < prm[0]) else prm[2] * (x + y)
+
+    def scale(d):
+        return d[2] if d[0] == 0 else d[2] * d[3] if d[0] == 1 else math.exp(d[2] + 0.5 * d[3] ** 2)
+
+    def ladder(ds):
+        return sorted({scale(d) * m for d in ds for m in (0.02, 0.1, 0.3, 1, 2, 4, 10, 30, 100)})
+
+    def outer(f, ds, extra=()):
+        pts = [0] + sorted(set(ladder(ds)) | set(extra)) + [mp.inf]
+        return mp.quad(f, pts)
+
+    def inner(f, x, ds):
+        pts = sorted({p for p in ([0.5 * x] + [q for d in ds for m in (0.02, 0.1, 0.4, 1, 2.5, 6, 15, 40)
+                                                for q in (scale(d) * m, x - scale(d) * m)]
+                                  + ([prm[0], x - prm[0]] if kind == 3 else [])) if 0 < p < x})
+        return mp.quad(f, [0] + pts + [x])
+
+    def wfn(x, k):
+        g = [dens(d, x) / d[1] for d in pd]
+        den = sum(g)
+        return mp.mpf(0) if den == 0 else sum(g[:k]) / den
+
     Q = np.zeros((orders, N, N))
     R = np.zeros((orders, N, N))
     S = np.zeros((orders, 2, N))
+    thr = [prm[0], 2 * prm[0]] if kind == 3 else []
     for m in range(orders):
         for k in range(N):
             for j in range(N):
                 if not (k <= j or np_[k] <= m):
-                    Q[m, j, k] = _outer(lambda x: q_integrand_outer(x, j, k, kf, pdists, m), [sc[j], sc[k]])
+                    Q[m, j, k] = outer(lambda x: x ** m * inner(
+                        lambda y: K(x - y, y) * (dens(pd[j], x - y) * dens(pd[k], y) + dens(pd[k], x - y) * dens(pd[j], y)) / 2,
+                        x, [pd[j], pd[k]]), [pd[j], pd[k]], thr)
                 if not np_[k] <= m:
-                    R[m, j, k] = _outer(lambda x: r_integrand_outer(x, j, k, kf, pdists, m), [sc[k]])
+                    R[m, j, k] = outer(lambda x: x ** m * dens(pd[k], x) * outer(
+                        lambda y: K(x, y) * dens(pd[j], y), [pd[j]], [x] + thr[:1]), [pd[k]], thr[:1])
         for k in range(N):
-            zero = (np_[k] <= m and np_[k + 1] <= m) if k < N - 1 else np_[k] <= m
-            if zero:
+            if (np_[k] <= m and np_[k + 1] <= m) if k < N - 1 else np_[k] <= m:
                 continue
-            S[m, 0, k] = _outer(lambda x: weighting_fn(x, k + 1, pdists) * s_integrand_inner(x, k, kf, pdists, m), sc)
-            S[m, 1, k] = _outer(lambda x: (1 - weighting_fn(x, k + 1, pdists)) * s_integrand_inner(x, k, kf, pdists, m), sc)
-    out = []
-    for k in range(N):
-        for m in range(np_[k]):
-            v = Q[m, :, k].sum() - R[m, :, k].sum() + S[m, 0, k]
-            if k > 0:
-                v += S[m, 1, k - 1]
-            out.append(v)
-    return np.array(out), Q, R, S
-
-
-CASES = [
-    # the reference's own NumericalCoalStyle test configuration (test_Sources_correctness.jl:175-263)
-    dict(name="ref_test_3gamma_linear", kf=(1, [1.0]),
-         pdists=[(1, 10.0, 10.0, 3.0), (1, 20.0, 100.0, 5.0), (1, 2.0, 500.0, 6.0)]),
-    dict(name="3gamma_hydrodynamic", kf=(2, [1e2 * math.pi * 1e6 * (1e-9) ** (4.0 / 3.0)]),   # normalised E = 1e2 pi, norms (1e6, 1e-9)
-         pdists=[(1, 120.0, 0.02, 2.5), (1, 3.0, 4.0, 3.0), (1, 0.05, 300.0, 4.0)]),
-    dict(name="2gamma_long", kf=(3, [0.5236, 9.44e9 * 1e6 * 1e-18, 5.78 * 1e6 * 1e-9]),       # box_gamma_mixture_long.jl:20, normalised
-         pdists=[(1, 100.0, 0.05, 2.0), (1, 1.0, 5.0, 3.0)]),
-    dict(name="1gamma_hydrodynamic", kf=(2, [1e2 * math.pi * 1e6 * (1e-9) ** (4.0 / 3.0)]), pdists=[(1, 50.0, 0.3, 1.7)]),
-]
+            si = lambda x: x ** m * inner(lambda y: K(x - y, y) * dens(pd[k], x - y) * dens(pd[k], y) / 2, x, [pd[k]])
+            S[m, 0, k] = outer(lambda x: wfn(x, k + 1) * si(x), pd, thr)
+            S[m, 1, k] = outer(lambda x: (1 - wfn(x, k + 1)) * si(x), pd, thr)
+    return Q, R, S
 
 
 def main():
-    out = {"_comment": "generated by oracle/numerical_adaptive.py (scipy.integrate.quad, epsrel 1e-8): "
-                       "get_coal_ints(::NumericalCoalStyle) of Coalescence.jl:470-708 by nested adaptive quadrature; "
-                       "pdists are (type, n, theta, k) in normalised units, kernel (kind, params) normalised",
-           "cases": []}
+    from oracle import cloudy_oracle as O
+
+    with_mp = "--mpmath" in sys.argv
+    out = {"_comment": "generated by oracle/numerical_adaptive.py: get_coal_ints(::NumericalCoalStyle) of Coalescence.jl:470-708 "
+                       "by nested adaptive Gauss-Kronrod quadrature (oracle/cloudy_oracle_adaptive.c, 1e-10 outer / 1e-12 "
+                       "inner); pdists are (type, n, theta, k) in normalised units, kernel (kind, params) normalised; "
+                       "Q, R: [order][j][k], S: [order][1|2][k]",
+           "eps_outer": 1e-10, "eps_inner": 1e-12, "cases": []}
     for c in CASES:
-        ci, Q, R, S = get_coal_ints_numerical(c["pdists"], c["kf"])
-        out["cases"].append(dict(name=c["name"], kf=list(c["kf"]), pdists=[list(d) for d in c["pdists"]],
-                                 coal_ints=ci.tolist(), Q=Q.tolist(), R=R.tolist(), S=S.tolist()))
-        print(c["name"], ci, flush=True)
+        t0 = time.time()
+        pd = [O.make_dist(int(d[0]), d[1], d[2], d[3]) for d in c["pdists"]]
+        kf = O.kernel_func(c["kf"][0], *c["kf"][1])
+        ci, Q, R, S = O.get_coal_ints_numerical_adaptive(pd, kf, 1e-10, 1e-12)
+        rec = dict(name=c["name"], kf=[c["kf"][0], list(c["kf"][1])], pdists=[list(d) for d in c["pdists"]],
+                   coal_ints=ci.tolist(), Q=Q.tolist(), R=R.tolist(), S=S.tolist())
+        msg = ""
+        if with_mp and c.get("mp"):
+            Qm, Rm, Sm = mp_matrices(c)
+            diffs = [np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)) if a.size else 0.0
+                     for a, b in ((Q, Qm), (R, Rm), (S, Sm))]
+            rec["mpmath_max_rel_diff"] = float(max(diffs))
+            msg = f" mpmath max rel diff {max(diffs):.2e}"
+        elif c.get("mp"):
+            prev = _previous(c["name"])
+            if prev is not None and "mpmath_max_rel_diff" in prev and np.allclose(prev["Q"], rec["Q"], rtol=1e-12, atol=0) \
+                    and np.allclose(prev["S"], rec["S"], rtol=1e-12, atol=0):
+                rec["mpmath_max_rel_diff"] = prev["mpmath_max_rel_diff"]   # unchanged values: keep the recorded check
+        out["cases"].append(rec)
+        print(f"{c['name']}: {time.time() - t0:.1f} s{msg}", ci, flush=True)
     with open(os.path.join(ROOT, "tests", "golden", "numerical_adaptive.json"), "w") as f:
         json.dump(out, f, indent=1)
+
+
+def _previous(name):
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "numerical_adaptive.json")) as f:
+            return next((c for c in json.load(f)["cases"] if c["name"] == name), None)
+    except Exception:
+        return None
 
 
 if __name__ == "__main__":

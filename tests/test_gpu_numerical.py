@@ -286,3 +286,139 @@ def test_cfg4q_full_size_properties(gpu_cloudy):
     rhs(dm, m, mk(3e2 * np.pi), 0.0)
     d3 = dm.to_numpy()
     assert np.max(np.abs(d3 - 3.0 * d) / np.maximum(np.abs(3.0 * d), 1e-300)) < 1e-12
+
+
+# ---- CONVERGED mode (quad_mode = CLOUDY_QUAD_CONVERGED, csrc/quad_conv.hpp) --------------------------------------------
+TOL_CONVERGED = 1e-11   # HIP vs the same-rule oracle; the oracle vs adaptive quadrature is a CPU test (<= 1e-8 of scale)
+
+
+def converged_case(cloudy, oracle, dist_types, kname, q=8):
+    par, op, okf = numerical_case(cloudy, oracle, dist_types, kname, q)
+    par.quad_mode = cloudy.QUAD_CONVERGED
+    return par, op, okf
+
+
+@pytest.mark.parametrize("dist_types,kname,q", [
+    ([1], "hydro", 8), ([1], "long", 8), ([0], "linear", 8), ([1], "constant", 4),
+    ([1, 1], "hydro", 8), ([1, 1], "long", 8), ([0, 1], "hydro", 8), ([1, 0], "linear", 6), ([0, 0], "long", 10),
+    ([1, 1, 1], "hydro", 8), ([1, 1, 1], "long", 8), ([1, 1, 1], "linear", 8), ([1, 0, 1], "hydro", 12),
+    ([1, 1, 1, 1], "hydro", 8), ([0, 1, 1, 1], "long", 6), ([1, 1], "hydro", 16), ([1, 1, 1], "constant", 2),
+])
+def test_converged_mode_vs_same_rule_oracle(gpu_cloudy, oracle, dist_types, kname, q):
+    """cloudy_coal_rhs of a CLOUDY_QUAD_CONVERGED plan (closed forms of the region integrals + one 1-D rule per mode for
+    the weighting_fn split) against oracle/cloudy_oracle_quad.c's restatement of the same formulas, incl. the ~1 %
+    degenerate parcels of the synthetic batch (clamped closures, empty modes)"""
+    cloudy = gpu_cloudy
+    par, op, okf = converged_case(cloudy, oracle, dist_types, kname, q)
+    mom = mixed_moments(dist_types, 1500, seed=300 + 7 * len(dist_types) + q)
+    got = run_numerical(cloudy, par, mom)
+    want, scale = oracle.rhs_coal_numerical_converged_batch(op, okf, q, mom, with_scale=True)
+    worst = assert_same_rule(got, want, scale, np.zeros_like(scale), f"converged {dist_types} {kname}", tol=TOL_CONVERGED)
+    print(f"converged {dist_types} {kname} q = {q}: max |hip - oracle| / scale = {worst:.2e}")
+    ok = np.all(np.isfinite(got), axis=0)
+    rows = np.cumsum([0] + [{0: 2, 1: 3}[t] for t in dist_types])[:-1] + 1
+    mass, mag = got[rows].sum(axis=0), scale[rows].sum(axis=0)
+    assert np.all(np.abs(mass[ok]) <= 1e-11 * mag[ok] + 1e-300)            # mass is conserved by the closed forms
+
+
+def test_converged_mode_jit_aot_params_and_float_planes(gpu_cloudy, oracle):
+    cloudy = gpu_cloudy
+    L = cloudy.lib()
+    par, op, okf = converged_case(cloudy, oracle, [1, 1, 1], "hydro")
+    mom = bench.synth_moments(3, 2000, seed=5)
+    want, scale = oracle.rhs_coal_numerical_converged_batch(op, okf, 8, mom, with_scale=True)
+    kf = par.kernel_func
+    jit = cloudy.NumericalPlan([1, 1, 1], kf, NORMS, 8, specialize=1, quad_mode=1)
+    aot = cloudy.NumericalPlan([1, 1, 1], kf, NORMS, 8, specialize=-1, quad_mode=1)
+    assert jit.specialized and not aot.specialized
+    m = dev(cloudy, mom)
+    for plan in (jit, aot):
+        dm = cloudy.DeviceArray.zeros(9, mom.shape[1])
+        cloudy._lib.check(L.cloudy_coal_rhs(plan.handle, mom.shape[1], mom.shape[1], m.ptr, dm.ptr, None))
+        assert_same_rule(dm.to_numpy(), want, scale, np.zeros_like(scale), "specialised" if plan is jit else "ahead of time",
+                         tol=TOL_CONVERGED)
+    # get_coal_ints(::NumericalCoalStyle, pdists, kernel_func) on (n, theta, k) planes, normalised units out
+    cd = cloudy.CoalescenceData(cloudy.CoalescenceTensor(np.array([[0.0]])), (3, 3, 3), (INF,) * 3, NORMS)
+    params = cloudy.DeviceArray.zeros(9, mom.shape[1])
+    cloudy._lib.check(L.cloudy_update_dist_from_moments(cd.plan([1, 1, 1]).handle, mom.shape[1], mom.shape[1], m.ptr,
+                                                        params.ptr, None))
+    ci = cloudy.get_coal_ints(cloudy.NumericalCoalStyle(), ([1, 1, 1], params), kf, quad_order=8, quad_mode=1).to_numpy()
+    norms9 = np.tile([NORMS[0], NORMS[0] * NORMS[1], NORMS[0] * NORMS[1] ** 2], 3)[:, None]
+    assert_same_rule(ci * norms9, want, scale, np.zeros_like(scale), "get_coal_ints on parameter planes", tol=TOL_CONVERGED)
+    got32 = run_numerical(cloudy, par, mom.astype(np.float32))
+    want32, scale32 = oracle.rhs_coal_numerical_converged_batch(op, okf, 8, mom.astype(np.float32).astype(np.float64),
+                                                                with_scale=True)
+    ok = np.isfinite(want32) & (np.abs(want32) < 3e38)
+    assert np.all(np.abs(got32[ok] - want32[ok]) <= 1e-6 * scale32[ok] + 1e-37)
+    # Lognormal modes are not served in converged mode
+    with pytest.raises(cloudy.CloudyError) as ei:
+        cloudy.NumericalPlan([1, 3], kf, NORMS, 8, quad_mode=1)
+    assert ei.value.code == cloudy._lib.EUNSUPPORTED
+    with pytest.raises(cloudy.CloudyError) as ei:
+        cloudy.NumericalPlan([1, 1], kf, NORMS, 8, quad_mode=2)
+    assert ei.value.code == cloudy._lib.EINVAL
+
+
+def test_converged_mode_reaches_the_adaptive_golden_values_on_the_device(gpu_cloudy):
+    """the device result itself (not only the oracle's) against nested adaptive quadrature of the reference integrals:
+    every Gamma / Exponential case of tests/golden/numerical_adaptive.json through cloudy_get_coal_ints, <= 1e-8 of scale
+    (north_star's tolerance for quadrature kernels against Coalescence.jl:503-708), with the 10-point rule beside it"""
+    import json
+    import os
+
+    cloudy = gpu_cloudy
+    with open(os.path.join(os.path.dirname(__file__), "golden", "numerical_adaptive.json")) as f:
+        gold = json.load(f)
+    mk = {0: cloudy.ConstantKernelFunction, 1: cloudy.LinearKernelFunction, 2: cloudy.HydrodynamicKernelFunction,
+          3: cloudy.LongKernelFunction}
+    n_cases, worst = 0, 0.0
+    for c in gold["cases"]:
+        types = [int(d[0]) for d in c["pdists"]]
+        if 3 in types:
+            continue
+        n_cases += 1
+        kf = mk[c["kf"][0]](*c["kf"][1])
+        prm = np.array([v for d in c["pdists"] for v in (d[1], d[2], d[3])])[:, None].repeat(4, axis=1)
+        Q, R, S = (np.abs(np.array(c[x])) for x in "QRS")
+        npm = [2 if t == 0 else 3 for t in types]
+        scale = np.concatenate([[Q[m, :, k].sum() + R[m, :, k].sum() + S[m, 0, k] + (S[m, 1, k - 1] if k else 0.0)
+                                 for m in range(npm[k])] for k in range(len(types))])
+        res = {}
+        for mode, q in ((1, 8), (0, 10)):
+            ci = cloudy.get_coal_ints(cloudy.NumericalCoalStyle(), (types, dev(cloudy, prm)), kf, quad_order=q,
+                                      quad_mode=mode).to_numpy()[:, 0]
+            res[mode] = float(np.max(np.abs(ci - np.array(c["coal_ints"])) / scale))
+        worst = max(worst, res[1])
+        print(f"{c['name']:36s} converged {res[1]:.1e}   10-point rule {res[0]:.1e}   (of scale, vs adaptive)")
+    assert n_cases >= 15 and worst <= 1e-8, worst
+
+
+def test_converged_mode_fused_ssprk33_and_full_size_properties(gpu_cloudy, oracle):
+    cloudy = gpu_cloudy
+    par, op, okf = converged_case(cloudy, oracle, [1, 1, 1], "hydro")
+    n = 200
+    mom = mixed_moments([1, 1, 1], n, seed=17)
+    dt, n_steps = 1e-3, 2
+    want = _ssprk33_host(lambda u: oracle.rhs_coal_numerical_converged_batch(op, okf, 8, u), mom, dt, n_steps)
+    u = dev(cloudy, mom)
+    cloudy.solve_ssprk33(par, u, dt, n_steps, coal_type=cloudy.NumericalCoalStyle())
+    got = u.to_numpy()
+    with np.errstate(all="ignore"):
+        ok = np.isfinite(want).all(axis=0) & (np.abs(want[:2]) <= 10 * np.abs(mom[:2]) + 1e-300).all(axis=0)
+    assert ok.sum() > 0.85 * n
+    ref = np.abs(mom) + np.abs(want)
+    assert (np.abs(got - want)[:, ok] / np.maximum(ref[:, ok], 1e-300)).max() < 1e-9
+    # BASELINE configs[3] at its per-GPU size: mass conservation, signs, bilinearity in number
+    n = 12_500_000
+    mom = bench.synth_moments(3, n, seed=bench.SEED, degenerate_frac=0.0)
+    rhs = cloudy.make_box_model_rhs(cloudy.NumericalCoalStyle())
+    m, dm = dev(cloudy, mom), cloudy.DeviceArray.zeros(9, n)
+    rhs(dm, m, par, 0.0)
+    d = dm.to_numpy()
+    assert np.all(np.isfinite(d))
+    mass, mag = d[1] + d[4] + d[7], np.abs(d[1]) + np.abs(d[4]) + np.abs(d[7])
+    assert np.max(np.abs(mass) / np.maximum(mag, 1e-300)) < 1e-9
+    assert np.all(d[0] + d[3] + d[6] <= 0.0) and np.all(d[0] <= 0.0) and np.all(d[8] >= 0.0)
+    rhs(dm, dev(cloudy, 2.0 * mom), par, 0.0)
+    d2 = dm.to_numpy()
+    assert np.max(np.abs(d2 - 4.0 * d) / np.maximum(np.abs(4.0 * d), 1e-300)) < 1e-12
