@@ -255,7 +255,7 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
                 const double b = KIND == KF_LONG ? (sg == 0 ? e1 : sg == 1 ? e2 : zhi) : zhi;
                 const double len = b - a;
                 if (!(len > 0.0)) continue;
-                int np = KIND == KF_LONG ? (int)ceil(double(kConvPanels) * len / total) : kConvPanels;
+                int np = KIND == KF_LONG ? (int)ceil(double(kConvPanels) * (len / total) - 1e-9) : kConvPanels;
                 np = np < 1 ? 1 : np;
                 const double h = len / double(np);
 #pragma unroll 1

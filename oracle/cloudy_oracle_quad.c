@@ -572,7 +572,7 @@ static void co_conv_rule(double A, double theta, const double *brk, int nbrk, in
     const double lgA = co_lgam(A), total = zhi - zlo;
     for (int sgm = 0; sgm + 1 < ne; ++sgm) {
         const double a = edge[sgm], len = edge[sgm + 1] - a;
-        int n = (int)ceil(npan * len / total);
+        int n = (int)ceil(npan * (len / total) - 1e-9); /* (a whole range is npan panels exactly, whatever the rounding) */
         if (n < 1) n = 1;
         const double h = len / n;
         for (int i = 0; i < n; ++i)

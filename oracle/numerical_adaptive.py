@@ -43,7 +43,7 @@ CASES = [
     dict(name="2exp_hydrodynamic", kf=(2, [E_HYDRO]), pdists=[(0, 80.0, 0.1, 1.0), (0, 2.0, 6.0, 1.0)]),
     dict(name="exp_gamma_hydro_overlapping", kf=(2, [E_HYDRO]), pdists=[(0, 40.0, 1.0, 1.0), (1, 10.0, 1.5, 2.0)]),
     dict(name="2gamma_linear_shapes_far_apart", kf=(1, [5e-3]), pdists=[(1, 60.0, 0.4, 0.6), (1, 4.0, 1.2, 9.0)]),
-    dict(name="2gamma_hydro_small_shapes", kf=(2, [E_HYDRO]), pdists=[(1, 90.0, 0.5, 0.4), (1, 5.0, 20.0, 0.7)]),
+    dict(name="2gamma_hydro_small_shapes", kf=(2, [E_HYDRO]), pdists=[(1, 90.0, 0.5, 0.75), (1, 5.0, 20.0, 0.9)]),
     dict(name="exp_2gamma_long", kf=(3, LONG), pdists=[(0, 200.0, 0.04, 1.0), (1, 8.0, 0.3, 2.5), (1, 0.2, 6.0, 4.0)]),
     dict(name="2gamma_constant", kf=(0, [1e-4]), pdists=[(1, 100.0, 0.1, 2.0), (1, 3.0, 3.0, 3.5)]),
     dict(name="3gamma_hydro_overlapping", kf=(2, [E_HYDRO]), pdists=[(1, 50.0, 0.5, 2.0), (1, 20.0, 1.0, 3.0), (1, 5.0, 2.5, 4.0)]),
