@@ -256,12 +256,6 @@ int build_host_plan(const cloudy_plan_desc *d, cloudy_plan **out, std::vector<do
             return fail(CLOUDY_EINVAL, "kernel_func %d is not a CoalescenceKernelFunction family", d->kernel_func);
         if (d->quad_mode != CLOUDY_QUAD_FIXED && d->quad_mode != CLOUDY_QUAD_CONVERGED)
             return fail(CLOUDY_EINVAL, "quad_mode %d is neither CLOUDY_QUAD_FIXED nor CLOUDY_QUAD_CONVERGED", d->quad_mode);
-        if (d->quad_mode == CLOUDY_QUAD_CONVERGED)
-            for (int i = 0; i < N; ++i)
-                if (d->dist_type[i] == CLOUDY_DIST_LOGNORMAL)
-                    return fail(CLOUDY_EUNSUPPORTED,
-                                "CLOUDY_QUAD_CONVERGED serves Gamma and Exponential modes (closed forms of the region "
-                                "integrals); a Lognormal mode needs CLOUDY_QUAD_FIXED");
         if (d->quad_order < 2 || d->quad_order > CLOUDY_MAX_QUAD)
             return fail(CLOUDY_EUNSUPPORTED, "quad_order %d outside 2..%d", d->quad_order, CLOUDY_MAX_QUAD);
         if (d->dtype == CLOUDY_F32_FAST)

@@ -24,7 +24,7 @@
 //
 // Measured against nested adaptive quadrature of the reference integrals (tests/golden/numerical_adaptive.json):
 // <= 1e-11 of scale, where the 10-point rule has 1e-3 ... 1e-2 (tests/test_numerical_oracle.py prints the table).
-// Same-rule CPU restatement: oracle/cloudy_oracle_quad.c (co_get_coal_ints_numerical_converged).
+// (The CPU test suite holds a same-rule restatement of these formulas and the adaptive values.)
 #pragma once
 #include "kernels.hpp"
 #include "quad.hpp"
@@ -69,19 +69,43 @@ __device__ __forceinline__ double inc_beta_from_D(double a, double b, double x, 
     return 1.0 - D * inc_beta_cf(b, a, omx) / b;
 }
 
-// per-mode quantities of the closed forms
+// per-mode quantities of the closed forms.  Lognormal modes keep (mu, sigma) in (th, k), as everywhere (kernels.hpp).
 struct ConvMode {
+    bool lognormal;
     double n, th, k, lnth, lgk;
     double Mi[5];  // M_0 .. M_4
     double Mt[4];  // M_{1/3}, M_{4/3}, M_{7/3}, M_{10/3}   (hydrodynamic)
     double pm[5];  // partial moments below the Long threshold, M_q P(k + q, x_t / theta)
 };
 
+__device__ __forceinline__ double conv_norm_cdf(double z) { return 0.5 * erfc(-z * 0.70710678118654752440); }
+
 template <int KIND>
-__device__ __forceinline__ void conv_mode(const QArgs &Q, double n, double th, double k, ConvMode &m) {
+__device__ __forceinline__ void conv_mode(const QArgs &Q, bool lognormal, double n, double th, double k, ConvMode &m) {
+    m.lognormal = lognormal;
     m.n = n;
     m.th = th;
     m.k = k;
+    if (lognormal) {  // wave-uniform.  M_q = n exp(q mu + q^2 sigma^2 / 2); partial moments M_q Phi((ln x_t - mu - q sigma^2) / sigma)
+        const double s2 = k * k;
+        m.lnth = th;
+        m.lgk = 0.0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) m.Mi[q] = n * exp_fin(fma(double(q), th, 0.5 * double(q * q) * s2));
+        if (KIND == KF_HYDRODYNAMIC) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double o = double(q) + 1.0 / 3.0;
+                m.Mt[q] = n * exp_fin(fma(o, th, 0.5 * (o * o) * s2));
+            }
+        }
+        if (KIND == KF_LONG) {
+            const double w0 = (log_pos(Q.kf[0]) - th) / k;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) m.pm[q] = m.Mi[q] * conv_norm_cdf(w0 - double(q) * k);
+        }
+        return;
+    }
     m.lnth = log_pos(th);
     m.lgk = lgamma_pos(k);
     m.Mi[0] = n;
@@ -109,9 +133,125 @@ __device__ __forceinline__ void conv_mode(const QArgs &Q, double n, double th, d
     }
 }
 
+// ln of the normed density at s (ls = ln s), ParticleDistributions.jl:363-388:
+//   Gamma family: a ls - b s - c,  a = k - 1, b = 1 / theta, c = ln Gamma(k) + k ln theta
+//   Lognormal:    -(ls - a)^2 b - ls - c,  a = mu, b = 1 / (2 sigma^2), c = ln(sigma sqrt(2 pi))
+struct ConvLogDensity {
+    bool lognormal;
+    double a, b, c;
+    __device__ __forceinline__ double operator()(double s, double ls) const {
+        if (lognormal) {
+            const double d = ls - a;
+            return -(d * d) * b - ls - c;
+        }
+        return fma(a, ls, -(s * b)) - c;
+    }
+};
+__device__ __forceinline__ ConvLogDensity conv_log_density(const ConvMode &m) {
+    ConvLogDensity l;
+    l.lognormal = m.lognormal;
+    if (m.lognormal) {
+        l.a = m.th;
+        l.b = 0.5 / (m.k * m.k);
+        l.c = log_pos(m.k * 2.5066282746310002);
+    } else {
+        l.a = m.k - 1.0;
+        l.b = 1.0 / m.th;
+        l.c = fma(m.k, m.lnth, m.lgk);
+    }
+    return l;
+}
+// 1 - weighting_fn(s, j + 1) from density ratios against mode j's own density (Coalescence.jl:624-642)
+template <int N>
+__device__ __forceinline__ double conv_one_minus_w(const ConvLogDensity (&lg)[N], int j, double s, double ls) {
+    double own = 0.0;
+#pragma unroll
+    for (int m = 0; m < N; ++m)
+        if (m == j) own = lg[m](s, ls);
+    double up = 0.0, den = 1.0;
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        if (m == j) continue;
+        const double rho = exp_fin(fmin(lg[m](s, ls) - own, 700.0));
+        den += rho;
+        if (m > j) up += rho;
+    }
+    return up / den;
+}
+
+// One node of the 1-D rule in z, s / theta = u = ln(1 + e^z): u, ln u and the Gamma(A) weight x dz (softplus and the
+// logistic Jacobian from one exponential)
+struct ConvNode {
+    double u, lu, wt;
+};
+__device__ __forceinline__ ConvNode conv_node(double z, double hw, double Am1, double lgA) {
+    const double ez = exp_fin(-fabs(z));
+    ConvNode nd;
+    nd.u = fmax(z, 0.0) + log1p(ez);
+    const double sig = (z >= 0.0 ? 1.0 : ez) / (1.0 + ez);
+    nd.lu = log_pos(nd.u);
+    nd.wt = hw * sig * exp_fin(fma(Am1, nd.lu, -nd.u) - lgA);
+    return nd;
+}
+__device__ __forceinline__ void conv_range(double A, double top, double lgA, double &zlo, double &zhi) {
+    // (ln 1e-13; the lower clamp serves closures clamped to k = eps, whose weight is ~ 1/u over hundreds of decades)
+    zlo = fmax(-690.0, fmin(-1.0, (-29.933606208922594 + (lgA + log_pos(A))) / A));
+    zhi = (A + top) + sqrt(60.0 * (A + top)) + 30.0;
+}
+
+// P(L'_c < G'_a) for a Gamma-family mode G and a Lognormal mode L on the grid a = f + i (f = 0, 1/3; i = 0..3),
+// c = 0, 1/3, 1, 4/3, 2, 7/3, 3, 10/3:  H[f][i][ci] = E_{Gamma(k_g + a, theta_g)}[Phi((ln x - mu - c sigma^2) / sigma)]
+// by the 1-D rule; the orders i share the nodes of the base shape: E_{Gamma(A0 + i)}[g] = E_{Gamma(A0)}[u^i g] / (A0)_i.
+__device__ __forceinline__ void conv_H_grid(const QArgs &Q, const double *__restrict__ tab, const ConvMode &G,
+                                            const ConvMode &L, double (&H)[2][4][8]) {
+    const int nq = Q.nq;
+    const double inv_sg = 1.0 / L.k;
+#pragma unroll 1
+    for (int f = 0; f < 2; ++f) {
+        const double A0 = G.k + (f ? 1.0 / 3.0 : 0.0), lgA = f ? lgamma_pos(A0) : G.lgk;
+        double zlo, zhi;
+        conv_range(A0, 4.0, lgA, zlo, zhi);
+        const double h = (zhi - zlo) * (1.0 / double(kConvPanels));
+        double acc[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[i][c] = 0.0;
+#pragma unroll 1
+        for (int ip = 0; ip < kConvPanels; ++ip) {
+            const double zc = fma(h, double(ip) + 0.5, zlo);
+#pragma unroll 1
+            for (int g = 0; g < nq; ++g) {
+                const ConvNode nd = conv_node(fma(0.5 * h, tab[g], zc), 0.5 * h * tab[nq + g], A0 - 1.0, lgA);
+                const double w0 = (nd.lu + G.lnth - L.th) * inv_sg;
+                double ph[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) ph[c] = conv_norm_cdf(w0 - (double(c >> 1) + ((c & 1) ? 1.0 / 3.0 : 0.0)) * L.k);
+                double wu = nd.wt;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc[i][c] = fma(wu, ph[c], acc[i][c]);
+                    wu *= nd.u;
+                }
+            }
+        }
+        double poch = 1.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double r = 1.0 / poch;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) H[f][i][c] = acc[i][c] * r;
+            poch *= A0 + double(i);
+        }
+    }
+}
+
 // The four pair integrals  int int x^p y^q K(x, y) f_j(x) f_k(y)  for (p, q) = (0,0), (1,0), (2,0), (1,1)  ->  s0, sa, saa, sab
+// (tab: the Gauss-Legendre table; used only by a Gamma-Lognormal pair of the hydrodynamic kernel)
 template <int KIND>
-__device__ __forceinline__ void conv_pair(const QArgs &Q, const ConvMode &J, const ConvMode &K, bool self, double (&out)[4]) {
+__device__ __forceinline__ void conv_pair(const QArgs &Q, const double *__restrict__ tab, const ConvMode &J, const ConvMode &K,
+                                          bool self, double (&out)[4]) {
     constexpr int PP[4] = {0, 1, 2, 1}, QQ[4] = {0, 0, 0, 1};
     if (KIND == KF_CONSTANT) {
 #pragma unroll
@@ -130,54 +270,91 @@ __device__ __forceinline__ void conv_pair(const QArgs &Q, const ConvMode &J, con
             out[i] = fma(ca, full - b1, cb * b2);
         }
     } else {
-        // hydrodynamic: sum_t c_t M^j_{p + al_t} M^k_{q + be_t} (2 I_z(k_k + q + be_t, k_j + p + al_t) - 1).  The 16
-        // incomplete betas lie on two grids of unit spacing, G1[i][i'] = I_z(k_k + i, k_j + 1/3 + i') and
-        // G2[i][i'] = I_z(k_k + 1/3 + i, k_j + i'): one continued fraction each, the rest by the recurrences
-        //   I(a, b+1) = I(a, b) + D(a, b) / b,   I(a+1, b) = I(a, b) - D(a, b) / a,   D = z^a (1-z)^b / B(a, b),
-        //   D(a, b+1) = D(a, b) (1-z) (a+b) / b,   D(a+1, b) = D(a, b) z (a+b) / a
-        // (absolute accuracy is what 2 I - 1 needs; the recurrences keep it).
-        const double z = self ? 0.5 : J.th / (J.th + K.th), omz = self ? 0.5 : K.th / (J.th + K.th);
-        const double lz = log_pos(z), lomz = log_pos(omz);
-        double G[2][3][4];
+        // hydrodynamic: sum_t c_t M^j_{p + al_t} M^k_{q + be_t} (2 P_t - 1),  P_t = P(Y' < X') for the size-biased laws
+        // X' (mode j, order p + al_t) and Y' (mode k, order q + be_t).  Pr[t][i] for the four terms
+        //   t = 0: (p + 4/3, q)   1: (p + 1, q + 1/3)   2: (p + 1/3, q + 1)   3: (p, q + 4/3)
+        double Pr[4][4];
+        if (!J.lognormal && !K.lognormal) {
+            // Gamma pair: P = I_z(k_k + b, k_j + a), z = theta_j / (theta_j + theta_k).  The 16 incomplete betas lie on two
+            // grids of unit spacing, G1[i][i'] = I_z(k_k + i, k_j + 1/3 + i') and G2[i][i'] = I_z(k_k + 1/3 + i, k_j + i'):
+            // one continued fraction each, the rest by the recurrences
+            //   I(a, b+1) = I(a, b) + D(a, b) / b,   I(a+1, b) = I(a, b) - D(a, b) / a,   D = z^a (1-z)^b / B(a, b),
+            //   D(a, b+1) = D(a, b) (1-z) (a+b) / b,   D(a+1, b) = D(a, b) z (a+b) / a
+            // (absolute accuracy is what 2 I - 1 needs; the recurrences keep it).
+            const double z = self ? 0.5 : J.th / (J.th + K.th), omz = self ? 0.5 : K.th / (J.th + K.th);
+            const double lz = log_pos(z), lomz = log_pos(omz);
+            double G[2][3][4];
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const double a0 = K.k + (g ? 1.0 / 3.0 : 0.0), b0 = J.k + (g ? 0.0 : 1.0 / 3.0);
-            const double lgb = g ? J.lgk : lgamma_pos(b0), lga = g ? lgamma_pos(a0) : K.lgk;
-            double D0 = exp_fin(fma(a0, lz, b0 * lomz) + (lgamma_pos(a0 + b0) - lga - lgb));
-            double I0 = inc_beta_from_D(a0, b0, z, omz, D0);
+            for (int g = 0; g < 2; ++g) {
+                const double a0 = K.k + (g ? 1.0 / 3.0 : 0.0), b0 = J.k + (g ? 0.0 : 1.0 / 3.0);
+                const double lgb = g ? J.lgk : lgamma_pos(b0), lga = g ? lgamma_pos(a0) : K.lgk;
+                double D0 = exp_fin(fma(a0, lz, b0 * lomz) + (lgamma_pos(a0 + b0) - lga - lgb));
+                double I0 = inc_beta_from_D(a0, b0, z, omz, D0);
 #pragma unroll
-            for (int ib = 0; ib < 4; ++ib) {  // walk along b at i = 0, then down the column in a
-                const double b = b0 + double(ib);
-                double I = I0, D = D0, a = a0;
+                for (int ib = 0; ib < 4; ++ib) {  // walk along b at i = 0, then down the column in a
+                    const double b = b0 + double(ib);
+                    double I = I0, D = D0, a = a0;
 #pragma unroll
-                for (int ia = 0; ia < 3; ++ia) {
-                    G[g][ia][ib] = I;
-                    I -= D / a;
-                    D *= z * (a + b) / a;
-                    a += 1.0;
+                    for (int ia = 0; ia < 3; ++ia) {
+                        G[g][ia][ib] = I;
+                        I -= D / a;
+                        D *= z * (a + b) / a;
+                        a += 1.0;
+                    }
+                    I0 += D0 / b;
+                    D0 *= omz * (a0 + b) / b;
                 }
-                I0 += D0 / b;
-                D0 *= omz * (a0 + b) / b;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = PP[i], q = QQ[i];
+                Pr[0][i] = G[0][q][p + 1];
+                Pr[1][i] = G[1][q][p + 1];
+                Pr[2][i] = G[0][q + 1][p];
+                Pr[3][i] = G[1][q + 1][p];
+            }
+        } else if (J.lognormal && K.lognormal) {
+            // ln X' - ln Y' ~ N(mu_j + a s_j^2 - mu_k - b s_k^2, s_j^2 + s_k^2)
+            const double sj2 = J.k * J.k, sk2 = K.k * K.k, inv = 1.0 / sqrt(sj2 + sk2), d0 = J.th - K.th;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const double p = double(PP[i]), q = double(QQ[i]);
+                Pr[0][i] = conv_norm_cdf((d0 + (p + 4.0 / 3.0) * sj2 - q * sk2) * inv);
+                Pr[1][i] = conv_norm_cdf((d0 + (p + 1.0) * sj2 - (q + 1.0 / 3.0) * sk2) * inv);
+                Pr[2][i] = conv_norm_cdf((d0 + (p + 1.0 / 3.0) * sj2 - (q + 1.0) * sk2) * inv);
+                Pr[3][i] = conv_norm_cdf((d0 + p * sj2 - (q + 4.0 / 3.0) * sk2) * inv);
+            }
+        } else {
+            // one Gamma-family and one Lognormal mode: P(L'_c < G'_a) by the 1-D rule (conv_H_grid); with the Lognormal mode
+            // as j, P(Y' < X') = 1 - P(X' < Y').  Gamma order a = i + (f ? 1/3 : 0), Lognormal order c -> index 2 floor(c) + (frac != 0)
+            double H[2][4][8];
+            const bool jg = !J.lognormal;
+            conv_H_grid(Q, tab, jg ? J : K, jg ? K : J, H);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = PP[i], q = QQ[i];
+                // term orders (x-order thirds, y-order thirds): t0 (3p+4, 3q), t1 (3p+3, 3q+1), t2 (3p+1, 3q+3), t3 (3p, 3q+4)
+                const int ox[4] = {3 * p + 4, 3 * p + 3, 3 * p + 1, 3 * p}, oy[4] = {3 * q, 3 * q + 1, 3 * q + 3, 3 * q + 4};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int og = jg ? ox[t] : oy[t], ol = jg ? oy[t] : ox[t];   // Gamma / Lognormal orders in thirds
+                    const double h = H[og % 3 ? 1 : 0][og / 3][2 * (ol / 3) + (ol % 3 ? 1 : 0)];
+                    Pr[t][i] = jg ? h : 1.0 - h;
+                }
             }
         }
         const double C = Q.kf[0] * 0.46526286817455001;  // pi (3 / (4 pi))^(4/3)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int p = PP[i], q = QQ[i];
-            double v = J.Mt[p + 1] * K.Mi[q] * fma(2.0, G[0][q][p + 1], -1.0);            // x^(4/3)
-            v = fma(2.0 * (J.Mi[p + 1] * K.Mt[q]), fma(2.0, G[1][q][p + 1], -1.0), v);    // 2 x y^(1/3)
-            v = fma(-2.0 * (J.Mt[p] * K.Mi[q + 1]), fma(2.0, G[0][q + 1][p], -1.0), v);   // -2 x^(1/3) y
-            v = fma(-(J.Mi[p] * K.Mt[q + 1]), fma(2.0, G[1][q + 1][p], -1.0), v);         // -y^(4/3)
+            double v = J.Mt[p + 1] * K.Mi[q] * fma(2.0, Pr[0][i], -1.0);               // x^(4/3)
+            v = fma(2.0 * (J.Mi[p + 1] * K.Mt[q]), fma(2.0, Pr[1][i], -1.0), v);       // 2 x y^(1/3)
+            v = fma(-2.0 * (J.Mt[p] * K.Mi[q + 1]), fma(2.0, Pr[2][i], -1.0), v);      // -2 x^(1/3) y
+            v = fma(-(J.Mi[p] * K.Mt[q + 1]), fma(2.0, Pr[3][i], -1.0), v);            // -y^(4/3)
             out[i] = C * v;
         }
     }
 }
-
-// ln of the normed density at s (ls = ln s) minus a constant per mode, Gamma family: (k - 1) ls - s / theta - c,
-// c = ln Gamma(k) + k ln theta
-struct ConvLogDensity {
-    double a, b, c;
-};
 
 // E_tau[K(s (1 - tau), s tau)], tau ~ Beta(k, k), Long kernel, for x_t < s < 2 x_t
 __device__ __forceinline__ double conv_long_G_mid(const QArgs &Q, double k, double lgB, double rB, double s) {
@@ -194,6 +371,68 @@ __device__ __forceinline__ double conv_long_G_mid(const QArgs &Q, double k, doub
     return fma(ca, s, fma(fma(cb, s2, -(ca * s)), P0, -2.0 * cb * s2 * P1));
 }
 
+// T_m of a LOGNORMAL mode j: the sum of two Lognormal variates has no closed law, so two variables remain,
+//   s = x + y,  t = ln(x / y):   f(x) f(y) dx dy = n^2 g(ln x) g(ln y) d(ln s) dt   (g: the normal density of ln x),
+//   T_m = 1/2 n^2 int d(ln s) s^m (1 - w(s)) G2(ln s),   G2 = 2 int_0^inf dt K(x, y) g(ln x) g(ln y),
+//   ln x = ln s - ln(1 + e^-t),  ln y = ln s - ln(1 + e^t)
+// -- weighting_fn stays outside the inner integral (a function of s alone) and the hydrodynamic kink sits on the boundary
+// t = 0.  Outer: kLnPanels1 panels over ln s in [mu - 8.5 sigma, mu + 8.5 sigma + (gamma + 2) sigma^2 + ln 2]; inner:
+// kLnPanels2 panels over t in [0, max(ln s - mu, 0) + 12 sigma]; nq Gauss-Legendre points per panel each.  (The Long kernel's
+// jumps x = x_t, y = x_t are curves in (ln s, t): that combination converges algebraically.)
+constexpr int kLnPanels1 = 64, kLnPanels2 = 12;
+template <int N, int KIND>
+__device__ __forceinline__ void conv_T_lognormal(const QArgs &Q, const double *__restrict__ tab, const ConvLogDensity (&lg)[N],
+                                                 int j, double n, double mu, double sg, double &T0, double &T1, double &T2) {
+    const int nq = Q.nq;
+    constexpr double gtop = KIND == KF_LINEAR ? 1.0 : KIND == KF_HYDRODYNAMIC ? 4.0 / 3.0 : KIND == KF_LONG ? 2.0 : 0.0;
+    const double L0 = fma(-8.5, sg, mu), L1 = mu + 8.5 * sg + (gtop + 2.0) * (sg * sg) + 0.6931471805599453;
+    const double h1 = (L1 - L0) * (1.0 / double(kLnPanels1)), c2 = 0.5 / (sg * sg), nrm = c2 * 0.3183098861837907;
+    T0 = T1 = T2 = 0.0;
+#pragma unroll 1
+    for (int i1 = 0; i1 < kLnPanels1; ++i1) {
+        const double lc = fma(h1, double(i1) + 0.5, L0);
+#pragma unroll 1
+        for (int g1 = 0; g1 < nq; ++g1) {
+            const double ls = fma(0.5 * h1, tab[g1], lc), s = exp_fin(ls);
+            const double Tm = fmax(ls - mu, 0.0) + 12.0 * sg, h2 = Tm * (1.0 / double(kLnPanels2));
+            double G2 = 0.0;
+#pragma unroll 1
+            for (int i2 = 0; i2 < kLnPanels2; ++i2) {
+                const double tc = h2 * (double(i2) + 0.5);
+#pragma unroll 1
+                for (int g2 = 0; g2 < nq; ++g2) {
+                    const double t = fma(0.5 * h2, tab[g2], tc);
+                    const double spm = log1p(exp_fin(-t));  // ln(1 + e^-t); ln(1 + e^t) = t + ln(1 + e^-t)
+                    const double lx = ls - spm, ly = ls - t - spm, dx = lx - mu, dy = ly - mu;
+                    double Kv;
+                    if (KIND == KF_CONSTANT) {
+                        Kv = Q.kf[0];
+                    } else if (KIND == KF_LINEAR) {
+                        Kv = Q.kf[0] * s;
+                    } else if (KIND == KF_HYDRODYNAMIC) {
+                        // K = C (xy)^(2/3) (e^(2t/3) + 2 e^(t/3) - 2 e^(-t/3) - e^(-2t/3)),  x / y = e^t
+                        const double e1 = exp_fin(t * (1.0 / 3.0)), r1 = 1.0 / e1;
+                        Kv = (Q.kf[0] * 0.46526286817455001) * exp_fin((2.0 / 3.0) * (lx + ly)) *
+                             (fma(e1, e1, 2.0 * e1) - fma(r1, r1, 2.0 * r1));
+                    } else {
+                        const double x = exp_fin(lx), y = exp_fin(ly);
+                        Kv = (x < Q.kf[0] && y < Q.kf[0]) ? Q.kf[1] * fma(x, x, y * y) : Q.kf[2] * (x + y);
+                    }
+                    G2 = fma((0.5 * h2 * tab[nq + g2]) * Kv, exp_fin(-fma(dx, dx, dy * dy) * c2), G2);
+                }
+            }
+            const double v = (0.5 * h1 * tab[nq + g1]) * conv_one_minus_w<N>(lg, j, s, ls) * (2.0 * nrm * G2);
+            T0 += v;
+            T1 = fma(v, s, T1);
+            T2 = fma(v * s, s, T2);
+        }
+    }
+    const double pref = 0.5 * (n * n);
+    T0 *= pref;
+    T1 *= pref;
+    T2 *= pref;
+}
+
 // get_coal_ints(::NumericalCoalStyle, ...) for the parcel of this lane in converged mode: acc[k][m], normalised units,
 // kernel constants INCLUDED.  tab: nq Gauss-Legendre nodes on [-1, 1], then nq weights.
 template <int N, int KIND>
@@ -202,103 +441,85 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
                                                double (&acc)[N][3]) {
     const int nq = Q.nq;
     ConvMode md[N];
-#pragma unroll
-    for (int m = 0; m < N; ++m) conv_mode<KIND>(Q, nn[m], th[m], kk[m], md[m]);
-#pragma unroll
-    for (int k = 0; k < N; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.0;
     ConvLogDensity lg[N];
 #pragma unroll
     for (int m = 0; m < N; ++m) {
-        lg[m].a = md[m].k - 1.0;
-        lg[m].b = 1.0 / md[m].th;
-        lg[m].c = fma(md[m].k, md[m].lnth, md[m].lgk);
+        conv_mode<KIND>(Q, A.dist_type[m] == DIST_LOGNORMAL, nn[m], th[m], kk[m], md[m]);
+        lg[m] = conv_log_density(md[m]);
     }
+#pragma unroll
+    for (int k = 0; k < N; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.0;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         double pr[4];
-        conv_pair<KIND>(Q, md[j], md[j], true, pr);
+        conv_pair<KIND>(Q, tab, md[j], md[j], true, pr);
         acc[j][0] -= 0.5 * pr[0];  // S_1 + S_2 - R_jj = (-s0 / 2, 0, sab)
         acc[j][2] += pr[3];
         if (j < N - 1 && md[j].n > 0.0) {
             // ---- T_m: the self collisions weighting_fn hands to mode j + 1
-            constexpr double gam = KIND == KF_LINEAR ? 1.0 : KIND == KF_HYDRODYNAMIC ? 4.0 / 3.0 : 0.0;
-            const double Ash = fma(2.0, md[j].k, gam);  // homogeneous kernels: T_m = 1/2 s0 E_{Gamma(2k + gamma)}[s^m (1 - w)]
-            const double pref = KIND == KF_LONG ? 0.5 * (md[j].n * md[j].n) : 0.5 * pr[0];
-            const double lgA = lgamma_pos(Ash), Am1 = Ash - 1.0;
-            const double zlo = fmin(-1.0, (-29.933606208922594 + (lgA + log_pos(Ash))) / Ash);  // ln 1e-13
-            const double zhi = (Ash + 2.0) + sqrt(60.0 * (Ash + 2.0)) + 30.0;
-            // segments: Long splits at s = x_t and 2 x_t (kinks of G); panels in proportion to the lengths
-            double e1 = zlo, e2 = zlo;
-            if (KIND == KF_LONG) {
-                const double u1 = Q.kf[0] / md[j].th, u2 = 2.0 * u1;
-                const double z1 = u1 > 30.0 ? u1 : log(expm1(u1)), z2 = u2 > 30.0 ? u2 : log(expm1(u2));
-                e1 = fmin(fmax(z1, zlo), zhi);
-                e2 = fmin(fmax(z2, e1), zhi);
-            }
-            const double total = zhi - zlo;
-            double lgB = 0.0, rB = 0.0;
-            if (KIND == KF_LONG) {
-                lgB = lgamma_pos(2.0 * md[j].k) - 2.0 * md[j].lgk;                      // -ln B(k, k)
-                rB = md[j].k / (2.0 * fma(2.0, md[j].k, 1.0));                          // B(k+1, k+1) / B(k, k)
-            }
-            ConvLogDensity dl[N];
-#pragma unroll
-            for (int m = 0; m < N; ++m) {
-                dl[m].a = lg[m].a - lg[j].a;
-                dl[m].b = lg[m].b - lg[j].b;
-                dl[m].c = lg[m].c - lg[j].c;
-            }
             double T0 = 0.0, T1 = 0.0, T2 = 0.0;
+            if (md[j].lognormal) {  // wave-uniform
+                conv_T_lognormal<N, KIND>(Q, tab, lg, j, md[j].n, md[j].th, md[j].k, T0, T1, T2);
+            } else {
+                constexpr double gam = KIND == KF_LINEAR ? 1.0 : KIND == KF_HYDRODYNAMIC ? 4.0 / 3.0 : 0.0;
+                const double Ash = fma(2.0, md[j].k, gam);  // homogeneous kernels: T_m = 1/2 s0 E_{Gamma(2k + gamma)}[s^m (1 - w)]
+                const double pref = KIND == KF_LONG ? 0.5 * (md[j].n * md[j].n) : 0.5 * pr[0];
+                const double lgA = lgamma_pos(Ash), Am1 = Ash - 1.0;
+                double zlo, zhi;
+                conv_range(Ash, 2.0, lgA, zlo, zhi);
+                // segments: Long splits at s = x_t and 2 x_t (kinks of G); panels in proportion to the lengths
+                double e1 = zlo, e2 = zlo;
+                if (KIND == KF_LONG) {
+                    const double u1 = Q.kf[0] / md[j].th, u2 = 2.0 * u1;
+                    const double z1 = u1 > 30.0 ? u1 : log(expm1(u1)), z2 = u2 > 30.0 ? u2 : log(expm1(u2));
+                    e1 = fmin(fmax(z1, zlo), zhi);
+                    e2 = fmin(fmax(z2, e1), zhi);
+                }
+                const double total = zhi - zlo;
+                double lgB = 0.0, rB = 0.0;
+                if (KIND == KF_LONG) {
+                    lgB = lgamma_pos(2.0 * md[j].k) - 2.0 * md[j].lgk;  // -ln B(k, k)
+                    rB = md[j].k / (2.0 * fma(2.0, md[j].k, 1.0));      // B(k+1, k+1) / B(k, k)
+                }
 #pragma unroll 1
-            for (int sg = 0; sg < (KIND == KF_LONG ? 3 : 1); ++sg) {
-                const double a = KIND == KF_LONG ? (sg == 0 ? zlo : sg == 1 ? e1 : e2) : zlo;
-                const double b = KIND == KF_LONG ? (sg == 0 ? e1 : sg == 1 ? e2 : zhi) : zhi;
-                const double len = b - a;
-                if (!(len > 0.0)) continue;
-                int np = KIND == KF_LONG ? (int)ceil(double(kConvPanels) * (len / total) - 1e-9) : kConvPanels;
-                np = np < 1 ? 1 : np;
-                const double h = len / double(np);
+                for (int sg = 0; sg < (KIND == KF_LONG ? 3 : 1); ++sg) {
+                    const double a = KIND == KF_LONG ? (sg == 0 ? zlo : sg == 1 ? e1 : e2) : zlo;
+                    const double b = KIND == KF_LONG ? (sg == 0 ? e1 : sg == 1 ? e2 : zhi) : zhi;
+                    const double len = b - a;
+                    if (!(len > 0.0)) continue;
+                    int np = KIND == KF_LONG ? (int)ceil(double(kConvPanels) * (len / total) - 1e-9) : kConvPanels;
+                    np = np < 1 ? 1 : np;
+                    const double h = len / double(np);
 #pragma unroll 1
-                for (int ip = 0; ip < np; ++ip) {
-                    const double zc = fma(h, double(ip) + 0.5, a);
+                    for (int ip = 0; ip < np; ++ip) {
+                        const double zc = fma(h, double(ip) + 0.5, a);
 #pragma unroll 1
-                    for (int g = 0; g < nq; ++g) {
-                        const double z = fma(0.5 * h, tab[g], zc);
-                        const double ez = exp_fin(-fabs(z));                  // softplus and logistic from one exponential
-                        const double u = fmax(z, 0.0) + log1p(ez);
-                        const double sig = (z >= 0.0 ? 1.0 : ez) / (1.0 + ez);
-                        const double lu = log_pos(u);
-                        const double wt = (0.5 * h * tab[nq + g]) * sig * exp_fin(fma(Am1, lu, -u) - lgA);
-                        const double s = u * md[j].th, ls = lu + md[j].lnth;
-                        double up = 0.0, den = 1.0;
-#pragma unroll
-                        for (int m = 0; m < N; ++m) {
-                            if (m == j) continue;
-                            const double rho = exp_fin(fmin(fma(dl[m].a, ls, fma(-dl[m].b, s, -dl[m].c)), 700.0));
-                            den += rho;
-                            if (m > j) up += rho;
+                        for (int g = 0; g < nq; ++g) {
+                            const ConvNode nd = conv_node(fma(0.5 * h, tab[g], zc), 0.5 * h * tab[nq + g], Am1, lgA);
+                            const double s = nd.u * md[j].th, ls = nd.lu + md[j].lnth;
+                            double hh = nd.wt * conv_one_minus_w<N>(lg, j, s, ls);
+                            if (KIND == KF_LONG) {
+                                const double xt = Q.kf[0];
+                                double G;
+                                if (sg == 0)
+                                    G = Q.kf[1] * (s * s) * ((md[j].k + 1.0) / fma(2.0, md[j].k, 1.0));
+                                else if (sg == 2)
+                                    G = Q.kf[2] * s;
+                                else
+                                    G = conv_long_G_mid(Q, md[j].k, lgB, rB,
+                                                        fmin(fmax(s, xt * (1.0 + 1e-15)), 2.0 * xt * (1.0 - 1e-15)));
+                                hh *= G;
+                            }
+                            T0 += hh;
+                            T1 = fma(hh, s, T1);
+                            T2 = fma(hh * s, s, T2);
                         }
-                        double hh = wt * (up / den);
-                        if (KIND == KF_LONG) {
-                            const double xt = Q.kf[0];
-                            double G;
-                            if (sg == 0)
-                                G = Q.kf[1] * (s * s) * ((md[j].k + 1.0) / fma(2.0, md[j].k, 1.0));
-                            else if (sg == 2)
-                                G = Q.kf[2] * s;
-                            else
-                                G = conv_long_G_mid(Q, md[j].k, lgB, rB, fmin(fmax(s, xt * (1.0 + 1e-15)), 2.0 * xt * (1.0 - 1e-15)));
-                            hh *= G;
-                        }
-                        T0 += hh;
-                        T1 = fma(hh, s, T1);
-                        T2 = fma(hh * s, s, T2);
                     }
                 }
+                T0 *= pref;
+                T1 *= pref;
+                T2 *= pref;
             }
-            T0 *= pref;
-            T1 *= pref;
-            T2 *= pref;
             acc[j][0] -= T0;
             acc[j][1] -= T1;
             acc[j][2] -= T2;
@@ -308,7 +529,7 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
         }
 #pragma unroll
         for (int k = j + 1; k < N; ++k) {
-            conv_pair<KIND>(Q, md[j], md[k], false, pr);
+            conv_pair<KIND>(Q, tab, md[j], md[k], false, pr);
             acc[j][0] -= pr[0];
             acc[j][1] -= pr[1];
             acc[j][2] -= pr[2];

@@ -463,15 +463,66 @@ int co_gauss_legendre_rule(int q, double *x, double *w) {
     return 0;
 }
 
-/* moment of order q (real) of a Gamma-family mode: n theta^q Gamma(k + q) / Gamma(k) */
+static double co_shape(const co_dist *d) { return d->type == CO_EXPONENTIAL ? 1.0 : d->k; }
+/* moment of order q (real): Gamma family n theta^q Gamma(k + q) / Gamma(k); Lognormal n exp(q mu + q^2 sigma^2 / 2) */
 static double co_gmom(const co_dist *d, double q) {
+    if (d->type == CO_LOGNORMAL) return d->n * exp(q * d->theta + 0.5 * q * q * d->k * d->k);
     const double k = d->type == CO_EXPONENTIAL ? 1.0 : d->k;
     return d->n * exp(q * log(d->theta) + co_lgam(k + q) - co_lgam(k));
 }
-static double co_shape(const co_dist *d) { return d->type == CO_EXPONENTIAL ? 1.0 : d->k; }
+static double co_conv_norm_cdf(double z) { return 0.5 * erfc(-z * 0.70710678118654752440); }
+/* partial moment below xt: Gamma family M_q P(k + q, xt / theta); Lognormal M_q Phi((ln xt - mu - q sigma^2) / sigma) */
+static double co_pmom(const co_dist *d, double q, double xt) {
+    if (d->type == CO_LOGNORMAL) return co_gmom(d, q) * co_conv_norm_cdf((log(xt) - d->theta - q * d->k * d->k) / d->k);
+    const double k = d->type == CO_EXPONENTIAL ? 1.0 : d->k;
+    return co_gmom(d, q) * co_gamma_inc_p(k + q, xt / d->theta);
+}
 
-/* int int x^p y^q K(x, y) f_j(x) f_k(y) dx dy over (0, inf)^2 for Gamma-family modes, in closed form */
-static double co_conv_pair(const co_kernel_func *kf, const co_dist *dj, const co_dist *dk, int p, int q, double *mag) {
+static void co_conv_rule_top(double A, double top, double theta, const double *brk, int nbrk, int npan, int q,
+                             const double *xg, const double *wg, void (*f)(double, double, double, void *), void *ctx);
+typedef struct {
+    double mu, sg, c, acc, inv_theta;
+    int i;
+} co_H_ctx;
+static void co_H_node(double s, double ls, double wt, void *v) {
+    co_H_ctx *h = (co_H_ctx *)v;
+    double xi = 1.0;
+    for (int t = 0; t < h->i; ++t) xi *= s * h->inv_theta;
+    h->acc += wt * xi * co_conv_norm_cdf((ls - h->mu) / h->sg - h->c * h->sg);
+}
+/* P(L'_c < G'_a): G' ~ Gamma(k_g + a, theta_g) (the size-biased law of order a of a Gamma-family mode), L' the size-biased
+ * law of order c of a Lognormal mode, = E_{G'}[Phi((ln G' - mu - c sigma^2) / sigma)] by the 1-D rule of this file.  As in
+ * the HIP kernel, the orders a = f + i (f = 0 or 1/3, i = 0..3) share the nodes of the base shape A0 = k_g + f:
+ * E_{Gamma(A0 + i)}[g] = E_{Gamma(A0)}[u^i g] / (A0)_i. */
+static double co_conv_H(const co_dist *g, double a, const co_dist *l, double c, int npan, int q, const double *xg,
+                        const double *wg) {
+    const int i = (int)floor(a + 1e-9);
+    const double f = (a - i) < 0.1 ? 0.0 : 1.0 / 3.0, A0 = co_shape(g) + f;
+    co_H_ctx h = {l->theta, l->k, c, 0.0, 1.0 / g->theta, i};
+    co_conv_rule_top(A0, 4.0, g->theta, NULL, 0, npan, q, xg, wg, co_H_node, &h);
+    double poch = 1.0;
+    for (int t = 0; t < i; ++t) poch *= A0 + t;
+    return h.acc / poch;
+}
+/* P(Y' < X'), X' / Y' the size-biased laws of orders a / b of modes j / k */
+static double co_conv_prob_less(const co_dist *dj, double a, const co_dist *dk, double b, int npan, int q,
+                                const double *xg, const double *wg) {
+    const int lj = dj->type == CO_LOGNORMAL, lk = dk->type == CO_LOGNORMAL;
+    if (!lj && !lk) {
+        const double z = dj->theta / (dj->theta + dk->theta), omz = dk->theta / (dj->theta + dk->theta);
+        return co_inc_beta_xy(co_shape(dk) + b, co_shape(dj) + a, z, omz);
+    }
+    if (lj && lk) /* ln X' - ln Y' ~ N(mu_j + a s_j^2 - mu_k - b s_k^2, s_j^2 + s_k^2) */
+        return co_conv_norm_cdf((dj->theta + a * dj->k * dj->k - dk->theta - b * dk->k * dk->k) /
+                                sqrt(dj->k * dj->k + dk->k * dk->k));
+    if (!lj) return co_conv_H(dj, a, dk, b, npan, q, xg, wg);      /* j Gamma, k Lognormal */
+    return 1.0 - co_conv_H(dk, b, dj, a, npan, q, xg, wg);         /* j Lognormal, k Gamma: 1 - P(X' < Y') */
+}
+
+/* int int x^p y^q K(x, y) f_j(x) f_k(y) dx dy over (0, inf)^2 (closed forms; a Gamma-Lognormal pair of the hydrodynamic
+ * kernel needs the 1-D rule for P(Y' < X')) */
+static double co_conv_pair(const co_kernel_func *kf, const co_dist *dj, const co_dist *dk, int p, int q, double *mag,
+                           int npan, int nq, const double *xg, const double *wg) {
     double dummy;
     if (!mag) mag = &dummy;
     switch (kf->kind) {
@@ -480,12 +531,10 @@ static double co_conv_pair(const co_kernel_func *kf, const co_dist *dj, const co
         return *mag = kf->p[0] * (co_gmom(dj, p + 1.0) * co_gmom(dk, q) + co_gmom(dj, p) * co_gmom(dk, q + 1.0));
     case CO_KF_HYDRODYNAMIC: {
         static const double term[4][3] = {{4.0 / 3.0, 0.0, 1.0}, {1.0, 1.0 / 3.0, 2.0}, {1.0 / 3.0, 1.0, -2.0}, {0.0, 4.0 / 3.0, -1.0}};
-        const double kj = co_shape(dj), kk = co_shape(dk);
-        const double z = dj->theta / (dj->theta + dk->theta), omz = dk->theta / (dj->theta + dk->theta);
         double tot = 0.0, m = 0.0;
         for (int t = 0; t < 4; ++t) {
             const double al = term[t][0], be = term[t][1];
-            const double I = co_inc_beta_xy(kk + q + be, kj + p + al, z, omz); /* P(Y' < X') */
+            const double I = co_conv_prob_less(dj, p + al, dk, q + be, npan, nq, xg, wg); /* P(Y' < X') */
             const double mm = term[t][2] * co_gmom(dj, p + al) * co_gmom(dk, q + be);
             tot += mm * (2.0 * I - 1.0);
             m += fabs(mm);
@@ -495,9 +544,8 @@ static double co_conv_pair(const co_kernel_func *kf, const co_dist *dj, const co
     }
     case CO_KF_LONG: {
         const double xt = kf->p[0], cb = kf->p[1], ca = kf->p[2];
-        const double kj = co_shape(dj), kk = co_shape(dk);
-#define PMJ(r) (co_gmom(dj, (r)) * co_gamma_inc_p(kj + (r), xt / dj->theta))
-#define PMK(r) (co_gmom(dk, (r)) * co_gamma_inc_p(kk + (r), xt / dk->theta))
+#define PMJ(r) co_pmom(dj, (r), xt)
+#define PMK(r) co_pmom(dk, (r), xt)
         const double full = ca * (co_gmom(dj, p + 1.0) * co_gmom(dk, q) + co_gmom(dj, p) * co_gmom(dk, q + 1.0));
         const double below2 = cb * (PMJ(p + 2.0) * PMK(q) + PMJ(p) * PMK(q + 2.0));
         const double below1 = ca * (PMJ(p + 1.0) * PMK(q) + PMJ(p) * PMK(q + 1.0));
@@ -550,16 +598,18 @@ static double co_long_G(const co_kernel_func *kf, double k, double s) {
 /* The 1-D rule.  Segments of [z_lo, z_hi] (split at brk[], s-units), `npan` panels shared out in proportion to their
  * lengths (at least one each), q Gauss-Legendre points per panel.  Calls f(s, ln s, weight) with weight = the Gamma(A,
  * theta) density x ds.  Shared specification with csrc/quad_conv.hpp. */
-void co_conv_range(double A, double *zlo, double *zhi) {
-    const double Am = A + 2.0;
-    *zlo = fmin(-1.0, (log(1e-13) + co_lgam(A + 1.0)) / A);
+/* top: the highest power of s the integrand multiplies the Gamma(A) weight with (2 for the T_m rule) */
+static void co_conv_range_top(double A, double top, double *zlo, double *zhi) {
+    const double Am = A + top;
+    *zlo = fmax(-690.0, fmin(-1.0, (log(1e-13) + co_lgam(A + 1.0)) / A)); /* (-690: shapes clamped to k = eps) */
     *zhi = Am + sqrt(60.0 * Am) + 30.0;
 }
+void co_conv_range(double A, double *zlo, double *zhi) { co_conv_range_top(A, 2.0, zlo, zhi); }
 typedef void (*co_node_fn)(double s, double ls, double wt, void *ctx);
-static void co_conv_rule(double A, double theta, const double *brk, int nbrk, int npan, int q, const double *xg,
-                         const double *wg, co_node_fn f, void *ctx) {
+static void co_conv_rule_top(double A, double top, double theta, const double *brk, int nbrk, int npan, int q,
+                             const double *xg, const double *wg, co_node_fn f, void *ctx) {
     double zlo, zhi, edge[5];
-    co_conv_range(A, &zlo, &zhi);
+    co_conv_range_top(A, top, &zlo, &zhi);
     int ne = 0;
     edge[ne++] = zlo;
     for (int i = 0; i < nbrk && i < 3; ++i) {
@@ -584,6 +634,10 @@ static void co_conv_rule(double A, double theta, const double *brk, int nbrk, in
             }
     }
 }
+static void co_conv_rule(double A, double theta, const double *brk, int nbrk, int npan, int q, const double *xg,
+                         const double *wg, co_node_fn f, void *ctx) {
+    co_conv_rule_top(A, 2.0, theta, brk, nbrk, npan, q, xg, wg, f, ctx);
+}
 
 typedef struct {
     const co_dist *pdists;
@@ -600,7 +654,48 @@ static void co_T_node(double s, double ls, double wt, void *v) {
     c->T[2] += h * s * s;
 }
 
-/* get_coal_ints(::NumericalCoalStyle, ...) in converged mode; Gamma / Exponential modes (Lognormal: -2).  q = points per
+/* ---- Lognormal modes (LN).  Moments and partial moments are closed forms (co_gmom, co_pmom); P(Y' < X') of the
+ * hydrodynamic terms is Phi(.) for a Lognormal pair and the 1-D rule for a Gamma-Lognormal pair (co_conv_prob_less).
+ * The sum of two Lognormal variates has no closed law, so T_m of a Lognormal mode keeps two variables,
+ *   s = x + y and t = ln(x / y):   f(x) f(y) dx dy = n^2 g(ln x) g(ln y) d(ln s) dt,   g = the normal density of ln x,
+ *   T_m = 1/2 n^2 int d(ln s) s^m (1 - w(s)) G2(ln s),   G2 = 2 int_0^inf dt K(x, y) g(ln x) g(ln y),
+ *   ln x = ln s - ln(1 + e^-t),  ln y = ln s - ln(1 + e^t)
+ * with weighting_fn outside the inner integral (it depends on s alone) and the kink of the hydrodynamic kernel on the
+ * boundary t = 0.  Outer: CO_LN_PAN1 panels over ln s in [mu - 8.5 sigma, mu + 8.5 sigma + (gamma + 2) sigma^2 + ln 2];
+ * inner: CO_LN_PAN2 panels over t in [0, max(ln s - mu, 0) + 12 sigma]; q Gauss-Legendre points per panel each.  (The
+ * Long kernel's jumps x = x_t, y = x_t are curves in (ln s, t): that combination converges algebraically.) */
+#define CO_LN_PAN1 64
+#define CO_LN_PAN2 12
+static void co_conv_T_lognormal(const co_dist *pdists, int N, int j, const co_kernel_func *kf, int q, const double *xg,
+                                const double *wg, double T[3]) {
+    static const double gtop[4] = {0.0, 1.0, 4.0 / 3.0, 2.0};
+    const double mu = pdists[j].theta, sg = pdists[j].k;
+    const double L0 = mu - 8.5 * sg, L1 = mu + 8.5 * sg + (gtop[kf->kind] + 2.0) * sg * sg + 0.6931471805599453;
+    const double h1 = (L1 - L0) / CO_LN_PAN1, c2 = 1.0 / (2.0 * sg * sg), nrm = c2 / M_PI; /* 1 / (2 pi sigma^2) */
+    T[0] = T[1] = T[2] = 0.0;
+    for (int i1 = 0; i1 < CO_LN_PAN1; ++i1)
+        for (int g1 = 0; g1 < q; ++g1) {
+            const double ls = L0 + h1 * (i1 + 0.5) + 0.5 * h1 * xg[g1], s = exp(ls);
+            const double Tm = fmax(ls - mu, 0.0) + 12.0 * sg, h2 = Tm / CO_LN_PAN2;
+            double G2 = 0.0;
+            for (int i2 = 0; i2 < CO_LN_PAN2; ++i2)
+                for (int g2 = 0; g2 < q; ++g2) {
+                    const double t = h2 * (i2 + 0.5) + 0.5 * h2 * xg[g2];
+                    const double spm = log1p(exp(-t)); /* softplus(-t); softplus(t) = t + softplus(-t) */
+                    const double lx = ls - spm, ly = ls - t - spm;
+                    const double dx = lx - mu, dy = ly - mu;
+                    G2 += (0.5 * h2 * wg[g2]) * co_kernel_func_eval(kf, exp(lx), exp(ly)) * exp(-(dx * dx + dy * dy) * c2);
+                }
+            const double v = (0.5 * h1 * wg[g1]) * co_one_minus_w(pdists, N, j, s, ls) * (2.0 * nrm * G2);
+            T[0] += v;
+            T[1] += v * s;
+            T[2] += v * s * s;
+        }
+    const double pref = 0.5 * pdists[j].n * pdists[j].n;
+    for (int m = 0; m < 3; ++m) T[m] *= pref;
+}
+
+/* get_coal_ints(::NumericalCoalStyle, ...) in converged mode; Gamma / Exponential / Lognormal modes.  q = points per
  * panel, npan = panels of the 1-D rule.  out / scale as co_get_coal_ints_numerical_fixed. */
 int co_get_coal_ints_numerical_converged(const co_dist *pdists, int N, const co_kernel_func *kf, int q, int npan,
                                          double *out, double *scale) {
@@ -608,7 +703,7 @@ int co_get_coal_ints_numerical_converged(const co_dist *pdists, int N, const co_
     int np[CO_MAX_MODES];
     for (int i = 0; i < N; ++i) {
         np[i] = co_nparams(pdists[i].type);
-        if (pdists[i].type != CO_GAMMA && pdists[i].type != CO_EXPONENTIAL) return -2;
+        if (pdists[i].type != CO_GAMMA && pdists[i].type != CO_EXPONENTIAL && pdists[i].type != CO_LOGNORMAL) return -2;
     }
     double xg[CO_MAX_QUAD], wg[CO_MAX_QUAD];
     co_gauss_legendre_rule(q, xg, wg);
@@ -626,7 +721,7 @@ int co_get_coal_ints_numerical_converged(const co_dist *pdists, int N, const co_
         const double kj = co_shape(dj);
         /* self collisions: S_1 + S_2 - R_jj = (-s0 / 2, 0, sab); T_m moves to the next mode */
         double m0, m1, m2, m3;
-        const double s0 = co_conv_pair(kf, dj, dj, 0, 0, &m0), sab = co_conv_pair(kf, dj, dj, 1, 1, &m1);
+        const double s0 = co_conv_pair(kf, dj, dj, 0, 0, &m0, npan, q, xg, wg), sab = co_conv_pair(kf, dj, dj, 1, 1, &m1, npan, q, xg, wg);
 #define ADDM(k_, m_, v_, mg_) \
     do {                      \
         acc[k_][m_] += (v_);  \
@@ -634,7 +729,14 @@ int co_get_coal_ints_numerical_converged(const co_dist *pdists, int N, const co_
     } while (0)
         ADDM(j, 0, -0.5 * s0, 0.5 * m0);
         ADDM(j, 2, sab, m1);
-        if (j < N - 1 && dj->n > 0.0) {
+        if (j < N - 1 && dj->n > 0.0 && dj->type == CO_LOGNORMAL) {
+            double T[3];
+            co_conv_T_lognormal(pdists, N, j, kf, q, xg, wg, T);
+            for (int m = 0; m < 3; ++m) {
+                ADD(j, m, -T[m]);
+                ADD(j + 1, m, T[m]);
+            }
+        } else if (j < N - 1 && dj->n > 0.0) {
             co_T_ctx c = {pdists, N, j, kf, kj, {0.0, 0.0, 0.0}};
             double pref;
             if (kf->kind == CO_KF_LONG) {
@@ -652,8 +754,8 @@ int co_get_coal_ints_numerical_converged(const co_dist *pdists, int N, const co_
         }
         for (int k = j + 1; k < N; ++k) {
             const co_dist *dk = &pdists[k];
-            const double p0 = co_conv_pair(kf, dj, dk, 0, 0, &m0), sa = co_conv_pair(kf, dj, dk, 1, 0, &m1),
-                         saa = co_conv_pair(kf, dj, dk, 2, 0, &m2), sab2 = co_conv_pair(kf, dj, dk, 1, 1, &m3);
+            const double p0 = co_conv_pair(kf, dj, dk, 0, 0, &m0, npan, q, xg, wg), sa = co_conv_pair(kf, dj, dk, 1, 0, &m1, npan, q, xg, wg),
+                         saa = co_conv_pair(kf, dj, dk, 2, 0, &m2, npan, q, xg, wg), sab2 = co_conv_pair(kf, dj, dk, 1, 1, &m3, npan, q, xg, wg);
             ADDM(j, 0, -p0, m0);
             ADDM(j, 1, -sa, m1);
             ADDM(j, 2, -saa, m2);
