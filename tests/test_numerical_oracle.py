@@ -199,7 +199,8 @@ def test_converged_mode_building_blocks(oracle):
             d = [O.make_dist(O.GAMMA, float(10 ** rng.uniform(-2, 3)), float(10 ** rng.uniform(-3, 2)), float(rng.uniform(0.05, 10.0)))]
             num, sc = O.get_coal_ints_numerical_converged(d, kf, 8, with_scale=True)
             ana = O.get_coal_ints(d, O.coalescence_data(c, [3], [INF]))
-            assert np.max(np.abs(num - ana) / sc) < 1e-13
+            # (mass: the closed forms have no term at all; the analytic path's Q - R + S cancels to rounding)
+            assert num[1] == 0.0 and np.max(np.abs(num - ana)[[0, 2]] / sc[[0, 2]]) < 1e-13
     # one mode, hydrodynamic: dM0 = -1/2 int int K f f by direct quadrature over the triangle y < x (K symmetric)
     d = O.make_dist(O.GAMMA, 3.0, 0.7, 2.2)
     kf = O.kernel_func(O.KF_HYDRODYNAMIC, 0.3)
