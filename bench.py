@@ -313,10 +313,9 @@ def _run_workload(pkg, name, n_parcels, steps, warmup, rank, dist, torch):
     # (With ~1 % degenerate parcels in the batch, whose clamped closures give tendencies up to 1e30, the batch sum is
     # dominated by a few parcels and the residual is below one ulp of it; the per-parcel figure is the sharper one.)
     gross = abs(float(gsums[1]))
-    ns = min(100_000, n_parcels)
-    ms_, dms_ = pkg.DeviceArray.from_numpy(wl["mom"][:, :ns]), pkg.DeviceArray.zeros(plan.nmom, ns)
-    rhs(dms_, ms_, wl["par"], 0.0)
-    ds = dms_.to_numpy()
+    # (a slice of the full-size result: no extra, smaller launch of the same kernel -- the rocprofv3 stats of a kernel name
+    # then average launches of ONE size)
+    ds = dm.columns_to_numpy(min(100_000, n_parcels))
     nm = plan.nmom // 3
     net = sum(ds[3 * i + 1] for i in range(nm))
     mag = sum(np.abs(ds[3 * i + 1]) for i in range(nm))
@@ -444,6 +443,45 @@ def _cpu_baseline(name, target_seconds=12.0):
                                              "1 CPU of the reference's CI; upper bounds, not measurements)")
 
 
+CLOCK_HZ = 2.4e9          # MI355X peak engine clock (MI355X_MICROARCH.md)
+N_SIMD = 256 * 4          # 256 CUs x 4 SIMDs; one wave64 VALU instruction occupies a SIMD's 16 lanes for 4 cycles
+
+
+class _EventTimer:
+    """milliseconds of everything launched on the default stream inside the `with` block, by HIP events recorded on that
+    stream (cloudy_timer_begin / cloudy_timer_end)"""
+
+    def __init__(self, pkg):
+        self.pkg, self.ms = pkg, None
+
+    def __enter__(self):
+        import ctypes as C
+
+        self._t = C.c_void_p()
+        self.pkg._lib.check(self.pkg.lib().cloudy_timer_begin(None, C.byref(self._t)))
+        return self
+
+    def __exit__(self, *exc):
+        import ctypes as C
+
+        ms = C.c_float()
+        self.pkg._lib.check(self.pkg.lib().cloudy_timer_end(self._t, None, C.byref(ms)))
+        self.ms = float(ms.value)
+        return False
+
+
+def _hbm_roofline(kernel, bytes_per_launch, kernel_ms, measured=None, key=None):
+    """HBM roofline block of a streaming variant: algorithmic bytes per launch over the HIP-event launch duration"""
+    gbs = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
+    out = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+           "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+           "traffic_from_profiles": None}
+    k = ((measured or {}).get("kernels") or {}).get(key) if key else None
+    if k and k.get("hbm_bytes_per_launch"):
+        out["traffic_from_profiles"] = k["hbm_bytes_per_launch"]
+    return out
+
+
 def _valu_roofline(measured, key, n_items, kernel_ms):
     """fp64-VALU roofline block of a compute-bound variant: useful fp64 flops per item from the committed rocprofv3
     counters (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 x 64 x active-lane fraction, tools/summarize_profiles.py) over the kernel
@@ -452,11 +490,18 @@ def _valu_roofline(measured, key, n_items, kernel_ms):
     if not k or not kernel_ms:
         return None
     tf = k["fp64_flops_per_item"] * n_items / (kernel_ms * 1e-3) / 1e12
+    # second figure: issued VALU instructions against the issue limit of the SIMDs (a wave64 instruction holds a SIMD for
+    # 4 cycles): "0.34 of the FMA peak" next to "0.9 of the issue slots" says the kernel is instruction-count bound
+    wave_insts = k["valu_insts_per_item"] * n_items / 64.0
+    issue = wave_insts * 4.0 / (N_SIMD * CLOCK_HZ * kernel_ms * 1e-3)
     return {"bound": "fp64-valu", "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": tf / FP64_VALU_PEAK_TFLOPS, "kernel": k["kernel"], "fp64_flops_per_item": k["fp64_flops_per_item"],
+            "frac": tf / FP64_VALU_PEAK_TFLOPS, "kernel": k["kernel"], "kernel_ms": kernel_ms,
+            "fp64_flops_per_item": k["fp64_flops_per_item"],
             "valu_insts_per_item": k["valu_insts_per_item"], "active_lane_fraction": k["lane_utilisation"],
-            "note": "flops per item and lane utilisation from the committed counter passes (profiles/measured_latest.json); "
-                    "kernel time from this run"}
+            "valu_issue_frac": issue,
+            "note": "flops / VALU instructions per item and lane utilisation from the committed counter passes "
+                    "(profiles/measured_latest.json); kernel time from this run by HIP events; valu_issue_frac = issued "
+                    "wave64 VALU instructions x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel time)"}
 
 
 CFG4Q_PARCELS = 12_500_000
@@ -502,11 +547,10 @@ def _cfg4q_variant(pkg, rank, world, measured, n=CFG4Q_PARCELS, reps=3):
     dt_step = 1e-3
     pkg._lib.check(L.cloudy_ssprk33_steps(plan.handle, n, n, m.ptr, dm.ptr, C.c_double(dt_step), 1, None))
     pkg._lib.check(L.cloudy_stream_synchronize(None))
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        pkg._lib.check(L.cloudy_ssprk33_steps(plan.handle, n, n, m.ptr, dm.ptr, C.c_double(dt_step), 1, None))
-    pkg._lib.check(L.cloudy_stream_synchronize(None))
-    dts = (time.perf_counter() - t0) / reps
+    with _EventTimer(pkg) as tm:
+        for _ in range(reps):
+            pkg._lib.check(L.cloudy_ssprk33_steps(plan.handle, n, n, m.ptr, dm.ptr, C.c_double(dt_step), 1, None))
+    dts = tm.ms * 1e-3 / reps
     out["fused_ssprk33"] = {"workload": "cloudy_ssprk33_steps on the same plan and batch: 1 SSPRK33 step (3 RHS evaluations) per call",
                             "value": 3 * n * world / dts, "unit": "parcel-RHS/s", "ms_per_call": 1e3 * dts}
     return out
@@ -593,7 +637,10 @@ def _headline_roofline(workload, plan, n_local, nmom, event_ms, per_rank_ms, tra
     if plan.all_inf:
         a = hbm(event_ms)
         return {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
-                "traffic": traffic, "kernel": label, "kernel_ms": event_ms,
+                "traffic": traffic,
+                "traffic_source": "2 x FETCH_SIZE + WRITE_SIZE of this kernel at this batch size from the committed rocprofv3 "
+                                  "--pmc passes (profiles/measured_latest.json); not collected in this run",
+                "kernel": label, "kernel_ms": event_ms,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "per_rank": [{"rank": r, "kernel_ms": ms, "achieved": hbm(ms), "frac": hbm(ms) / HBM_PEAK_GBS}
                              for r, ms in enumerate(per_rank_ms)]}
@@ -698,12 +745,11 @@ def main():
         n_steps, dt = 4, 1e-3
         pkg._lib.check(L.cloudy_ssprk33_steps(plan.handle, n_local, n_local, u.ptr, u.ptr, C.c_double(dt), n_steps, None))
         pkg._lib.check(L.cloudy_stream_synchronize(None))
-        t0 = time.perf_counter()
         reps = 5
-        for _ in range(reps):
-            pkg._lib.check(L.cloudy_ssprk33_steps(plan.handle, n_local, n_local, u.ptr, u.ptr, C.c_double(dt), n_steps, None))
-        pkg._lib.check(L.cloudy_stream_synchronize(None))
-        dts = (time.perf_counter() - t0) / reps
+        with _EventTimer(pkg) as tm:
+            for _ in range(reps):
+                pkg._lib.check(L.cloudy_ssprk33_steps(plan.handle, n_local, n_local, u.ptr, u.ptr, C.c_double(dt), n_steps, None))
+        dts = tm.ms * 1e-3 / reps
         variants["cfg3a_fused_ssprk33"] = {
             "workload": f"cloudy_ssprk33_steps: {n_steps} SSPRK33 steps per call (3 RHS evaluations each) with the state "
                         "in registers; one read + one write of the state per call",
@@ -729,6 +775,8 @@ def main():
             "value": n_local * world / (ms_a * 1e-3), "unit": "parcel-RHS/s", "kernel_ms": ms_a,
             "hbm_GBs": bytes_per_eval * n_local / (ms_a * 1e-3) / 1e9,
             "headline_plan_specialized": bool(res["plan"].specialized),
+            "roofline": _hbm_roofline("coal_rhs_allinf2_kernel<2, 3, double>", bytes_per_eval * n_local, ms_a, measured,
+                                      "cfg3a_aot_kernels"),
         }
         del m_a, dm_a
 
@@ -745,6 +793,7 @@ def main():
             "workload": "cfg3a with CLOUDY_F32 planes (float in HBM, fp64 arithmetic): BASELINE configs[4] fp32 path",
             "value": n_local * world / (ms32 * 1e-3), "unit": "parcel-RHS/s", "kernel_ms": ms32,
             "hbm_GBs": 2 * nmom * 4 * n_local / (ms32 * 1e-3) / 1e9,
+            "roofline": _hbm_roofline("cloudy_jit_allinf2_n2p3_f32", 2 * nmom * 4 * n_local, ms32, measured, "cfg3a_f32_planes"),
         }
         # CLOUDY_F32_FAST on the threshold workload (single-precision Simpson / incomplete-gamma pass)
         wlb = make_workload("cfg3b", n_local, seed=SEED + 1000 * rank)
@@ -758,6 +807,9 @@ def main():
                         "in tests/test_gpu_parity.py)",
             "value": n_local * world / (msf * 1e-3), "unit": "parcel-RHS/s", "kernel_ms": msf,
         }
+        rl = _valu_roofline(measured, "cfg3b_f32_fast", n_local, msf)
+        if rl:
+            variants["cfg3b_f32_fast"]["roofline"] = rl
         del m32, dm32
 
     if more_variants:
@@ -780,6 +832,8 @@ def main():
                 "hbm_GBs": 2 * planv.nmom * 8 * vn / (msv * 1e-3) / 1e9,
             }
             rl = _valu_roofline(measured, vname, vn, msv)
+            if vname == "cfg2":   # thresholds Inf: streaming, 48 B per parcel (cache resident at 1e6 parcels)
+                rl = _hbm_roofline(_kernel_label(planv, 1, 2).split(" ")[0], 2 * planv.nmom * 8 * vn, msv, measured, "cfg2")
             if rl:
                 variants[vname]["roofline"] = rl
             del mv, dmv
@@ -798,18 +852,20 @@ def main():
                 pkg._lib.check(L.cloudy_rainshaft_sources(plan5.handle, n5, n5, m5.ptr, cs5.ptr, sf5.ptr, None))
             pkg._lib.check(L.cloudy_stream_synchronize(None))
             reps = 5
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                pkg._lib.check(L.cloudy_rainshaft_sources(plan5.handle, n5, n5, m5.ptr, cs5.ptr, sf5.ptr, None))
-            pkg._lib.check(L.cloudy_stream_synchronize(None))
-            ms5 = 1e3 * (time.perf_counter() - t0) / reps
+            with _EventTimer(pkg) as tm:
+                for _ in range(reps):
+                    pkg._lib.check(L.cloudy_rainshaft_sources(plan5.handle, n5, n5, m5.ptr, cs5.ptr, sf5.ptr, None))
+            ms5 = tm.ms / reps
             variants[vname] = {
                 "workload": f"cfg5: {n5} cells/GPU, cfg3b tensors and thresholds + sedimentation flux vel={vel}, "
                             "float planes in HBM (6 moments in, 6 coalescence sources + 6 fluxes out = 72 B/cell), "
                             + ("fp64 arithmetic" if dt_code == 1 else "single-precision Simpson pass")
                             + "; checked against the fp64 oracle in tests/test_gpu_parity.py",
-                "value": n5 * world / (ms5 * 1e-3), "unit": "cell-RHS/s", "launch_ms_wall": ms5,
+                "value": n5 * world / (ms5 * 1e-3), "unit": "cell-RHS/s", "kernel_ms": ms5,
             }
+            rl = _valu_roofline(measured, vname, n5, ms5)
+            if rl:
+                variants[vname]["roofline"] = rl
         del m5, cs5, sf5
         # the rainshaft drivers' time integration fused into one launch (cloudy_rainshaft_ssprk33_steps), fp64:
         # (i) throughput on 5e5 independent columns of 20 cells, (ii) latency of the reference example itself
@@ -827,9 +883,9 @@ def main():
             pkg._lib.check(L.cloudy_stream_synchronize(None))
 
         _col_steps(ncol, nst, 1e-3)
-        t0 = time.perf_counter()
-        _col_steps(ncol, nst, 1e-3)
-        msr = 1e3 * (time.perf_counter() - t0)
+        with _EventTimer(pkg) as tm:
+            _col_steps(ncol, nst, 1e-3)
+        msr = tm.ms
         variants["rainshaft_ssprk33_columns"] = {
             "workload": f"cloudy_rainshaft_ssprk33_steps: {ncol} columns x {nz} cells/GPU, cfg3b tensors and thresholds "
                         f"+ sedimentation vel={vel}, {nst} SSPRK33 steps (3 RHS evaluations each) in one launch, fp64",

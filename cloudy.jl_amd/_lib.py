@@ -103,6 +103,8 @@ SYMBOLS = {
     "cloudy_memset": (_i, [_vp, _i, _sz, _vp]),
     "cloudy_stream_synchronize": (_i, [_vp]),
     "cloudy_time_coal_rhs": (_i, [_vp, _sz, _sz, _vp, _vp, _vp, _i, C.POINTER(C.c_float)]),
+    "cloudy_timer_begin": (_i, [_vp, C.POINTER(_vp)]),
+    "cloudy_timer_end": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
     "cloudy_last_error": (C.c_char_p, []),
     "cloudy_version": (_i, []),
 }

@@ -911,6 +911,36 @@ int cloudy_time_coal_rhs(const cloudy_plan *plan, size_t n, size_t ld, const voi
     return CLOUDY_OK;
 }
 
+int cloudy_timer_begin(void *stream, void **timer_out) {
+    if (!timer_out) return fail(CLOUDY_EINVAL, "timer_out is NULL");
+    hipEvent_t *ev = new (std::nothrow) hipEvent_t[2];
+    if (!ev) return fail(CLOUDY_ENOMEM, "out of host memory");
+    hipError_t e = hipEventCreate(&ev[0]);
+    if (e == hipSuccess) e = hipEventCreate(&ev[1]);
+    if (e == hipSuccess) e = hipEventRecord(ev[0], (hipStream_t)stream);
+    if (e != hipSuccess) {
+        delete[] ev;
+        return fail_hip(e, "cloudy_timer_begin");
+    }
+    *timer_out = ev;
+    return CLOUDY_OK;
+}
+
+int cloudy_timer_end(void *timer, void *stream, float *ms_total) {
+    if (!timer || !ms_total) return fail(CLOUDY_EINVAL, "timer / ms_total is NULL");
+    hipEvent_t *ev = static_cast<hipEvent_t *>(timer);
+    hipError_t e = hipEventRecord(ev[1], (hipStream_t)stream);
+    if (e == hipSuccess) e = hipEventSynchronize(ev[1]);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev[0], ev[1]);
+    (void)hipEventDestroy(ev[0]);
+    (void)hipEventDestroy(ev[1]);
+    delete[] ev;
+    if (e != hipSuccess) return fail_hip(e, "cloudy_timer_end");
+    *ms_total = ms;
+    return CLOUDY_OK;
+}
+
 int cloudy_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

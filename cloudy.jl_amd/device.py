@@ -49,6 +49,18 @@ class DeviceArray:
             _lib.check(_lib.lib().cloudy_stream_synchronize(None))
         return out
 
+    def columns_to_numpy(self, ncols):
+        """the first `ncols` parcels of every plane (one copy per plane): diagnostics on a slice of a big result"""
+        ncols = min(int(ncols), self.shape[1])
+        out = np.empty((self.shape[0], ncols), dtype=self.dtype)
+        L = _lib.lib()
+        _lib.check(L.cloudy_stream_synchronize(None))
+        for q in range(self.shape[0]):
+            _lib.check(L.cloudy_memcpy_d2h(out[q].ctypes.data, self.ptr + q * self.shape[1] * self.dtype.itemsize,
+                                           ncols * self.dtype.itemsize, None))
+        _lib.check(L.cloudy_stream_synchronize(None))
+        return out
+
     def data_ptr(self):
         return self.ptr
 

@@ -322,6 +322,12 @@ int cloudy_stream_synchronize(void *stream);
 int cloudy_time_coal_rhs(const cloudy_plan *plan, size_t n_parcels, size_t ld, const void *mom_dev,
                          void *dmom_dev, void *stream, int iters, float *ms_per_launch);
 
+/* generic launch timing with HIP events recorded on `stream` (the stream the kernels are launched on): begin records an
+ * event and hands out a timer, end records the second event, waits for it, returns the milliseconds between the two and
+ * releases the timer.  bench.py brackets every variant that is not a plain cloudy_coal_rhs loop with these. */
+int cloudy_timer_begin(void *stream, void **timer_out);
+int cloudy_timer_end(void *timer, void *stream, float *ms_total);
+
 const char *cloudy_last_error(void);
 int cloudy_version(void);
 

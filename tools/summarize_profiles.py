@@ -71,18 +71,26 @@ VARIANTS = {   # bench variant -> (kernel name prefix, items per launch in the b
     "cfg4q": ("cloudy_jit_quad_n3q10_hydro_f64", 12_500_000),
     "cfg3a_fused_ssprk33": ("cloudy_jit_ssprk33_n2p3_f64", 10_000_000),
     "rainshaft_ssprk33_columns": (("cloudy_jit_rainshaft_ssprk33_n2p3_f64", "rainshaft_ssprk33_kernel<2, 3, 1, double>"), 10_000_000),
+    "cfg4q_converged": ("cloudy_jit_quad_n3c8_hydro_f64", 12_500_000),
+    "cfg3b_f32_fast": ("cloudy_jit_sorted_n2p3_f32fast", 10_000_000),
+    "cfg5_f32_planes": ("cloudy_jit_sorted_rs_n2p3_f32", 12_500_000),
+    "cfg5_f32_fast": ("cloudy_jit_sorted_rs_n2p3_f32fast", 12_500_000),
+    "cfg2": ("cloudy_jit_allinf2_n1p2_f64", 1_000_000 // 2),
+    "cfg3a_f32_planes": ("cloudy_jit_allinf2_n2p3_f32", 10_000_000 // 2),
+    "cfg3a_aot_kernels": ("coal_rhs_allinf2_kernel<2, 3, double>", 10_000_000 // 2),
 }
 kern = {}
 for name, (prefix, items) in VARIANTS.items():
     prefixes = (prefix,) if isinstance(prefix, str) else prefix
-    cands = [r for r in rows if r["kernel"].startswith(prefixes) and "SQ_INSTS_VALU_FMA_F64" in r and r["grid_size"] >= 0.9 * items]
+    cands = [r for r in rows if r["kernel"] in prefixes and "SQ_INSTS_VALU_FMA_F64" in r and r["grid_size"] >= 0.9 * items]
     if not cands:
         continue
     r = max(cands, key=lambda x: x["grid_size"])
     util = r["SQ_THREAD_CYCLES_VALU"] / (r["SQ_ACTIVE_INST_VALU"] * 64.0)
     flops = (2 * r["SQ_INSTS_VALU_FMA_F64"] + r["SQ_INSTS_VALU_MUL_F64"] + r["SQ_INSTS_VALU_ADD_F64"]) * 64.0 * util
-    kern[name] = {"kernel": r["kernel"], "grid_size": r["grid_size"], "fp64_flops_per_item": flops / items,
-                  "valu_insts_per_item": r["SQ_INSTS_VALU"] * 64.0 / items, "lane_utilisation": util}
+    n_items = items * 2 if name in ("cfg2", "cfg3a_f32_planes", "cfg3a_aot_kernels") else items   # two parcels per lane
+    kern[name] = {"kernel": r["kernel"], "grid_size": r["grid_size"], "fp64_flops_per_item": flops / n_items,
+                  "valu_insts_per_item": r["SQ_INSTS_VALU"] * 64.0 / n_items, "lane_utilisation": util}
     t = traffic.get(f'{r["kernel"]}@{r["grid_size"]}')
     if t:
         kern[name]["hbm_bytes_per_launch"] = t["hbm_bytes_per_launch"]
