@@ -35,30 +35,31 @@ constexpr int kConvPanels = 48;  // panels of the 1-D rule (QArgs::nq Gauss-Lege
 
 // continued fraction of the incomplete beta function (DLMF 8.17.22, modified Lentz), converging for x < (a+1)/(a+b+2)
 __device__ __forceinline__ double inc_beta_cf(double a, double b, double x) {
+    // (quotients through recip_fast: ~1 ulp, 5 instructions instead of the 30 of an IEEE division -- four per step)
     const double tiny = 1e-300;
-    double c = 1.0, d = 1.0 - (a + b) * x / (a + 1.0);
+    double c = 1.0, d = 1.0 - (a + b) * x * recip_fast(a + 1.0);
     d = fabs(d) < tiny ? tiny : d;
-    d = 1.0 / d;
+    d = recip_fast(d);
     double h = d;
 #pragma unroll 1
     for (int m = 1; m <= 300; ++m) {
         const double md = double(m), m2 = 2.0 * md;
-        double aa = md * (b - md) * x / ((a + m2 - 1.0) * (a + m2));
+        double aa = md * (b - md) * x * recip_fast((a + m2 - 1.0) * (a + m2));
         d = fma(aa, d, 1.0);
         d = fabs(d) < tiny ? tiny : d;
-        c = 1.0 + aa / c;
+        c = fma(aa, recip_fast(c), 1.0);
         c = fabs(c) < tiny ? tiny : c;
-        d = 1.0 / d;
+        d = recip_fast(d);
         h *= d * c;
-        aa = -(a + md) * (a + b + md) * x / ((a + m2) * (a + m2 + 1.0));
+        aa = -(a + md) * (a + b + md) * x * recip_fast((a + m2) * (a + m2 + 1.0));
         d = fma(aa, d, 1.0);
         d = fabs(d) < tiny ? tiny : d;
-        c = 1.0 + aa / c;
+        c = fma(aa, recip_fast(c), 1.0);
         c = fabs(c) < tiny ? tiny : c;
-        d = 1.0 / d;
+        d = recip_fast(d);
         const double del = d * c;
         h *= del;
-        if (fabs(del - 1.0) < 1e-16) break;
+        if (fabs(del - 1.0) < 4e-16) break;
     }
     return h;
 }
@@ -176,7 +177,7 @@ __device__ __forceinline__ double conv_one_minus_w(const ConvLogDensity (&lg)[N]
         den += rho;
         if (m > j) up += rho;
     }
-    return up / den;
+    return up * recip_fast(den);
 }
 
 // One node of the 1-D rule in z, s / theta = u = ln(1 + e^z): u, ln u and the Gamma(A) weight x dz (softplus and the
@@ -188,7 +189,7 @@ __device__ __forceinline__ ConvNode conv_node(double z, double hw, double Am1, d
     const double ez = exp_fin(-fabs(z));
     ConvNode nd;
     nd.u = fmax(z, 0.0) + log1p(ez);
-    const double sig = (z >= 0.0 ? 1.0 : ez) / (1.0 + ez);
+    const double sig = (z >= 0.0 ? 1.0 : ez) * recip_fast(1.0 + ez);
     nd.lu = log_pos(nd.u);
     nd.wt = hw * sig * exp_fin(fma(Am1, nd.lu, -nd.u) - lgA);
     return nd;
