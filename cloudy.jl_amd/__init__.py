@@ -23,7 +23,7 @@ from .Coalescence import (CoalescenceData, NumericalPlan, Plan, get_coal_ints, g
                           kernel_func_code, numerical_plan, QUAD_CONVERGED, QUAD_FIXED)
 from .Sedimentation import (get_sedimentation_flux, make_rainshaft_rhs, rainshaft_sources, rhs_condensation,
                             solve_rainshaft_ssprk33)
-from .box_model import ODEParameters, make_box_model_rhs, rhs_coal, solve_ssprk33
+from .box_model import ODEParameters, make_box_model_rhs, rhs_coal, solve_ssprk33, solve_tsit5
 from .sharding import Communicator, allreduce_sums, mode_sums, moment_sums, shard_range
 
 __all__ = [n for n in dir() if not n.startswith("_")]

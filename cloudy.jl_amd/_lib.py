@@ -70,6 +70,7 @@ SYMBOLS = {
     "cloudy_coal_rhs_host": (_i, [_vp, _sz, _sz, _vp, _vp]),
     "cloudy_get_coal_ints": (_i, [_vp, _sz, _sz, _vp, _vp, _vp]),
     "cloudy_ssprk33_steps": (_i, [_vp, _sz, _sz, _vp, _vp, C.c_double, _i, _vp]),
+    "cloudy_tsit5_steps": (_i, [_vp, _sz, _sz, _vp, _vp, C.c_double, _i, _vp]),
     "cloudy_update_dist_from_moments": (_i, [_vp, _sz, _sz, _vp, _vp, _vp]),
     "cloudy_finite_2d_integrals": (_i, [_vp, _sz, _sz, _vp, _vp, _vp]),
     "cloudy_compute_thresholds": (_i, [_vp, _sz, _sz, _vp, _vp, _vp]),

@@ -95,3 +95,17 @@ def solve_ssprk33(par, u, dt, n_steps, out=None, stream=None, coal_type=None):
         raise ValueError(f"u and out must both be ({plan.nmom}, n) with equal leading dimension")
     _lib.check(_lib.lib().cloudy_ssprk33_steps(plan.handle, n, ld, uptr, optr, float(dt), int(n_steps), stream))
     return o
+
+
+def solve_tsit5(par, u, dt, n_steps, out=None, stream=None):
+    """solve(ODEProblem(rhs, u, tspan, par), Tsit5(), dt = dt, adaptive = false) for n_steps fixed steps, on the device
+    (cloudy_tsit5_steps): BASELINE configs[0] names Tsit5; no reference driver uses it (they call SSPRK33).  AnalyticalCoalStyle
+    plans with thresholds Inf or fixed, fp64 planes.  `u` is advanced in place unless `out` is given."""
+    plan = _plan_for(par, dtype_code(u))
+    uptr, planes, n, ld = as_device(u)
+    o = out if out is not None else u
+    optr, oplanes, on, old = as_device(o)
+    if planes != plan.nmom or oplanes != plan.nmom or on != n or old != ld:
+        raise ValueError(f"u and out must both be ({plan.nmom}, n) with equal leading dimension")
+    _lib.check(_lib.lib().cloudy_tsit5_steps(plan.handle, n, ld, uptr, optr, float(dt), int(n_steps), stream))
+    return o

@@ -698,6 +698,20 @@ int cloudy_ssprk33_steps(const cloudy_plan *plan, size_t n, size_t ld, const voi
     return run(plan, r);
 }
 
+int cloudy_tsit5_steps(const cloudy_plan *plan, size_t n, size_t ld, const void *u_in_dev, void *u_out_dev, double dt,
+                       int n_steps, void *stream) {
+    int rc = check_batch(plan, n, ld, u_in_dev, u_out_dev);
+    if (rc) return rc;
+    if (n_steps < 0 || !(dt == dt)) return fail(CLOUDY_EINVAL, "n_steps must be >= 0 and dt not NaN");
+    if (plan->h.coal_style != CLOUDY_ANALYTICAL_COAL || plan->h.mode == MODE_MOVING || plan->h.dtype != CLOUDY_F64)
+        return fail(CLOUDY_EUNSUPPORTED, "cloudy_tsit5_steps serves fp64 AnalyticalCoalStyle plans with thresholds Inf or "
+                                         "fixed; use cloudy_ssprk33_steps (the integrator of every reference driver)");
+    LaunchReq r{OP_TSIT5, IN_MOMENTS, 1, 0, n, ld, u_in_dev, u_out_dev, nullptr, (hipStream_t)stream};
+    r.dt = dt;
+    r.n_steps = n_steps;
+    return run(plan, r);
+}
+
 int cloudy_update_dist_from_moments(const cloudy_plan *plan, size_t n, size_t ld, const void *mom_dev,
                                     void *params_dev, void *stream) {
     int rc = check_batch(plan, n, ld, mom_dev, params_dev);

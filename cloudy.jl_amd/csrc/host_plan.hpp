@@ -43,7 +43,7 @@ struct HostPlan {
     double *qtab_dev = nullptr;
 };
 
-enum Op { OP_COAL = 0, OP_UPDATE_DIST = 1, OP_FINITE_2D = 2, OP_SEDI = 3, OP_SSPRK33 = 4, OP_COND = 5, OP_PREPARE = 6 /* plan creation: upload the constant block */, OP_NQ = 7, OP_RAINSHAFT_SSPRK33 = 8 };
+enum Op { OP_COAL = 0, OP_UPDATE_DIST = 1, OP_FINITE_2D = 2, OP_SEDI = 3, OP_SSPRK33 = 4, OP_COND = 5, OP_PREPARE = 6 /* plan creation: upload the constant block */, OP_NQ = 7, OP_RAINSHAFT_SSPRK33 = 8, OP_TSIT5 = 9 };
 
 struct LaunchReq {
     int op;

@@ -1246,6 +1246,104 @@ __global__ void __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(CLOUDY_
     ssprk33_body<N, P, MODE, TIO, false, BS>(Ag, nodes, n, ld, u_in, u_out, dt, n_steps);
 }
 
+// Fixed-step Tsit5 (Tsitouras 2011, the tableau of OrdinaryDiffEq's Tsit5()) -- BASELINE configs[0] names "CPU Tsit5" for
+// the single-box Golovin case.  No reference driver uses it (they all call solve(prob, SSPRK33(), dt = ...)), and
+// OrdinaryDiffEq's Tsit5 is adaptive by default with a GLOBAL error norm over the state; a batch of independent parcels has
+// no global norm, so this is the explicit 7-stage FSAL tableau applied with the caller's fixed dt, per parcel, state and
+// stage derivatives in registers (6 RHS evaluations per step, one read + one write of the state per call).  The 5th-order
+// convergence of the tableau is a GPU test (error ratio ~32 per halving of dt against Smoluchowski's closed form).
+namespace tsit5 {
+constexpr double a21 = 0.161;
+constexpr double a31 = -0.008480655492356989, a32 = 0.335480655492357;
+constexpr double a41 = 2.8971530571054935, a42 = -6.359448489975075, a43 = 4.3622954328695815;
+constexpr double a51 = 5.325864828439257, a52 = -11.748883564062828, a53 = 7.4955393428898365, a54 = -0.09249506636175525;
+constexpr double a61 = 5.86145544294642, a62 = -12.92096931784711, a63 = 8.159367898576159, a64 = -0.071584973281401,
+                 a65 = -0.028269050394068383;
+constexpr double a71 = 0.09646076681806523, a72 = 0.01, a73 = 0.4798896504144996, a74 = 1.379008574103742,
+                 a75 = -3.290069515436081, a76 = 2.324710524099774;
+}  // namespace tsit5
+
+template <int N, int P, int MODE, typename TIO, int BS = kBlock>
+__device__ __forceinline__ void tsit5_body(const KArgs<N, P> *__restrict__ Ag, const double *__restrict__ nodes, size_t n,
+                                           size_t ld, const TIO *u_in, TIO *u_out, double dt, int n_steps) {
+    using namespace tsit5;
+    const KArgs<N, P> &A = *Ag;
+    const size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
+    const bool valid = i < n;
+    if (MODE == MODE_ALLINF && !valid) return;
+    double u[N][3], k1[N][3], k2[N][3], k3[N][3], k4[N][3], k5[N][3], k6[N][3], w[N][3];
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        const int off = A.off[m];
+        u[m][0] = valid ? (double)u_in[(size_t)(off + 0) * ld + i] : 0.0;
+        u[m][1] = valid ? (double)u_in[(size_t)(off + 1) * ld + i] : 0.0;
+        u[m][2] = (valid && A.np[m] == 3) ? (double)u_in[(size_t)(off + 2) * ld + i] : 0.0;
+    }
+    // the plan constants through an opaque zero offset per RHS evaluation (see ssprk33_body)
+#define CLOUDY_TSIT5_RHS(state, deriv)                                   \
+    do {                                                                 \
+        size_t oz = 0;                                                   \
+        asm volatile("" : "+s"(oz));                                     \
+        rhs_physical<N, P, MODE, false, BS>(*(Ag + oz), nodes, valid, state, deriv); \
+    } while (0)
+    if (n_steps > 0) CLOUDY_TSIT5_RHS(u, k1);
+#pragma unroll 1
+    for (int step = 0; step < n_steps; ++step) {
+#pragma unroll
+        for (int m = 0; m < N; ++m)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) w[m][q] = fma(dt * a21, k1[m][q], u[m][q]);
+        CLOUDY_TSIT5_RHS(w, k2);
+#pragma unroll
+        for (int m = 0; m < N; ++m)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) w[m][q] = fma(dt, fma(a31, k1[m][q], a32 * k2[m][q]), u[m][q]);
+        CLOUDY_TSIT5_RHS(w, k3);
+#pragma unroll
+        for (int m = 0; m < N; ++m)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) w[m][q] = fma(dt, fma(a41, k1[m][q], fma(a42, k2[m][q], a43 * k3[m][q])), u[m][q]);
+        CLOUDY_TSIT5_RHS(w, k4);
+#pragma unroll
+        for (int m = 0; m < N; ++m)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                w[m][q] = fma(dt, fma(a51, k1[m][q], fma(a52, k2[m][q], fma(a53, k3[m][q], a54 * k4[m][q]))), u[m][q]);
+        CLOUDY_TSIT5_RHS(w, k5);
+#pragma unroll
+        for (int m = 0; m < N; ++m)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                w[m][q] = fma(dt, fma(a61, k1[m][q], fma(a62, k2[m][q], fma(a63, k3[m][q], fma(a64, k4[m][q], a65 * k5[m][q])))),
+                              u[m][q]);
+        CLOUDY_TSIT5_RHS(w, k6);
+#pragma unroll
+        for (int m = 0; m < N; ++m)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                u[m][q] = fma(dt, fma(a71, k1[m][q], fma(a72, k2[m][q], fma(a73, k3[m][q], fma(a74, k4[m][q],
+                                                                                            fma(a75, k5[m][q], a76 * k6[m][q]))))),
+                              u[m][q]);
+        if (step + 1 < n_steps) CLOUDY_TSIT5_RHS(u, k1);  // FSAL: the 7th stage derivative is the next step's first
+    }
+#undef CLOUDY_TSIT5_RHS
+    if (!valid) return;
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        const int off = A.off[m];
+        u_out[(size_t)(off + 0) * ld + i] = (TIO)u[m][0];
+        u_out[(size_t)(off + 1) * ld + i] = (TIO)u[m][1];
+        if (A.np[m] == 3) u_out[(size_t)(off + 2) * ld + i] = (TIO)u[m][2];
+    }
+}
+
+template <int N, int P, int MODE, typename TIO, int BS = kBlock>
+__global__ void __launch_bounds__(BS)
+    tsit5_kernel(const KArgs<N, P> *__restrict__ Ag, const double *__restrict__ nodes, size_t n, size_t ld, const TIO *u_in,
+                 TIO *u_out, double dt, int n_steps) {
+    tsit5_body<N, P, MODE, TIO, BS>(Ag, nodes, n, ld, u_in, u_out, dt, n_steps);
+}
+
 // ---- diagnostics / the callers either side of the operator ---------------------------------------
 
 template <int N, int P>

@@ -157,6 +157,7 @@ hipError_t launch_np(const HostPlan &h, const LaunchReq &r) {
         return hipSuccess;
     }
     case OP_SSPRK33:
+    case OP_TSIT5:
     case OP_RAINSHAFT_SSPRK33:
         return launch_int<N, P>(h, r);  // int_n<N>_p<P>.hip
     case OP_COAL:

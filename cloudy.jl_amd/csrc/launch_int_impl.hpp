@@ -35,6 +35,24 @@ hipError_t launch_int_io(const HostPlan &h, const LaunchReq &r) {
                                h.nodes_dev, r.n, r.ld, in, out, r.dt, r.n_steps);
         break;
     }
+    case OP_TSIT5: {  // cloudy_tsit5_steps: fp64 planes, thresholds Inf or fixed
+        if (!h.kargs_dev) return hipErrorNotInitialized;
+        if constexpr (sizeof(TIO) == 8) {
+            const KArgs<N, P> *Ad = static_cast<const KArgs<N, P> *>(h.kargs_dev);
+            const unsigned g = grid_for(r.n, heavy);
+            if (h.mode == MODE_ALLINF)
+                hipLaunchKernelGGL((tsit5_kernel<N, P, MODE_ALLINF, TIO>), dim3(g), dim3(kBlock), 0, r.stream, Ad, h.nodes_dev,
+                                   r.n, r.ld, in, out, r.dt, r.n_steps);
+            else if (h.mode == MODE_FIXED)
+                hipLaunchKernelGGL((tsit5_kernel<N, P, MODE_FIXED, TIO>), dim3(g), dim3(kBlock), 0, r.stream, Ad, h.nodes_dev,
+                                   r.n, r.ld, in, out, r.dt, r.n_steps);
+            else
+                return hipErrorInvalidValue;
+        } else {
+            return hipErrorInvalidValue;
+        }
+        break;
+    }
     case OP_RAINSHAFT_SSPRK33: {
         if (!h.kargs_dev) return hipErrorNotInitialized;
         if (r.nz < 1 || r.nz > (size_t)kBlock) return hipErrorInvalidValue;

@@ -35,6 +35,7 @@
  *                                    test/examples/utils/box_model_helpers.jl:55-67, src/Sources/Condensation.jl:22-37
  *   cloudy_ssprk33_steps          <- solve(ODEProblem(rhs, m0, tspan, p), SSPRK33(), dt = p.dt) of the drivers,
  *                                    test/examples/Analytical/box_single_gamma.jl:35-36 (OrdinaryDiffEq stepping)
+ *   cloudy_tsit5_steps            <- solve(prob, Tsit5(), dt = ..., adaptive = false) (BASELINE configs[0]; OrdinaryDiffEq tableau)
  *   cloudy_moment_sums            <- moments_sum diagnostic, test/examples/utils/plotting_helpers.jl:240-252
  *   cloudy_moment_sums_allreduce  <- the same summed over the ranks / GPUs that share a batch (RCCL; the reference is
  *                                    single-process, its global sum is the local one)
@@ -209,6 +210,15 @@ int cloudy_coal_rhs_host(const cloudy_plan *plan, size_t n_parcels, size_t ld, c
  * drivers integrate the same way, test/examples/Numerical/n_particles_gamma.jl:39-40). */
 int cloudy_ssprk33_steps(const cloudy_plan *plan, size_t n_parcels, size_t ld, const void *u_in_dev, void *u_out_dev,
                          double dt, int n_steps, void *stream);
+
+/* n_steps explicit steps of the Tsit5 tableau (Tsitouras 2011; OrdinaryDiffEq's Tsit5()) with FIXED dt, fused around the
+ * RHS like cloudy_ssprk33_steps (state and the six stage derivatives in registers, 6 RHS evaluations per step, FSAL).
+ * BASELINE configs[0] names Tsit5 for the single-box Golovin case; no reference driver uses it (all of them call
+ * solve(prob, SSPRK33(), dt = ...)), and OrdinaryDiffEq's adaptive step control needs a global error norm over the state,
+ * which a batch of independent parcels does not have: this is the tableau applied per parcel with the caller's dt.
+ * fp64 planes; AnalyticalCoalStyle plans with thresholds Inf or fixed (CLOUDY_EUNSUPPORTED otherwise). */
+int cloudy_tsit5_steps(const cloudy_plan *plan, size_t n_parcels, size_t ld, const void *u_in_dev, void *u_out_dev,
+                       double dt, int n_steps, void *stream);
 
 /* inner operator on given distributions: params = 3N planes (n, theta, k) per mode, normalised units
  * (k plane ignored for exponential modes); out = nmom planes, normalised units. */

@@ -327,6 +327,22 @@ function solve_ssprk33!(u, plan::Plan, dt, n_steps; stream = nothing, sync::Bool
 end
 
 """
+    solve_tsit5!(u, plan, dt, n_steps; stream = nothing, sync = true)
+
+`solve(prob, Tsit5(), dt = dt, adaptive = false)` for `n_steps` fixed steps on the device (BASELINE configs[0] names Tsit5;
+the reference drivers use SSPRK33): the Tsit5 tableau per parcel, state and stage derivatives in registers.
+"""
+function solve_tsit5!(u, plan::Plan, dt, n_steps; stream = nothing, sync::Bool = true)
+    n, ld = batch_shape(u, plan.nmom)
+    s = stream === nothing ? current_stream() : stream
+    check(ccall((:cloudy_tsit5_steps, lib), Cint,
+                (Ptr{Cvoid}, Csize_t, Csize_t, Ptr{Cvoid}, Ptr{Cvoid}, Cdouble, Cint, Ptr{Cvoid}),
+                plan.handle, n, ld, pointer(u), pointer(u), dt, n_steps, s))
+    sync && check(ccall((:cloudy_stream_synchronize, lib), Cint, (Ptr{Cvoid},), s))
+    return u
+end
+
+"""
     solve_rainshaft_ssprk33!(u, plan, nz, dz, dt, n_steps; stream = nothing, sync = true)
 
 `solve(ODEProblem(make_rainshaft_rhs(AnalyticalCoalStyle()), m, tspan, p), SSPRK33(), dt = p.dt)` of

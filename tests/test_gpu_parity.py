@@ -562,6 +562,83 @@ def test_cfg1_single_box_trajectory_ssprk33(gpu_cloudy, oracle):
     assert np.array_equal(u_out.to_numpy(), u0) and np.array_equal(u_in.to_numpy(), u0)
 
 
+_TSIT5_A = ((0.161,),
+            (-0.008480655492356989, 0.335480655492357),
+            (2.8971530571054935, -6.359448489975075, 4.3622954328695815),
+            (5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525),
+            (5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383),
+            (0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774))
+
+
+def _tsit5_host(rhs_fn, u, dt, n_steps):
+    """the Tsit5 tableau (Tsitouras 2011; OrdinaryDiffEq's Tsit5()) with a fixed step and a host-side RHS callable"""
+    u = u.copy()
+    for _ in range(n_steps):
+        k = [rhs_fn(u)]
+        for row in _TSIT5_A[:-1]:
+            k.append(rhs_fn(u + dt * sum(a * ki for a, ki in zip(row, k))))
+        u = u + dt * sum(a * ki for a, ki in zip(_TSIT5_A[-1], k))
+    return u
+
+
+def test_cfg0_single_box_tsit5_fixed_step(gpu_cloudy, oracle):
+    """BASELINE configs[0] as worded ("Single 0-D box parcel ... Golovin kernel, 3 prognostic moments, CPU Tsit5"):
+    cloudy_tsit5_steps = the Tsit5 tableau per parcel with a fixed dt (no reference driver uses Tsit5, and OrdinaryDiffEq's
+    step control needs a global error norm: DESIGN 3.5).  (i) against the same tableau driven by the oracle RHS on the
+    host, box_single_gamma.jl's configuration and a thresholded 2-mode batch; (ii) the order of the tableau itself:
+    constant kernel, M0(t) = 1 / (1 / M0 + A t / 2) (Smoluchowski 1916), error ratio ~2^5 per halving of dt."""
+    cloudy = gpu_cloudy
+    kern = cloudy.CoalescenceTensor(cloudy.LinearKernelFunction(5.0), 1, 1e-6)
+    cd = cloudy.CoalescenceData(kern, (3,), (INF,), bench.NORMS)
+    par = cloudy.ODEParameters((cloudy.GammaPrimitiveParticleDistribution(1e8, 1e-10, 1.0),), cd, (3,), bench.NORMS)
+    u0 = np.tile(np.array([1e8, 1e-2, 2e-12])[:, None], (1, 64))
+    dt, n_steps = 10.0, 12
+    op = oracle.make_params([1], kern.c, (INF,), norms=bench.NORMS)
+    want = _tsit5_host(lambda u: oracle.rhs_coal_batch(op, u), u0, dt, n_steps)
+    u = dev(cloudy, u0)
+    cloudy.solve_tsit5(par, u, dt, n_steps)
+    got = u.to_numpy()
+    assert np.all(got == got[:, :1]) and np.allclose(got, want, rtol=1e-12, atol=0)
+    # Golovin: M1 conserved, M0(t) = M0 exp(-b M1 t); 5th order at dt b M1 = 0.5 per step
+    assert np.allclose(got[1], 1e-2, rtol=1e-13)
+    assert got[0, 0] == pytest.approx(1e8 * math.exp(-5.0 * 1e-2 * 120.0), rel=2e-5)
+    # a thresholded two-mode batch (cfg3b): every lane of the workgroup ranks its parcels in every stage
+    wl = bench.make_workload("cfg3b", 700, seed=4)
+    opb = bench.oracle_params("cfg3b")
+    dtb, nb_ = 1e-3, 2
+    wantb = _tsit5_host(lambda v: oracle.rhs_coal_batch(opb, v), wl["mom"], dtb, nb_)
+    ub = dev(cloudy, wl["mom"])
+    cloudy.solve_tsit5(wl["par"], ub, dtb, nb_)
+    gotb = ub.to_numpy()
+    with np.errstate(all="ignore"):
+        ok = np.isfinite(wantb).all(axis=0) & (np.abs(wantb[:2]) <= 10 * np.abs(wl["mom"][:2]) + 1e-300).all(axis=0)
+    assert ok.sum() > 0.9 * 700
+    ref = np.abs(wl["mom"]) + np.abs(wantb)
+    assert (np.abs(gotb - wantb)[:, ok] / np.maximum(ref[:, ok], 1e-300)).max() < 1e-10
+    # order of the tableau
+    A = 1e-4
+    cdc = cloudy.CoalescenceData(cloudy.CoalescenceTensor([[A]]), (3,), (INF,))
+    parc = cloudy.ODEParameters((cloudy.GammaPrimitiveParticleDistribution(1.0, 1.0, 1.0),), cdc, (3,), (1.0, 1.0))
+    m0 = np.array([[1e3], [2e3], [8e3]]).repeat(8, axis=1)
+    T = 40.0   # A M0 T / 2 = 2: the number concentration falls to a third
+    exact = 1.0 / (1.0 / 1e3 + A * T / 2.0)
+    errs = []
+    for steps in (4, 8, 16):
+        uc = dev(cloudy, m0)
+        cloudy.solve_tsit5(parc, uc, T / steps, steps)
+        errs.append(abs(uc.to_numpy()[0, 0] - exact) / exact)
+    print("Tsit5 fixed-step errors of M0 at dt, dt/2, dt/4:", errs)
+    assert errs[0] < 1e-4 and 20.0 < errs[0] / errs[1] < 50.0 and 20.0 < errs[1] / errs[2] < 50.0
+    # status codes
+    L, E = cloudy.lib(), cloudy._lib
+    mv = cloudy.CoalescenceData(kern, (3, 3), (0.9, 1.0), bench.NORMS, cloudy.MovingThreshold()).plan([1, 1])
+    z6 = cloudy.DeviceArray.zeros(6, 8)
+    assert L.cloudy_tsit5_steps(mv.handle, 8, 8, z6.ptr, z6.ptr, 1.0, 1, None) == E.EUNSUPPORTED
+    npl = cloudy.NumericalPlan([1, 1], cloudy.LinearKernelFunction(5e-3), bench.NORMS, 10)
+    assert L.cloudy_tsit5_steps(npl.handle, 8, 8, z6.ptr, z6.ptr, 1.0, 1, None) == E.EUNSUPPORTED
+    assert L.cloudy_tsit5_steps(cd.plan([1]).handle, 8, 8, z6.ptr, z6.ptr, 1.0, -1, None) == E.EINVAL
+
+
 @pytest.mark.parametrize("name,tol", [("cfg3a", TOL_POLY), ("cfg3b", TOL_QUAD)])
 def test_fused_ssprk33_batch_vs_oracle_stepping(gpu_cloudy, oracle, name, tol):
     """box_gamma_mixture_long.jl:37-46 pattern on a batch of different boxes, 4 steps.  The synthetic parcels span
