@@ -294,6 +294,37 @@ def check_numerical_config(pkg, cfg, n, seed):
     return (float(np.max(err[fin] / np.maximum(scale[fin], 1e-300))) if fin.any() else 0.0), dj
 
 
+def check_converged_config(pkg, cfg, n, seed):
+    """CLOUDY_QUAD_CONVERGED plan of a random NumericalCoalStyle configuration against the same-rule oracle
+    (co_rhs_coal_numerical_converged): plan-time compiled and ahead-of-time kernels, fp64 planes"""
+    kf_cls = [pkg.ConstantKernelFunction, pkg.LinearKernelFunction, pkg.HydrodynamicKernelFunction, pkg.LongKernelFunction]
+    kfn = pkg.get_normalized_kernel_func(kf_cls[cfg["kind"]](*cfg["params"]), cfg["norms"])
+    okf = O.get_normalized_kernel_func(O.kernel_func(cfg["kind"], *cfg["params"]), cfg["norms"])
+    op = O.make_params(cfg["dist"], np.zeros((1, 1)), (INF,) * cfg["N"], norms=cfg["norms"], k_range=cfg["k_range"])
+    q = int(min(max(cfg["nq"], 4), 16))
+    mom = moments_for(cfg["dist"], n, seed)
+    jit = pkg.NumericalPlan(cfg["dist"], kfn, cfg["norms"], q, k_range=cfg["k_range"], specialize=1, quad_mode=1)
+    aot = pkg.NumericalPlan(cfg["dist"], kfn, cfg["norms"], q, k_range=cfg["k_range"], specialize=-1, quad_mode=1)
+    a, b = run(pkg, jit, mom, np.float64), run(pkg, aot, mom, np.float64)
+    want, scale = O.rhs_coal_numerical_converged_batch(op, okf, q, mom, with_scale=True)
+    keep = np.ones(mom.shape[1], dtype=bool)
+    if 3 in cfg["dist"]:
+        prm = O.update_dist_batch(op, mom)
+        for i, t in enumerate(cfg["dist"]):
+            if t == 3:
+                keep &= prm[3 * i + 2] > 1e-3
+    assert np.array_equal(np.isnan(a[:, keep]), np.isnan(want[:, keep])), "NaN pattern differs"
+    fin = np.isfinite(want) & keep[None, :]
+    err = np.abs(a - want)
+    bad = fin & ~(err <= 1e-11 * scale)
+    worst = float(np.max(err[fin] / np.maximum(scale[fin], 1e-300))) if fin.any() else 0.0
+    assert not bad.any(), f"{bad.sum()} entries beyond 1e-11 of scale, worst {worst:.3e}"
+    both = np.isfinite(a) & np.isfinite(b) & keep[None, :]
+    dj = float(np.max(np.abs(a - b)[both] / np.maximum(scale[both], 1e-300))) if both.any() else 0.0
+    assert dj <= 1e-13, f"plan-time compiled and ahead-of-time kernels differ by {dj:.2e} of scale"
+    return worst, dj
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--configs", type=int, default=40)
@@ -301,12 +332,25 @@ def main():
     ap.add_argument("--parcels", type=int, default=400)
     ap.add_argument("--wild", action="store_true", help="also randomise norms and the k clamp range")
     ap.add_argument("--numerical", action="store_true", help="NumericalCoalStyle (fixed Gauss rule) plans instead of tensor plans")
+    ap.add_argument("--converged", action="store_true", help="NumericalCoalStyle plans in CLOUDY_QUAD_CONVERGED mode")
     a = ap.parse_args()
     pkg = load_package()
     rng = np.random.default_rng(a.seed)
     t0 = time.time()
     fails = 0
     for c in range(a.configs):
+        if a.converged:
+            cfg = random_numerical_config(rng, a.wild)
+            tag = (f"#{c} converged N={cfg['N']} dist={cfg['dist']} kernel={['constant', 'linear', 'hydro', 'long'][cfg['kind']]}"
+                   f"{tuple(f'{v:.3g}' for v in cfg['params'])} q={min(max(cfg['nq'], 4), 16)}"
+                   + (f" norms=({cfg['norms'][0]:.1e},{cfg['norms'][1]:.1e}) k_range={cfg['k_range']}" if a.wild else ""))
+            try:
+                worst, dj = check_converged_config(pkg, cfg, a.parcels, 5000 + c)
+                print(f"ok   {tag}: max |hip-oracle|/scale {worst:.2e}, |jit-aot|/scale {dj:.1e}", flush=True)
+            except (AssertionError, pkg.CloudyError) as e:
+                fails += 1
+                print(f"FAIL {tag}: {e}", flush=True)
+            continue
         if a.numerical:
             cfg = random_numerical_config(rng, a.wild)
             tag = (f"#{c} numerical N={cfg['N']} dist={cfg['dist']} kernel={['constant', 'linear', 'hydro', 'long'][cfg['kind']]}"
