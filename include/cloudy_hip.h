@@ -15,8 +15,9 @@
  *                                    src/Sources/Coalescence.jl:115-185
  *   (coal_style = CLOUDY_NUMERICAL_COAL: the same two entry points are
  *    rhs_coal!(NumericalCoalStyle(), dm, m, par, ts) with par.kernel_func, box_model_helpers.jl:47-48, and
- *    get_coal_ints(::NumericalCoalStyle, pdists, kernel_func), src/Sources/Coalescence.jl:470-489 -- with a fixed
- *    Gauss rule in place of the reference's adaptive quadgk, see cloudy_plan_desc.quad_order)
+ *    get_coal_ints(::NumericalCoalStyle, pdists, kernel_func), src/Sources/Coalescence.jl:470-489 -- the reference's
+ *    nested adaptive quadgk replaced by a fixed Gauss rule (cloudy_plan_desc.quad_order) or, with quad_mode =
+ *    CLOUDY_QUAD_CONVERGED, by closed forms + one 1-D rule per mode that reach quadgk's answer to <= 1e-9 of scale)
  *   cloudy_update_dist_from_moments <- update_dist_from_moments(pdist, moments)
  *                                    src/ParticleDistributions/ParticleDistributions.jl:456-476, 512-523
  *   cloudy_finite_2d_integrals    <- get_finite_2d_integrals / moment_source_helper
@@ -141,11 +142,15 @@ typedef struct cloudy_plan_desc {
                                                 environment variable CLOUDY_HIP_JIT=0 turns it off), 1 = required
                                                 (plan creation fails otherwise), -1 = off */
     /* ---- NumericalCoalStyle plans (make_box_model_rhs(NumericalCoalStyle()), Coalescence.jl:470-708) ----
-     * coal_style = CLOUDY_NUMERICAL_COAL: the integrals of the kernel FUNCTION p.kernel_func over the densities, each by
-     * one fixed quad_order-point Gauss rule per distribution (generalised Gauss-Laguerre for Gamma / Exponential modes,
-     * Gauss-Hermite in ln x for Lognormal modes; tensor product over a pair of modes after the substitution x' = x - y)
-     * where the reference nests adaptive quadgk(rtol = 1e-8).  Exact for the constant and linear kernels; a
-     * discretisation for the hydrodynamic and Long kernels (DESIGN.md states the measured error).  kernel_c, tensor_p,
+     * coal_style = CLOUDY_NUMERICAL_COAL: the integrals of the kernel FUNCTION p.kernel_func over the densities, where
+     * the reference nests adaptive quadgk(rtol = 1e-8).  quad_mode = CLOUDY_QUAD_FIXED: each by one fixed quad_order-point
+     * Gauss rule per distribution (generalised Gauss-Laguerre for Gamma / Exponential modes, Gauss-Hermite in ln x for
+     * Lognormal modes; tensor product over a pair of modes after the substitution x' = x - y) -- exact for the constant
+     * and linear kernels up to the weighting_fn split, a discretisation for the hydrodynamic and Long kernels (1e-4 ...
+     * 4e-2 of scale at 10 points).  quad_mode = CLOUDY_QUAD_CONVERGED: the integrals split along the kernel function's
+     * non-smooth sets -- closed forms for Q and R, one composite Gauss-Legendre rule per mode (quad_order points per
+     * panel, 8 suffice) for the weighting_fn split -- within 1e-9 of scale of the adaptive result, at
+     * ~10 x the cost of the 10-point rule.  kernel_c, tensor_p,
      * dist_thresholds and threshold_style are ignored (the style has no thresholds: weighting_fn splits the self
      * collisions, Coalescence.jl:624-642).  Monodisperse modes: CLOUDY_EINVAL (no normed_density_func method).
      * Shape parameters: the per-parcel Gauss-Laguerre rules are staged for 0 < k <= max(k_range[1], 1), the range
@@ -154,7 +159,8 @@ typedef struct cloudy_plan_desc {
     int32_t coal_style;                      /* CLOUDY_ANALYTICAL_COAL (default) / CLOUDY_NUMERICAL_COAL */
     int32_t kernel_func;                     /* CLOUDY_KFUNC_* */
     int32_t kernel_func_is_normalized;       /* 0: library applies get_normalized_kernel_func(kernel, norms), :124-154 */
-    int32_t quad_order;                      /* points per distribution, 2..CLOUDY_MAX_QUAD; default 10 */
+    int32_t quad_order;                      /* FIXED: points per distribution; CONVERGED: Gauss-Legendre points per
+                                                panel; 2..CLOUDY_MAX_QUAD; default 10 */
     double kernel_func_params[3];            /* physical units unless kernel_func_is_normalized */
     int32_t thresholds_are_normalized;       /* FixedThreshold only: 1 = dist_thresholds are already divided by norms[1],
                                                 i.e. the CoalescenceData.dist_thresholds FIELD (Coalescence.jl:78-84) rather
