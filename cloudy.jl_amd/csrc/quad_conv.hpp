@@ -18,8 +18,8 @@
 //     T_m = S_2k^(m) = 1/2 n^2 E[ S^m (1 - w(S)) G(S) ],     G(s) = E_tau[ K(s (1 - tau), s tau) ],
 // with G in closed form too (homogeneous kernels: G(s) = G(1) s^gamma, absorbed in the Gamma weight; Long: incomplete betas
 // of argument x_t / s between x_t and 2 x_t).  What is left is ONE 1-D integral per mode of a smooth sigmoid against a Gamma
-// density: a composite Gauss-Legendre rule in z, s / theta = ln(1 + e^z) (logarithmic near 0, linear in the tail), with
-// the panels split at the kinks of G.  Every lane does the same number of nodes; the incomplete-beta continued fractions
+// density: a composite Gauss-Legendre rule in t, s / theta = e^t for t < 0 and 1 + t beyond (logarithmic near 0, linear in
+// the tail), with the panels split at t = 0 and at the kinks of G.  Every lane does the same number of nodes; the incomplete-beta continued fractions
 // are the only data-dependent trip counts.
 //
 // Measured against nested adaptive quadrature of the reference integrals (tests/golden/numerical_adaptive.json):
@@ -180,24 +180,68 @@ __device__ __forceinline__ double conv_one_minus_w(const ConvLogDensity (&lg)[N]
     return up * recip_fast(den);
 }
 
-// One node of the 1-D rule in z, s / theta = u = ln(1 + e^z): u, ln u and the Gamma(A) weight x dz (softplus and the
-// logistic Jacobian from one exponential)
+// The variable of the 1-D rule: t in [t_lo, t_hi], u = s / theta = e^t for t < 0 (logarithmic near 0, where the Gamma
+// weight is u^(A-1): a pure exponential in t) and u = 1 + t for t >= 0 (linear in the tail); t = 0 is always a panel edge,
+// so every panel sees an analytic integrand.  One node: u, ln u and the Gamma(A) weight x dt -- one exponential and at
+// most one logarithm.  `lower`: the panel lies in t <= 0.
 struct ConvNode {
     double u, lu, wt;
 };
-__device__ __forceinline__ ConvNode conv_node(double z, double hw, double Am1, double lgA) {
-    const double ez = exp_fin(-fabs(z));
+__device__ __forceinline__ ConvNode conv_node(double t, bool lower, double hw, double A, double lgA) {
     ConvNode nd;
-    nd.u = fmax(z, 0.0) + log1p(ez);
-    const double sig = (z >= 0.0 ? 1.0 : ez) * recip_fast(1.0 + ez);
-    nd.lu = log_pos(nd.u);
-    nd.wt = hw * sig * exp_fin(fma(Am1, nd.lu, -nd.u) - lgA);
+    if (lower) {  // u = e^t, du = u dt
+        nd.u = exp_fin(t);
+        nd.lu = t;
+        nd.wt = hw * exp_fin(fma(A, t, -nd.u) - lgA);
+    } else {
+        nd.u = 1.0 + t;
+        nd.lu = log_pos(nd.u);
+        nd.wt = hw * exp_fin(fma(A - 1.0, nd.lu, -nd.u) - lgA);
+    }
     return nd;
 }
-__device__ __forceinline__ void conv_range(double A, double top, double lgA, double &zlo, double &zhi) {
+__device__ __forceinline__ void conv_range(double A, double top, double lgA, double &tlo, double &thi) {
     // (ln 1e-13; the lower clamp serves closures clamped to k = eps, whose weight is ~ 1/u over hundreds of decades)
-    zlo = fmax(-690.0, fmin(-1.0, (-29.933606208922594 + (lgA + log_pos(A))) / A));
-    zhi = (A + top) + sqrt(60.0 * (A + top)) + 30.0;
+    tlo = fmax(-690.0, fmin(-1.0, (-29.933606208922594 + (lgA + log_pos(A))) / A));
+    thi = (A + top) + sqrt(60.0 * (A + top)) + 30.0 - 1.0;
+}
+// The segments of a rule: [t_lo, t_hi] split at t = 0 and at up to two break points (ascending, in s / theta; <= 0: none),
+// panels shared out in proportion to the lengths.  ne edges e[0..ne), np[i] panels in [e[i], e[i+1]).
+struct ConvSegments {
+    double e[5];
+    int np[4], ne;
+};
+__device__ __forceinline__ ConvSegments conv_segments(double tlo, double thi, double ub1, double ub2) {
+    ConvSegments S;
+    S.ne = 0;
+    S.e[S.ne++] = tlo;
+    bool zero_in = false;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double t = INFINITY;
+        if (i < 2) {
+            const double u = i == 0 ? ub1 : ub2;
+            if (!(u > 1e-300) || u > 600.0) continue;
+            t = u < 1.0 ? log_pos(u) : u - 1.0;
+        }
+        if (!zero_in && t > 0.0) {
+            if (0.0 > S.e[S.ne - 1]) S.e[S.ne++] = 0.0;
+            zero_in = true;
+        }
+        if (t > S.e[S.ne - 1] && t < thi) S.e[S.ne++] = t;
+    }
+    S.e[S.ne++] = thi;
+    const double inv_total = 1.0 / (thi - tlo);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int n = 0;
+        if (i + 1 < S.ne) {
+            n = (int)ceil(double(kConvPanels) * ((S.e[i + 1] - S.e[i]) * inv_total) - 1e-9);
+            n = n < 1 ? 1 : n;
+        }
+        S.np[i] = n;
+    }
+    return S;
 }
 
 // P(L'_c < G'_a) for a Gamma-family mode G and a Lognormal mode L on the grid a = f + i (f = 0, 1/3; i = 0..3),
@@ -210,30 +254,35 @@ __device__ __forceinline__ void conv_H_grid(const QArgs &Q, const double *__rest
 #pragma unroll 1
     for (int f = 0; f < 2; ++f) {
         const double A0 = G.k + (f ? 1.0 / 3.0 : 0.0), lgA = f ? lgamma_pos(A0) : G.lgk;
-        double zlo, zhi;
-        conv_range(A0, 4.0, lgA, zlo, zhi);
-        const double h = (zhi - zlo) * (1.0 / double(kConvPanels));
+        double tlo, thi;
+        conv_range(A0, 4.0, lgA, tlo, thi);
+        const ConvSegments S = conv_segments(tlo, thi, 0.0, 0.0);
         double acc[4][8];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int c = 0; c < 8; ++c) acc[i][c] = 0.0;
 #pragma unroll 1
-        for (int ip = 0; ip < kConvPanels; ++ip) {
-            const double zc = fma(h, double(ip) + 0.5, zlo);
+        for (int sg = 0; sg + 1 < S.ne; ++sg) {
+            const double a = S.e[sg], h = (S.e[sg + 1] - a) / double(S.np[sg]);
+            const bool lower = S.e[sg + 1] <= 0.0;
 #pragma unroll 1
-            for (int g = 0; g < nq; ++g) {
-                const ConvNode nd = conv_node(fma(0.5 * h, tab[g], zc), 0.5 * h * tab[nq + g], A0 - 1.0, lgA);
-                const double w0 = (nd.lu + G.lnth - L.th) * inv_sg;
-                double ph[8];
+            for (int ip = 0; ip < S.np[sg]; ++ip) {
+                const double tc = fma(h, double(ip) + 0.5, a);
+#pragma unroll 1
+                for (int g = 0; g < nq; ++g) {
+                    const ConvNode nd = conv_node(fma(0.5 * h, tab[g], tc), lower, 0.5 * h * tab[nq + g], A0, lgA);
+                    const double w0 = (nd.lu + G.lnth - L.th) * inv_sg;
+                    double ph[8];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) ph[c] = conv_norm_cdf(w0 - (double(c >> 1) + ((c & 1) ? 1.0 / 3.0 : 0.0)) * L.k);
-                double wu = nd.wt;
+                    for (int c = 0; c < 8; ++c) ph[c] = conv_norm_cdf(w0 - (double(c >> 1) + ((c & 1) ? 1.0 / 3.0 : 0.0)) * L.k);
+                    double wu = nd.wt;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                    for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) acc[i][c] = fma(wu, ph[c], acc[i][c]);
-                    wu *= nd.u;
+                        for (int c = 0; c < 8; ++c) acc[i][c] = fma(wu, ph[c], acc[i][c]);
+                        wu *= nd.u;
+                    }
                 }
             }
         }
@@ -465,50 +514,38 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
                 constexpr double gam = KIND == KF_LINEAR ? 1.0 : KIND == KF_HYDRODYNAMIC ? 4.0 / 3.0 : 0.0;
                 const double Ash = fma(2.0, md[j].k, gam);  // homogeneous kernels: T_m = 1/2 s0 E_{Gamma(2k + gamma)}[s^m (1 - w)]
                 const double pref = KIND == KF_LONG ? 0.5 * (md[j].n * md[j].n) : 0.5 * pr[0];
-                const double lgA = lgamma_pos(Ash), Am1 = Ash - 1.0;
-                double zlo, zhi;
-                conv_range(Ash, 2.0, lgA, zlo, zhi);
-                // segments: Long splits at s = x_t and 2 x_t (kinks of G); panels in proportion to the lengths
-                double e1 = zlo, e2 = zlo;
-                if (KIND == KF_LONG) {
-                    const double u1 = Q.kf[0] / md[j].th, u2 = 2.0 * u1;
-                    const double z1 = u1 > 30.0 ? u1 : log(expm1(u1)), z2 = u2 > 30.0 ? u2 : log(expm1(u2));
-                    e1 = fmin(fmax(z1, zlo), zhi);
-                    e2 = fmin(fmax(z2, e1), zhi);
-                }
-                const double total = zhi - zlo;
+                const double lgA = lgamma_pos(Ash);
+                double tlo, thi;
+                conv_range(Ash, 2.0, lgA, tlo, thi);
+                // segments: the junction t = 0; Long also splits at s = x_t and 2 x_t (kinks of G)
+                const double ub1 = KIND == KF_LONG ? Q.kf[0] / md[j].th : 0.0;
+                const ConvSegments S = conv_segments(tlo, thi, ub1, 2.0 * ub1);
                 double lgB = 0.0, rB = 0.0;
                 if (KIND == KF_LONG) {
                     lgB = lgamma_pos(2.0 * md[j].k) - 2.0 * md[j].lgk;  // -ln B(k, k)
                     rB = md[j].k / (2.0 * fma(2.0, md[j].k, 1.0));      // B(k+1, k+1) / B(k, k)
                 }
 #pragma unroll 1
-                for (int sg = 0; sg < (KIND == KF_LONG ? 3 : 1); ++sg) {
-                    const double a = KIND == KF_LONG ? (sg == 0 ? zlo : sg == 1 ? e1 : e2) : zlo;
-                    const double b = KIND == KF_LONG ? (sg == 0 ? e1 : sg == 1 ? e2 : zhi) : zhi;
-                    const double len = b - a;
-                    if (!(len > 0.0)) continue;
-                    int np = KIND == KF_LONG ? (int)ceil(double(kConvPanels) * (len / total) - 1e-9) : kConvPanels;
-                    np = np < 1 ? 1 : np;
-                    const double h = len / double(np);
+                for (int sg = 0; sg + 1 < S.ne; ++sg) {
+                    const double a = S.e[sg], h = (S.e[sg + 1] - a) / double(S.np[sg]);
+                    const bool lower = S.e[sg + 1] <= 0.0;
 #pragma unroll 1
-                    for (int ip = 0; ip < np; ++ip) {
-                        const double zc = fma(h, double(ip) + 0.5, a);
+                    for (int ip = 0; ip < S.np[sg]; ++ip) {
+                        const double tc = fma(h, double(ip) + 0.5, a);
 #pragma unroll 1
                         for (int g = 0; g < nq; ++g) {
-                            const ConvNode nd = conv_node(fma(0.5 * h, tab[g], zc), 0.5 * h * tab[nq + g], Am1, lgA);
+                            const ConvNode nd = conv_node(fma(0.5 * h, tab[g], tc), lower, 0.5 * h * tab[nq + g], Ash, lgA);
                             const double s = nd.u * md[j].th, ls = nd.lu + md[j].lnth;
                             double hh = nd.wt * conv_one_minus_w<N>(lg, j, s, ls);
                             if (KIND == KF_LONG) {
                                 const double xt = Q.kf[0];
                                 double G;
-                                if (sg == 0)
+                                if (s <= xt)
                                     G = Q.kf[1] * (s * s) * ((md[j].k + 1.0) / fma(2.0, md[j].k, 1.0));
-                                else if (sg == 2)
+                                else if (s >= 2.0 * xt)
                                     G = Q.kf[2] * s;
                                 else
-                                    G = conv_long_G_mid(Q, md[j].k, lgB, rB,
-                                                        fmin(fmax(s, xt * (1.0 + 1e-15)), 2.0 * xt * (1.0 - 1e-15)));
+                                    G = conv_long_G_mid(Q, md[j].k, lgB, rB, s);
                                 hh *= G;
                             }
                             T0 += hh;

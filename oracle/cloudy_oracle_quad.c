@@ -581,7 +581,6 @@ static double co_one_minus_w(const co_dist *pdists, int N, int j, double s, doub
     return up / den;
 }
 
-static double co_softplus_q(double x) { return x > 0.0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
 
 /* E_tau[K(s (1 - tau), s tau)], tau ~ Beta(k, k), for the Long kernel */
 static double co_long_G(const co_kernel_func *kf, double k, double s) {
@@ -599,38 +598,59 @@ static double co_long_G(const co_kernel_func *kf, double k, double s) {
  * lengths (at least one each), q Gauss-Legendre points per panel.  Calls f(s, ln s, weight) with weight = the Gamma(A,
  * theta) density x ds.  Shared specification with csrc/quad_conv.hpp. */
 /* top: the highest power of s the integrand multiplies the Gamma(A) weight with (2 for the T_m rule) */
-static void co_conv_range_top(double A, double top, double *zlo, double *zhi) {
+static void co_conv_range_top(double A, double top, double *tlo, double *thi) {
     const double Am = A + top;
-    *zlo = fmax(-690.0, fmin(-1.0, (log(1e-13) + co_lgam(A + 1.0)) / A)); /* (-690: shapes clamped to k = eps) */
-    *zhi = Am + sqrt(60.0 * Am) + 30.0;
+    *tlo = fmax(-690.0, fmin(-1.0, (log(1e-13) + co_lgam(A + 1.0)) / A)); /* (-690: shapes clamped to k = eps) */
+    *thi = Am + sqrt(60.0 * Am) + 30.0 - 1.0;
 }
-void co_conv_range(double A, double *zlo, double *zhi) { co_conv_range_top(A, 2.0, zlo, zhi); }
+void co_conv_range(double A, double *tlo, double *thi) { co_conv_range_top(A, 2.0, tlo, thi); }
 typedef void (*co_node_fn)(double s, double ls, double wt, void *ctx);
+/* The variable of the rule: t in [t_lo, t_hi], u = s / theta = e^t for t < 0 (logarithmic near 0, where the weight is
+ * u^(A-1): in t it is a pure exponential) and u = 1 + t for t >= 0 (linear in the tail); t = 0 is always a panel edge, so
+ * every panel sees an analytic integrand.  One exponential and at most one logarithm per node. */
 static void co_conv_rule_top(double A, double top, double theta, const double *brk, int nbrk, int npan, int q,
                              const double *xg, const double *wg, co_node_fn f, void *ctx) {
-    double zlo, zhi, edge[5];
-    co_conv_range_top(A, top, &zlo, &zhi);
+    double tlo, thi, edge[6];
+    co_conv_range_top(A, top, &tlo, &thi);
     int ne = 0;
-    edge[ne++] = zlo;
-    for (int i = 0; i < nbrk && i < 3; ++i) {
-        const double u = brk[i] / theta;
-        if (!(u > 1e-300) || u > 600.0) continue;
-        const double z = u > 30.0 ? u : log(expm1(u)); /* inverse of u = ln(1 + e^z) */
-        if (z > edge[ne - 1] && z < zhi) edge[ne++] = z;
+    edge[ne++] = tlo;
+    int zero_in = 0;
+    for (int i = 0; i <= nbrk && i < 3; ++i) { /* break points (ascending) and, in its place, the junction t = 0 */
+        double t = INFINITY;
+        if (i < nbrk) {
+            const double u = brk[i] / theta;
+            if (!(u > 1e-300) || u > 600.0) continue;
+            t = u < 1.0 ? log(u) : u - 1.0;
+        }
+        if (!zero_in && t > 0.0) {
+            if (0.0 > edge[ne - 1]) edge[ne++] = 0.0;
+            zero_in = 1;
+        }
+        if (t > edge[ne - 1] && t < thi) edge[ne++] = t;
     }
-    edge[ne++] = zhi;
-    const double lgA = co_lgam(A), total = zhi - zlo;
+    if (!zero_in && 0.0 > edge[ne - 1]) edge[ne++] = 0.0;
+    edge[ne++] = thi;
+    const double lgA = co_lgam(A), total = thi - tlo, lth = log(theta);
     for (int sgm = 0; sgm + 1 < ne; ++sgm) {
         const double a = edge[sgm], len = edge[sgm + 1] - a;
         int n = (int)ceil(npan * (len / total) - 1e-9); /* (a whole range is npan panels exactly, whatever the rounding) */
         if (n < 1) n = 1;
         const double h = len / n;
+        const int lower = edge[sgm + 1] <= 0.0;
         for (int i = 0; i < n; ++i)
             for (int g = 0; g < q; ++g) {
-                const double z = a + h * (i + 0.5) + 0.5 * h * xg[g];
-                const double u = co_softplus_q(z), lu = log(u);
-                const double wt = 0.5 * h * wg[g] * exp((A - 1.0) * lu - u - lgA) / (1.0 + exp(-z));
-                f(u * theta, lu + log(theta), wt, ctx);
+                const double t = a + h * (i + 0.5) + 0.5 * h * xg[g];
+                double u, lu, lw;
+                if (lower) { /* u = e^t, du = u dt */
+                    u = exp(t);
+                    lu = t;
+                    lw = A * t - u - lgA;
+                } else { /* u = 1 + t */
+                    u = 1.0 + t;
+                    lu = log(u);
+                    lw = (A - 1.0) * lu - u - lgA;
+                }
+                f(u * theta, lu + lth, 0.5 * h * wg[g] * exp(lw), ctx);
             }
     }
 }
