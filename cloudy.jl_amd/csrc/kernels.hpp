@@ -101,10 +101,24 @@ __host__ __device__ constexpr int trisym(int p, int q) {
 // RN(q + e r) is the correctly rounded quotient (Markstein's correction step) -- 3 VALU ops, no v_div_*.
 __device__ __forceinline__ double div_by_const(double x, double d, double r) {
     const double q = x * r;
-    const double e = fma(-q, d, x);
-    const double qc = fma(e, r, q);
-    return (fabs(q) <= 1.7976931348623157e308) ? qc : q;  // keep Inf / NaN from the first product
-    // (not `q - q == 0`: under -ffp-contract=fast that contracts to fma(x, r, -q), the rounding error of q)
+    // Inf / NaN of the first product must survive: there the residual is NaN, and v_min_f64 (minNum: the non-NaN operand)
+    // turns it into a finite number, so the FMA returns q itself -- one instruction instead of a compare and two selects
+    const double e = __builtin_fmin(fma(-q, d, x), 1.7976931348623157e308);
+    return fma(e, r, q);
+}
+
+// x / d for a divisor in the normal range (eps < d < 1e150, the guarded moments and the clamped shape of the closure
+// inversion): the reciprocal refinement, quotient, exact residual and final FMA of the IEEE division sequence without its
+// v_div_scale / v_div_fixup range handling -- the same bits as x / d there (the final FMA rounds the same exact value),
+// 8 instead of 11 instructions.  A non-finite numerator gives NaN where IEEE gives Inf.
+__device__ __forceinline__ double div_normal(double x, double d) {
+#if defined(CLOUDY_IEEE_DIV) || defined(CLOUDY_IEEE_CLOSURE_DIV)
+    return x / d;
+#else
+    const double r = recip_fast(d);
+    const double q = x * r;
+    return fma(fma(-d, q, x), r, q);
+#endif
 }
 
 // update_dist_from_moments, ParticleDistributions.jl:456-476 / :512-523 (normalised moments in)
@@ -136,13 +150,15 @@ __device__ __forceinline__ void invert_closure(int dist_type, double m0, double 
     }
     if (m0 > kEps && m1 > kEps) {
         n = m0;
-        const double mean = m1 / m0;
+        const double mean = div_normal(m1, m0);
         if (dist_type == DIST_GAMMA) {
-            double kk = mean / (m2 / m1 - mean);
+            // (the second quotient keeps the IEEE sequence: its divisor may be zero or subnormal -> k = kmax / kmin)
+            double kk = mean / (div_normal(m2, m1) - mean);
             // max(kmin, min(kmax, kk)) with Julia's NaN-propagating min/max
-            double inner = (kk < kmax || kk != kk) ? kk : kmax;
-            k = (inner > kmin || inner != inner) ? inner : kmin;
-            th = mean / k;
+            // (v_min / v_max drop a NaN operand, so the NaN of 0/0 is put back by one select)
+            const double clamped = __builtin_fmax(__builtin_fmin(kk, kmax), kmin);
+            k = (kk != kk) ? kk : clamped;
+            th = div_normal(mean, k);
         } else {  // Exponential :512-523, Monodisperse :530-541
             k = 1.0;
             th = mean;
