@@ -558,9 +558,9 @@ def _cfg4q_variant(pkg, rank, world, measured, n=CFG4Q_PARCELS, reps=3):
 
 def _cfg4q_converged_variant(pkg, rank, world, measured, fixed_ms, n=CFG4Q_PARCELS, reps=3, q=8):
     """The same batch through a CLOUDY_QUAD_CONVERGED plan (csrc/quad_conv.hpp): the integrals split along the kink of the
-    hydrodynamic kernel -- closed forms (incomplete beta) for Q and R, one 1-D rule per mode for the weighting_fn split --
-    reaching the reference's adaptive quadgk answer to <= 1e-9 of scale where the 10-point rule has ~1e-3
-    (tests/test_numerical_oracle.py).  Reports the cost ratio to the 10-point rule."""
+    hydrodynamic kernel -- closed forms (incomplete beta) for Q and R, one adaptive Gauss-Kronrod rule per mode for the
+    weighting_fn split -- reaching the reference's adaptive quadgk answer to <= 1e-9 of scale where the 10-point rule has
+    ~1e-3 (tests/test_numerical_oracle.py).  Reports the cost ratio to the 10-point rule."""
     import ctypes as C
 
     par = cfg4q_par(pkg)
@@ -578,9 +578,9 @@ def _cfg4q_converged_variant(pkg, rank, world, measured, fixed_ms, n=CFG4Q_PARCE
     mag = np.abs(d[1]) + np.abs(d[4]) + np.abs(d[7])
     ok = np.isfinite(net)
     out = {"workload": f"cfg4q_converged: the cfg4q batch ({n} parcels/GPU, 3 Gamma modes, hydrodynamic kernel function) "
-                       f"in converged mode: region integrals in closed form, {q}-point Gauss-Legendre panels x 48 for the "
-                       "weighting_fn split; error vs nested adaptive quadrature of the reference integrals <= 1e-9 of scale "
-                       "(10-point rule: 3e-4 ... 1e-2)",
+                       "in converged mode: region integrals in closed form, an adaptive Gauss-Kronrod (7, 15) rule per mode "
+                       "(relative tolerance 1e-9) for the weighting_fn split; error vs nested adaptive quadrature of the "
+                       "reference integrals <= 1e-9 of scale (10-point rule: 3e-4 ... 1e-2)",
            "value": n * world / (ms * 1e-3), "unit": "parcel-RHS/s", "kernel_ms": ms,
            "kernel": f"cloudy_jit_quad_n3c{q}_hydro_f64" if plan.specialized else "coal_rhs_quad_kernel<3, 2, double, true>",
            "cost_ratio_to_10pt_rule": ms / fixed_ms if fixed_ms else None,

@@ -171,7 +171,8 @@ QUAD_FIXED, QUAD_CONVERGED = 0, 1   # cloudy_plan_desc.quad_mode
 def numerical_plan(dist_types, kernel_func, norms, quad_order=10, k_range=(EPS, 10.0), dtype=0, specialize=0, quad_mode=0):
     """Cached NumericalPlan (one per distinct configuration).  quad_mode: QUAD_FIXED = one quad_order-point Gauss rule
     per distribution; QUAD_CONVERGED = the integrals split along the kernel function's non-smooth sets (closed forms +
-    one 1-D rule of quad_order points per panel per mode, csrc/quad_conv.hpp)."""
+    one adaptive Gauss-Kronrod rule per mode, csrc/quad_conv.hpp; quad_order = points per panel of the inner rule of a
+    Lognormal mode)."""
     key = (tuple(int(t) for t in dist_types), kernel_func, tuple(norms), int(quad_order), tuple(k_range), int(dtype),
            int(specialize), int(quad_mode))
     if key not in _numerical_plans:

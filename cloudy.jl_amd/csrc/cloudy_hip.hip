@@ -330,7 +330,8 @@ int build_host_plan(const cloudy_plan_desc *d, cloudy_plan **out, std::vector<do
                 return fail(CLOUDY_EINVAL, "kernel_func_params[%d] is NaN", k);
             }
         if (d->quad_mode == CLOUDY_QUAD_CONVERGED) {
-            // quad_conv.hpp: quad_order Gauss-Legendre points per panel of the one 1-D rule the mode needs
+            // quad_conv.hpp: quad_order Gauss-Legendre points per panel of the inner rule of a Lognormal mode's T_m (the
+            // adaptive rules carry their own Gauss-Kronrod nodes)
             h.q.mode = QUAD_CONVERGED;
             h.q.nq = d->quad_order;
             h.q.deg = 0;

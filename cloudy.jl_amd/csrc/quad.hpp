@@ -33,7 +33,7 @@ constexpr int kQuadDegMax = 24;  // degree of the start-value polynomials
 enum { QUAD_FIXED = 0, QUAD_CONVERGED = 1 };  // cloudy_plan_desc.quad_mode
 struct QArgs {  // wave-uniform constants of a NumericalCoalStyle plan
     // mode QUAD_FIXED: nq points of the per-distribution Gauss rule; QUAD_CONVERGED (quad_conv.hpp): nq Gauss-Legendre
-    // points per panel of the 1-D rule, table = nq nodes on [-1, 1] then nq weights
+    // points per panel of the inner rule of a Lognormal mode's T_m, table = nq nodes on [-1, 1] then nq weights
     int32_t kind, nq, deg, mode;
     double kf[3];     // normalised kernel-function parameters (get_normalized_kernel_func, KernelFunctions.jl:124-154)
     double t_scale;   // t = k * t_scale - 1 maps [0, k_hi] onto [-1, 1]

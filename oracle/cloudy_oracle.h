@@ -154,16 +154,19 @@ int co_get_coal_ints_numerical_fixed(const co_dist *pdists, int N, const co_kern
  * (Coalescence.jl:503-708) -- slow; generates tests/golden/numerical_adaptive.json.  Q, R: [orders][N][N]; S: [orders][2][N] */
 int co_get_coal_ints_numerical_adaptive(const co_dist *pdists, int N, const co_kernel_func *kf, double eps_outer,
                                         double eps_inner, double *out, double *Q, double *R, double *S);
-/* cloudy_oracle_quad.c, converged mode (CLOUDY_QUAD_CONVERGED): closed forms for Q and R, one 1-D rule per mode for the
- * weighting_fn split; q Gauss-Legendre points per panel, npan panels */
+/* cloudy_oracle_quad.c, converged mode (CLOUDY_QUAD_CONVERGED): closed forms for Q and R, adaptive Gauss-Kronrod (7, 15)
+ * rules for the weighting_fn split (and a Gamma-Lognormal pair's P(Y' < X')); tol = their acceptance tolerance
+ * (CO_CONV_TOL in the HIP kernels), q = points per panel of the inner rule of a Lognormal mode's T_m */
+#define CO_CONV_TOL 1e-9
 double co_inc_beta(double a, double b, double x);
 int co_gauss_legendre_rule(int q, double *x, double *w);
 void co_conv_range(double A, double *zlo, double *zhi);
-int co_get_coal_ints_numerical_converged(const co_dist *pdists, int N, const co_kernel_func *kf, int q, int npan,
+long co_conv_node_count(int reset); /* integrand evaluations of the adaptive rules on this thread since the last reset */
+int co_get_coal_ints_numerical_converged(const co_dist *pdists, int N, const co_kernel_func *kf, int q, double tol,
                                          double *out, double *scale);
-int co_rhs_coal_numerical_converged(const co_params *p, const co_kernel_func *kf_normalized, int q, int npan,
+int co_rhs_coal_numerical_converged(const co_params *p, const co_kernel_func *kf_normalized, int q, double tol,
                                     const double *mom, double *dmom, double *scale);
-int co_rhs_coal_numerical_converged_batch(const co_params *p, const co_kernel_func *kf_normalized, int q, int npan,
+int co_rhs_coal_numerical_converged_batch(const co_params *p, const co_kernel_func *kf_normalized, int q, double tol,
                                           long n_parcels, long ld, const double *mom, double *dmom, double *scale,
                                           int n_threads);
 int co_rhs_coal_numerical(const co_params *p, const co_kernel_func *kf_normalized, int nq, const double *mom,

@@ -137,9 +137,11 @@ def lib():
         L.co_inc_beta.restype = C.c_double
         L.co_inc_beta.argtypes = [C.c_double, C.c_double, C.c_double]
         L.co_gauss_legendre_rule.argtypes = [C.c_int, _dp, _dp]
-        L.co_get_coal_ints_numerical_converged.argtypes = [C.POINTER(Dist), C.c_int, C.POINTER(KernelFunc), C.c_int, C.c_int,
+        L.co_get_coal_ints_numerical_converged.argtypes = [C.POINTER(Dist), C.c_int, C.POINTER(KernelFunc), C.c_int, C.c_double,
                                                            _dp, _dp]
-        L.co_rhs_coal_numerical_converged_batch.argtypes = [C.POINTER(Params), C.POINTER(KernelFunc), C.c_int, C.c_int,
+        L.co_conv_node_count.argtypes = [C.c_int]
+        L.co_conv_node_count.restype = C.c_long
+        L.co_rhs_coal_numerical_converged_batch.argtypes = [C.POINTER(Params), C.POINTER(KernelFunc), C.c_int, C.c_double,
                                                             C.c_long, C.c_long, _dp, _dp, _dp, C.c_int]
         L.co_get_coal_ints_numerical_adaptive.argtypes = [C.POINTER(Dist), C.c_int, C.POINTER(KernelFunc), C.c_double,
                                                           C.c_double, _dp, _dp, _dp, _dp]
@@ -482,19 +484,24 @@ def get_coal_ints_numerical_fixed(pdists, kf, nq=10, with_scale=False):
     return (out, sc) if with_scale else out
 
 
-CONV_PANELS = 48   # panels of the converged mode's 1-D rule (kConvPanels in csrc/quad_conv.hpp)
+CONV_TOL = 1e-9   # acceptance tolerance of the converged mode's adaptive rules (kConvTol in csrc/quad_conv.hpp)
 
 
-def get_coal_ints_numerical_converged(pdists, kf, q=8, npan=CONV_PANELS, with_scale=False):
+def get_coal_ints_numerical_converged(pdists, kf, q=8, tol=CONV_TOL, with_scale=False, with_nodes=False):
     """get_coal_ints(::NumericalCoalStyle, ...) in converged mode (cloudy_oracle_quad.c): closed forms for Q and R, one
-    composite Gauss-Legendre rule (npan panels x q points) per mode for the weighting_fn split."""
+    adaptive Gauss-Kronrod (7, 15) rule per mode for the weighting_fn split (acceptance tolerance tol; q = points per panel
+    of the inner rule of a Lognormal mode).  with_nodes: also the number of integrand evaluations of the adaptive rules."""
     arr = (Dist * len(pdists))(*pdists)
     nmom = sum(nparams(d.type) for d in pdists)
     out, sc = np.zeros(nmom), np.zeros(nmom)
-    r = lib().co_get_coal_ints_numerical_converged(arr, len(pdists), C.byref(kf), int(q), int(npan), _d(out), _d(sc))
+    lib().co_conv_node_count(1)
+    r = lib().co_get_coal_ints_numerical_converged(arr, len(pdists), C.byref(kf), int(q), float(tol), _d(out), _d(sc))
+    nodes = lib().co_conv_node_count(1)
     if r < 0:
         raise ValueError("get_coal_ints_numerical_converged: " + ("Lognormal / Monodisperse modes are not served"
                                                                   if r == -2 else "bad arguments"))
+    if with_nodes:
+        return (out, sc, nodes) if with_scale else (out, nodes)
     return (out, sc) if with_scale else out
 
 
@@ -530,7 +537,7 @@ def rhs_coal_numerical_batch(p, kf_normalized, nq, mom, with_scale=False, n_thre
     return (d, s) if with_scale else d
 
 
-def rhs_coal_numerical_converged_batch(p, kf_normalized, q, mom, npan=CONV_PANELS, with_scale=False, n_threads=0, out=None):
+def rhs_coal_numerical_converged_batch(p, kf_normalized, q, mom, tol=CONV_TOL, with_scale=False, n_threads=0, out=None):
     """rhs_coal!(NumericalCoalStyle(), ...) in converged mode for a moment-major batch (same-rule restatement of
     csrc/quad_conv.hpp); p: make_params(...) (its tensors are unused)."""
     m = _darr(mom)
@@ -538,7 +545,7 @@ def rhs_coal_numerical_converged_batch(p, kf_normalized, q, mom, npan=CONV_PANEL
     assert nm == nmom_of(p)
     d = out if out is not None else np.empty_like(m)
     s = np.empty_like(m) if with_scale else None
-    if lib().co_rhs_coal_numerical_converged_batch(C.byref(p), C.byref(kf_normalized), int(q), int(npan), n, n, _d(m),
+    if lib().co_rhs_coal_numerical_converged_batch(C.byref(p), C.byref(kf_normalized), int(q), float(tol), n, n, _d(m),
                                                    _d(d), _d(s) if s is not None else None, int(n_threads)) < 0:
         raise ValueError("rhs_coal_numerical_converged_batch failed (Lognormal modes are not served in converged mode)")
     return (d, s) if with_scale else d

@@ -478,35 +478,206 @@ static double co_pmom(const co_dist *d, double q, double xt) {
     return co_gmom(d, q) * co_gamma_inc_p(k + q, xt / d->theta);
 }
 
-static void co_conv_rule_top(double A, double top, double theta, const double *brk, int nbrk, int npan, int q,
-                             const double *xg, const double *wg, void (*f)(double, double, double, void *), void *ctx);
-typedef struct {
-    double mu, sg, c, acc, inv_theta;
-    int i;
-} co_H_ctx;
-static void co_H_node(double s, double ls, double wt, void *v) {
-    co_H_ctx *h = (co_H_ctx *)v;
-    double xi = 1.0;
-    for (int t = 0; t < h->i; ++t) xi *= s * h->inv_theta;
-    h->acc += wt * xi * co_conv_norm_cdf((ls - h->mu) / h->sg - h->c * h->sg);
+static void co_conv_range_top(double A, double top, double *tlo, double *thi);
+/* ---- the adaptive 1-D rule of converged mode (shared specification with csrc/quad_conv.hpp) ----
+ * Variable t = ln(s / theta) in [t_lo, t_hi]: the Gamma weight u^(A-1) e^-u du is exp(A t - e^t) dt, entire in t (the
+ * bisection deals with the double-exponential upper flank).  Initial panels: the union of CO_CONV_NINIT equal
+ * pieces of [t_lo, t_hi] (width h0) with a list of marks -- the kinks of the integrand (Long: s = x_t, 2 x_t) and,
+ * for every other mode, marks graded around its core, where weighting_fn has its transitions: ln s = c and c +- w 2^i,
+ * i = 0 .. I (c = ln of the mode's mean size; w = sigma for a Lognormal mode, 1 / sqrt(max(k, 1)) for a Gamma mode; I = the
+ * first doubling at which w 2^I reaches the equal pieces' own width h0, at most CO_CONV_IMAX) -- walked from t_lo upwards (next edge = the smallest mark or equal-piece edge more than `gap` = 1e-7
+ * (t_hi - t_lo) beyond the current one).  So a spike of another mode, however narrow, meets panels of its own size, and
+ * the transitions in its flanks lie well inside a panel, not at an edge where the nodes would miss them.  Every initial panel
+ * is integrated by bisection with the Gauss-Kronrod (7, 15) pair: a panel is accepted when, for each output, |K15 - G7| <=
+ * tol x max(|the integral accumulated so far, this panel included|, CO_CONV_FLOOR x the output's scale) -- the relative
+ * criterion of the reference's quadgk(rtol), with the accumulated value standing in for the final one; the floor (1e-10 of
+ * the value the integral would have with 1 - w = 1) only ends the refinement of integrals that are zero to that level --
+ * at depth CO_CONV_LMAX, or once the rule has spent its budget of panel evaluations; the accepted value is K15.  With tol = 1e-9 the accepted K15 values are good to
+ * ~1e-14 of scale (G7 is the estimate's accuracy, K15 has 1.6 x its order), so a decision that flips on a rounding
+ * difference between two implementations moves the result by that much, not by tol. */
+#define CO_CONV_NINIT 16
+#define CO_CONV_LMAX 12
+#define CO_CONV_IMAX 12
+#define CO_CONV_FLOOR 1e-10
+#define CO_CONV_BUDGET 8192   /* panel evaluations of one rule (Gamma weight) */
+#define CO_CONV_BUDGET_LN 1024 /* ... of the outer rule of a Lognormal mode's T_m (96 q inner points per node) */
+#define CO_CONV_MAX_MARKS 96
+static const double CO_GK_X[15] = {-0.991455371120812639206854697526329, -0.949107912342758524526189684047851,
+                                   -0.864864423359769072789712788640926, -0.741531185599394439863864773280788,
+                                   -0.586087235467691130294144838258730, -0.405845151377397166906606412076961,
+                                   -0.207784955007898467600689403773245, 0.0,
+                                   0.207784955007898467600689403773245,  0.405845151377397166906606412076961,
+                                   0.586087235467691130294144838258730,  0.741531185599394439863864773280788,
+                                   0.864864423359769072789712788640926,  0.949107912342758524526189684047851,
+                                   0.991455371120812639206854697526329};
+static const double CO_GK_WK[15] = {0.022935322010529224963732008058970, 0.063092092629978553290700663189204,
+                                    0.104790010322250183839876322541518, 0.140653259715525918745189590510238,
+                                    0.169004726639267902826583426598550, 0.190350578064785409913256402421014,
+                                    0.204432940075298892414161999234649, 0.209482141084727828012999174891714,
+                                    0.204432940075298892414161999234649, 0.190350578064785409913256402421014,
+                                    0.169004726639267902826583426598550, 0.140653259715525918745189590510238,
+                                    0.104790010322250183839876322541518, 0.063092092629978553290700663189204,
+                                    0.022935322010529224963732008058970};
+static const double CO_GK_WG[15] = {0.0, 0.129484966168869693270611432679082, 0.0, 0.279705391489276667901467771423780,
+                                    0.0, 0.381830050505118944950369775488975, 0.0, 0.417959183673469387755102040816327,
+                                    0.0, 0.381830050505118944950369775488975, 0.0, 0.279705391489276667901467771423780,
+                                    0.0, 0.129484966168869693270611432679082, 0.0};
+static _Thread_local long co_conv_nodes_; /* integrand evaluations of the adaptive rules since the last reset */
+long co_conv_node_count(int reset) {
+    const long n = co_conv_nodes_;
+    if (reset) co_conv_nodes_ = 0;
+    return n;
 }
-/* P(L'_c < G'_a): G' ~ Gamma(k_g + a, theta_g) (the size-biased law of order a of a Gamma-family mode), L' the size-biased
- * law of order c of a Lognormal mode, = E_{G'}[Phi((ln G' - mu - c sigma^2) / sigma)] by the 1-D rule of this file.  As in
- * the HIP kernel, the orders a = f + i (f = 0 or 1/3, i = 0..3) share the nodes of the base shape A0 = k_g + f:
- * E_{Gamma(A0 + i)}[g] = E_{Gamma(A0)}[u^i g] / (A0)_i. */
-static double co_conv_H(const co_dist *g, double a, const co_dist *l, double c, int npan, int q, const double *xg,
-                        const double *wg) {
-    const int i = (int)floor(a + 1e-9);
-    const double f = (a - i) < 0.1 ? 0.0 : 1.0 / 3.0, A0 = co_shape(g) + f;
-    co_H_ctx h = {l->theta, l->k, c, 0.0, 1.0 / g->theta, i};
-    co_conv_rule_top(A0, 4.0, g->theta, NULL, 0, npan, q, xg, wg, co_H_node, &h);
-    double poch = 1.0;
-    for (int t = 0; t < i; ++t) poch *= A0 + t;
-    return h.acc / poch;
+/* vals[0..nout) = the integrand at t (per unit t) */
+typedef void (*co_vec_fn)(double t, double *vals, void *ctx);
+#define CO_CONV_MAX_OUT 32
+/* marks[0..nmarks): see above; the estimate looks at outputs est_idx[0..n_est) only (NULL: all),
+ * scaleS[] = the scale of each output (see CO_CONV_FLOOR) */
+static void co_conv_adaptive(double tlo, double thi, const double *marks, int nmarks, int nout, const int *est_idx,
+                             int n_est, double tol, const double *scaleS, int budget, co_vec_fn f, void *ctx,
+                             double *out) {
+    double vals[CO_CONV_MAX_OUT], K[CO_CONV_MAX_OUT], G[CO_CONV_MAX_OUT];
+    const double h0 = (thi - tlo) / CO_CONV_NINIT, gap = 1e-7 * (thi - tlo);
+    double cur = tlo;
+    int io = 1;
+    while (cur < thi) {
+        double nxt = thi, own = tlo + h0 * io;
+        while (own <= cur + gap) {
+            ++io;
+            own = tlo + h0 * io;
+        }
+        if (own < nxt) nxt = own;
+        for (int m = 0; m < nmarks; ++m)
+            if (marks[m] > cur + gap && marks[m] < nxt) nxt = marks[m];
+        if (nxt > thi - gap) nxt = thi;
+        const double a0 = cur, h = nxt - cur;
+        cur = nxt;
+        int L = 0;
+        unsigned i = 0;
+        for (;;) {
+            const double w = ldexp(h, -L), hw = 0.5 * w, c = (a0 + w * i) + hw;
+            for (int o = 0; o < nout; ++o) K[o] = G[o] = 0.0;
+            --budget;
+            for (int g = 0; g < 15; ++g) {
+                f(c + hw * CO_GK_X[g], vals, ctx);
+                ++co_conv_nodes_;
+                for (int o = 0; o < nout; ++o) {
+                    K[o] += CO_GK_WK[g] * vals[o];
+                    if (g & 1) G[o] += CO_GK_WG[g] * vals[o];
+                }
+            }
+            int ok = 1;
+            for (int e = 0; e < (est_idx ? n_est : nout); ++e) {
+                const int o = est_idx ? est_idx[e] : e;
+                /* (a NaN estimate accepts: the NaN reaches the output) */
+                if (fabs(K[o] - G[o]) * hw > tol * fmax(fabs(out[o] + K[o] * hw), CO_CONV_FLOOR * scaleS[o])) ok = 0;
+            }
+            if (ok || L == CO_CONV_LMAX || budget <= 0) {
+                for (int o = 0; o < nout; ++o) out[o] += K[o] * hw;
+                ++i;
+                while (L > 0 && !(i & 1u)) {
+                    i >>= 1;
+                    --L;
+                }
+                if (L == 0) break;
+            } else {
+                ++L;
+                i <<= 1;
+            }
+        }
+    }
+}
+/* t of a size s in the variable of a rule with scale theta */
+static double co_conv_t_of_s(double s, double theta) { return log(s / theta); }
+/* ln of the mean size of a mode and the width of its core in ln s */
+static double co_ln_mean(const co_dist *d) {
+    if (d->type == CO_LOGNORMAL) return d->theta + 0.5 * d->k * d->k;
+    return log(co_shape(d) * d->theta);
+}
+static double co_core_width(const co_dist *d) {
+    if (d->type == CO_LOGNORMAL) return d->k;
+    return 1.0 / sqrt(fmax(co_shape(d), 1.0));
+}
+/* the marks of a core (c, w) for a rule with equal pieces h0; theta > 0: a Gamma-weight rule with that scale (marks
+ * converted to its t), else a rule over ln s itself */
+static int co_core_marks(double c, double w, double h0, double theta, double *marks, int n) {
+    const double ratio = h0 / w; /* (every rule's variable is a logarithm of s: the equal pieces are h0 wide in ln s) */
+    int I = 0;
+    if (ratio > 1.0) I = ratio < 4096.0 ? (int)ceil(log2(ratio)) : CO_CONV_IMAX;
+    if (I > CO_CONV_IMAX) I = CO_CONV_IMAX;
+    for (int q = -(I + 1); q <= I + 1 && n < CO_CONV_MAX_MARKS; ++q) {
+        const double off = q == 0 ? 0.0 : (q < 0 ? -1.0 : 1.0) * ldexp(w, (q < 0 ? -q : q) - 1);
+        const double ls = c + off;
+        marks[n++] = theta > 0.0 ? ls - log(theta) : ls;
+    }
+    return n;
+}
+/* the Gamma(A) weight of the rule's variable at t: u, ln u and density x du/dt */
+static double co_conv_weight(double t, double A, double lgA, double *u, double *lu) {
+    *u = exp(t); /* du = u dt */
+    *lu = t;
+    return exp(A * t - *u - lgA);
+}
+
+/* P(L'_c < G'_a) for a Gamma-family mode G and a Lognormal mode L on the grid a = f + i (f = 0, 1/3; i = 0..3),
+ * c = 0, 1/3, 1, 4/3, 2, 7/3, 3, 10/3:  H[f][i][ci] = E_{Gamma(k_g + a, theta_g)}[Phi((ln x - mu - c sigma^2) / sigma)] by
+ * the adaptive rule; the orders i share the nodes of the base shape: E_{Gamma(A0 + i)}[g] = E_{Gamma(A0)}[u^i g] / (A0)_i.
+ * The error estimate looks at the four corner outputs (i = 0, 3; c = 0, 10/3). */
+typedef struct {
+    double A0, lgA, lth, mu, sg;
+} co_H_ctx;
+static void co_H_node(double t, double *vals, void *v) {
+    const co_H_ctx *h = (const co_H_ctx *)v;
+    double u, lu;
+    const double wt = co_conv_weight(t, h->A0, h->lgA, &u, &lu);
+    const double w0 = (lu + h->lth - h->mu) / h->sg;
+    double ph[8];
+    for (int c = 0; c < 8; ++c) ph[c] = co_conv_norm_cdf(w0 - ((c >> 1) + ((c & 1) ? 1.0 / 3.0 : 0.0)) * h->sg);
+    double wu = wt;
+    for (int i = 0; i < 4; ++i) {
+        for (int c = 0; c < 8; ++c) vals[8 * i + c] = wu * ph[c];
+        wu *= u;
+    }
+}
+typedef struct {
+    const co_dist *g, *l; /* the pair this grid belongs to */
+    double H[2][4][8];
+} co_H_grid;
+static void co_conv_H_grid(const co_dist *g, const co_dist *l, double tol, co_H_grid *out) {
+    out->g = g;
+    out->l = l;
+    static const int est_idx[4] = {0, 7, 24, 31};
+    for (int f = 0; f < 2; ++f) {
+        const double A0 = co_shape(g) + (f ? 1.0 / 3.0 : 0.0);
+        co_H_ctx h = {A0, co_lgam(A0), log(g->theta), l->theta, l->k};
+        double tlo, thi, acc[32], tolS[32], marks[CO_CONV_MAX_MARKS];
+        co_conv_range_top(A0, 4.0, &tlo, &thi);
+        int nm = 0;
+        nm = co_core_marks(l->theta + (5.0 / 3.0) * l->k * l->k, l->k, (thi - tlo) / CO_CONV_NINIT, g->theta, marks, nm); /* where the Phi's turn */
+        double poch = 1.0;
+        for (int i = 0; i < 4; ++i) {
+            for (int c = 0; c < 8; ++c) {
+                acc[8 * i + c] = 0.0;
+                tolS[8 * i + c] = poch;
+            }
+            poch *= A0 + i;
+        }
+        co_conv_adaptive(tlo, thi, marks, nm, 32, est_idx, 4, tol, tolS, CO_CONV_BUDGET, co_H_node, &h, acc);
+        poch = 1.0;
+        for (int i = 0; i < 4; ++i) {
+            for (int c = 0; c < 8; ++c) out->H[f][i][c] = acc[8 * i + c] / poch;
+            poch *= A0 + i;
+        }
+    }
+}
+/* look-up on the grid: a = f + i, c = cf + ci */
+static double co_conv_H(const co_H_grid *grid, double a, double c) {
+    const int i = (int)floor(a + 1e-9), ci = (int)floor(c + 1e-9);
+    const int f = (a - i) < 0.1 ? 0 : 1, cf = (c - ci) < 0.1 ? 0 : 1;
+    return grid->H[f][i][2 * ci + cf];
 }
 /* P(Y' < X'), X' / Y' the size-biased laws of orders a / b of modes j / k */
-static double co_conv_prob_less(const co_dist *dj, double a, const co_dist *dk, double b, int npan, int q,
-                                const double *xg, const double *wg) {
+static double co_conv_prob_less(const co_dist *dj, double a, const co_dist *dk, double b, const co_H_grid *hg) {
     const int lj = dj->type == CO_LOGNORMAL, lk = dk->type == CO_LOGNORMAL;
     if (!lj && !lk) {
         const double z = dj->theta / (dj->theta + dk->theta), omz = dk->theta / (dj->theta + dk->theta);
@@ -515,14 +686,14 @@ static double co_conv_prob_less(const co_dist *dj, double a, const co_dist *dk, 
     if (lj && lk) /* ln X' - ln Y' ~ N(mu_j + a s_j^2 - mu_k - b s_k^2, s_j^2 + s_k^2) */
         return co_conv_norm_cdf((dj->theta + a * dj->k * dj->k - dk->theta - b * dk->k * dk->k) /
                                 sqrt(dj->k * dj->k + dk->k * dk->k));
-    if (!lj) return co_conv_H(dj, a, dk, b, npan, q, xg, wg);      /* j Gamma, k Lognormal */
-    return 1.0 - co_conv_H(dk, b, dj, a, npan, q, xg, wg);         /* j Lognormal, k Gamma: 1 - P(X' < Y') */
+    if (!lj) return co_conv_H(hg, a, b);      /* j Gamma, k Lognormal: the grid of (G = j, L = k) */
+    return 1.0 - co_conv_H(hg, b, a);         /* j Lognormal, k Gamma: 1 - P(X' < Y'), the grid of (G = k, L = j) */
 }
 
 /* int int x^p y^q K(x, y) f_j(x) f_k(y) dx dy over (0, inf)^2 (closed forms; a Gamma-Lognormal pair of the hydrodynamic
  * kernel needs the 1-D rule for P(Y' < X')) */
 static double co_conv_pair(const co_kernel_func *kf, const co_dist *dj, const co_dist *dk, int p, int q, double *mag,
-                           int npan, int nq, const double *xg, const double *wg) {
+                           const co_H_grid *hg) {
     double dummy;
     if (!mag) mag = &dummy;
     switch (kf->kind) {
@@ -534,7 +705,7 @@ static double co_conv_pair(const co_kernel_func *kf, const co_dist *dj, const co
         double tot = 0.0, m = 0.0;
         for (int t = 0; t < 4; ++t) {
             const double al = term[t][0], be = term[t][1];
-            const double I = co_conv_prob_less(dj, p + al, dk, q + be, npan, nq, xg, wg); /* P(Y' < X') */
+            const double I = co_conv_prob_less(dj, p + al, dk, q + be, hg); /* P(Y' < X') */
             const double mm = term[t][2] * co_gmom(dj, p + al) * co_gmom(dk, q + be);
             tot += mm * (2.0 * I - 1.0);
             m += fabs(mm);
@@ -594,132 +765,98 @@ static double co_long_G(const co_kernel_func *kf, double k, double s) {
     return ca * s + (cb * s * s - ca * s) * P0 - 2.0 * cb * s * s * P1;
 }
 
-/* The 1-D rule.  Segments of [z_lo, z_hi] (split at brk[], s-units), `npan` panels shared out in proportion to their
- * lengths (at least one each), q Gauss-Legendre points per panel.  Calls f(s, ln s, weight) with weight = the Gamma(A,
- * theta) density x ds.  Shared specification with csrc/quad_conv.hpp. */
 /* top: the highest power of s the integrand multiplies the Gamma(A) weight with (2 for the T_m rule) */
 static void co_conv_range_top(double A, double top, double *tlo, double *thi) {
     const double Am = A + top;
     *tlo = fmax(-690.0, fmin(-1.0, (log(1e-13) + co_lgam(A + 1.0)) / A)); /* (-690: shapes clamped to k = eps) */
-    *thi = Am + sqrt(60.0 * Am) + 30.0 - 1.0;
+    *thi = log(Am + sqrt(60.0 * Am) + 30.0); /* (t = ln u) */
 }
 void co_conv_range(double A, double *tlo, double *thi) { co_conv_range_top(A, 2.0, tlo, thi); }
-typedef void (*co_node_fn)(double s, double ls, double wt, void *ctx);
-/* The variable of the rule: t in [t_lo, t_hi], u = s / theta = e^t for t < 0 (logarithmic near 0, where the weight is
- * u^(A-1): in t it is a pure exponential) and u = 1 + t for t >= 0 (linear in the tail); t = 0 is always a panel edge, so
- * every panel sees an analytic integrand.  One exponential and at most one logarithm per node. */
-static void co_conv_rule_top(double A, double top, double theta, const double *brk, int nbrk, int npan, int q,
-                             const double *xg, const double *wg, co_node_fn f, void *ctx) {
-    double tlo, thi, edge[6];
-    co_conv_range_top(A, top, &tlo, &thi);
-    int ne = 0;
-    edge[ne++] = tlo;
-    int zero_in = 0;
-    for (int i = 0; i <= nbrk && i < 3; ++i) { /* break points (ascending) and, in its place, the junction t = 0 */
-        double t = INFINITY;
-        if (i < nbrk) {
-            const double u = brk[i] / theta;
-            if (!(u > 1e-300) || u > 600.0) continue;
-            t = u < 1.0 ? log(u) : u - 1.0;
-        }
-        if (!zero_in && t > 0.0) {
-            if (0.0 > edge[ne - 1]) edge[ne++] = 0.0;
-            zero_in = 1;
-        }
-        if (t > edge[ne - 1] && t < thi) edge[ne++] = t;
-    }
-    if (!zero_in && 0.0 > edge[ne - 1]) edge[ne++] = 0.0;
-    edge[ne++] = thi;
-    const double lgA = co_lgam(A), total = thi - tlo, lth = log(theta);
-    for (int sgm = 0; sgm + 1 < ne; ++sgm) {
-        const double a = edge[sgm], len = edge[sgm + 1] - a;
-        int n = (int)ceil(npan * (len / total) - 1e-9); /* (a whole range is npan panels exactly, whatever the rounding) */
-        if (n < 1) n = 1;
-        const double h = len / n;
-        const int lower = edge[sgm + 1] <= 0.0;
-        for (int i = 0; i < n; ++i)
-            for (int g = 0; g < q; ++g) {
-                const double t = a + h * (i + 0.5) + 0.5 * h * xg[g];
-                double u, lu, lw;
-                if (lower) { /* u = e^t, du = u dt */
-                    u = exp(t);
-                    lu = t;
-                    lw = A * t - u - lgA;
-                } else { /* u = 1 + t */
-                    u = 1.0 + t;
-                    lu = log(u);
-                    lw = (A - 1.0) * lu - u - lgA;
-                }
-                f(u * theta, lu + lth, 0.5 * h * wg[g] * exp(lw), ctx);
-            }
-    }
-}
-static void co_conv_rule(double A, double theta, const double *brk, int nbrk, int npan, int q, const double *xg,
-                         const double *wg, co_node_fn f, void *ctx) {
-    co_conv_rule_top(A, 2.0, theta, brk, nbrk, npan, q, xg, wg, f, ctx);
-}
 
 typedef struct {
     const co_dist *pdists;
     int N, j;
     const co_kernel_func *kf;
-    double k, T[3];
+    double k, A, lgA, theta, lth;
 } co_T_ctx;
-static void co_T_node(double s, double ls, double wt, void *v) {
-    co_T_ctx *c = (co_T_ctx *)v;
+static void co_T_node(double t, double *vals, void *v) {
+    const co_T_ctx *c = (const co_T_ctx *)v;
+    double u, lu;
+    const double wt = co_conv_weight(t, c->A, c->lgA, &u, &lu);
+    const double s = u * c->theta, ls = lu + c->lth;
     double h = wt * co_one_minus_w(c->pdists, c->N, c->j, s, ls);
     if (c->kf->kind == CO_KF_LONG) h *= co_long_G(c->kf, c->k, s);
-    c->T[0] += h;
-    c->T[1] += h * s;
-    c->T[2] += h * s * s;
+    vals[0] = h;
+    vals[1] = h * s;
+    vals[2] = h * s * s;
 }
-
 /* ---- Lognormal modes (LN).  Moments and partial moments are closed forms (co_gmom, co_pmom); P(Y' < X') of the
- * hydrodynamic terms is Phi(.) for a Lognormal pair and the 1-D rule for a Gamma-Lognormal pair (co_conv_prob_less).
+ * hydrodynamic terms is Phi(.) for a Lognormal pair and the adaptive rule for a Gamma-Lognormal pair (co_conv_H_grid).
  * The sum of two Lognormal variates has no closed law, so T_m of a Lognormal mode keeps two variables,
  *   s = x + y and t = ln(x / y):   f(x) f(y) dx dy = n^2 g(ln x) g(ln y) d(ln s) dt,   g = the normal density of ln x,
  *   T_m = 1/2 n^2 int d(ln s) s^m (1 - w(s)) G2(ln s),   G2 = 2 int_0^inf dt K(x, y) g(ln x) g(ln y),
  *   ln x = ln s - ln(1 + e^-t),  ln y = ln s - ln(1 + e^t)
  * with weighting_fn outside the inner integral (it depends on s alone) and the kink of the hydrodynamic kernel on the
- * boundary t = 0.  Outer: CO_LN_PAN1 panels over ln s in [mu - 8.5 sigma, mu + 8.5 sigma + (gamma + 2) sigma^2 + ln 2];
- * inner: CO_LN_PAN2 panels over t in [0, max(ln s - mu, 0) + 12 sigma]; q Gauss-Legendre points per panel each.  (The
- * Long kernel's jumps x = x_t, y = x_t are curves in (ln s, t): that combination converges algebraically.) */
-#define CO_LN_PAN1 64
+ * boundary t = 0.  Outer: the adaptive rule over ln s in [mu - 8.5 sigma, mu + 8.5 sigma + (gamma + 2) sigma^2 + ln 2]
+ * (budget CO_CONV_BUDGET_LN), marks at the other modes' cores (and ln x_t, ln 2 x_t for Long); inner: CO_LN_PAN2
+ * panels of q Gauss-Legendre points over t in [0, max(ln s - mu, 0) + 12 sigma].  (The Long kernel's jumps x = x_t,
+ * y = x_t are curves in (ln s, t): that combination converges algebraically.) */
 #define CO_LN_PAN2 12
+typedef struct {
+    const co_dist *pdists;
+    int N, j, q;
+    const co_kernel_func *kf;
+    const double *xg, *wg;
+} co_TL_ctx;
+static void co_TL_node(double ls, double *vals, void *v) {
+    const co_TL_ctx *c = (const co_TL_ctx *)v;
+    const double mu = c->pdists[c->j].theta, sg = c->pdists[c->j].k, c2 = 1.0 / (2.0 * sg * sg), nrm = c2 / M_PI;
+    const double s = exp(ls), Tm = fmax(ls - mu, 0.0) + 12.0 * sg, h2 = Tm / CO_LN_PAN2;
+    double G2 = 0.0;
+    for (int i2 = 0; i2 < CO_LN_PAN2; ++i2)
+        for (int g2 = 0; g2 < c->q; ++g2) {
+            const double t = h2 * (i2 + 0.5) + 0.5 * h2 * c->xg[g2];
+            const double spm = log1p(exp(-t)); /* softplus(-t); softplus(t) = t + softplus(-t) */
+            const double lx = ls - spm, ly = ls - t - spm;
+            const double dx = lx - mu, dy = ly - mu;
+            G2 += (0.5 * h2 * c->wg[g2]) * co_kernel_func_eval(c->kf, exp(lx), exp(ly)) * exp(-(dx * dx + dy * dy) * c2);
+        }
+    const double val = co_one_minus_w(c->pdists, c->N, c->j, s, ls) * (2.0 * nrm * G2);
+    vals[0] = val;
+    vals[1] = val * s;
+    vals[2] = val * s * s;
+}
+/* totals[m]: the value of T_m with 1 - w = 1 (closed form), the scale of the error estimate */
 static void co_conv_T_lognormal(const co_dist *pdists, int N, int j, const co_kernel_func *kf, int q, const double *xg,
-                                const double *wg, double T[3]) {
+                                const double *wg, double tol, const double totals[3], double T[3]) {
     static const double gtop[4] = {0.0, 1.0, 4.0 / 3.0, 2.0};
     const double mu = pdists[j].theta, sg = pdists[j].k;
     const double L0 = mu - 8.5 * sg, L1 = mu + 8.5 * sg + (gtop[kf->kind] + 2.0) * sg * sg + 0.6931471805599453;
-    const double h1 = (L1 - L0) / CO_LN_PAN1, c2 = 1.0 / (2.0 * sg * sg), nrm = c2 / M_PI; /* 1 / (2 pi sigma^2) */
-    T[0] = T[1] = T[2] = 0.0;
-    for (int i1 = 0; i1 < CO_LN_PAN1; ++i1)
-        for (int g1 = 0; g1 < q; ++g1) {
-            const double ls = L0 + h1 * (i1 + 0.5) + 0.5 * h1 * xg[g1], s = exp(ls);
-            const double Tm = fmax(ls - mu, 0.0) + 12.0 * sg, h2 = Tm / CO_LN_PAN2;
-            double G2 = 0.0;
-            for (int i2 = 0; i2 < CO_LN_PAN2; ++i2)
-                for (int g2 = 0; g2 < q; ++g2) {
-                    const double t = h2 * (i2 + 0.5) + 0.5 * h2 * xg[g2];
-                    const double spm = log1p(exp(-t)); /* softplus(-t); softplus(t) = t + softplus(-t) */
-                    const double lx = ls - spm, ly = ls - t - spm;
-                    const double dx = lx - mu, dy = ly - mu;
-                    G2 += (0.5 * h2 * wg[g2]) * co_kernel_func_eval(kf, exp(lx), exp(ly)) * exp(-(dx * dx + dy * dy) * c2);
-                }
-            const double v = (0.5 * h1 * wg[g1]) * co_one_minus_w(pdists, N, j, s, ls) * (2.0 * nrm * G2);
-            T[0] += v;
-            T[1] += v * s;
-            T[2] += v * s * s;
-        }
     const double pref = 0.5 * pdists[j].n * pdists[j].n;
+    co_TL_ctx c = {pdists, N, j, q, kf, xg, wg};
+    /* marks in ln s (no junction): the other modes' cores and the Long kernel's x_t, 2 x_t */
+    double marks[CO_CONV_MAX_MARKS], tolS[3];
+    int nm = 0;
+    for (int m = 0; m < N; ++m)
+        if (m != j) nm = co_core_marks(co_ln_mean(&pdists[m]), co_core_width(&pdists[m]), (L1 - L0) / CO_CONV_NINIT, 0.0, marks, nm);
+    if (kf->kind == CO_KF_LONG) {
+        marks[nm++] = log(kf->p[0]);
+        marks[nm++] = log(2.0 * kf->p[0]);
+    }
+    for (int m = 0; m < 3; ++m) {
+        T[m] = 0.0;
+        tolS[m] = totals[m] / pref;
+    }
+    co_conv_adaptive(L0, L1, marks, nm, 3, NULL, 0, tol, tolS, CO_CONV_BUDGET_LN, co_TL_node, &c, T);
     for (int m = 0; m < 3; ++m) T[m] *= pref;
 }
 
 /* get_coal_ints(::NumericalCoalStyle, ...) in converged mode; Gamma / Exponential / Lognormal modes.  q = points per
- * panel, npan = panels of the 1-D rule.  out / scale as co_get_coal_ints_numerical_fixed. */
-int co_get_coal_ints_numerical_converged(const co_dist *pdists, int N, const co_kernel_func *kf, int q, int npan,
+ * panel of the inner rule of a Lognormal mode's T_m (the only fixed rule left), tol = the acceptance tolerance of the
+ * adaptive rules (CO_CONV_TOL = 1e-9 in the HIP kernels).  out / scale as co_get_coal_ints_numerical_fixed. */
+int co_get_coal_ints_numerical_converged(const co_dist *pdists, int N, const co_kernel_func *kf, int q, double tol,
                                          double *out, double *scale) {
-    if (N < 1 || N > CO_MAX_MODES || q < 1 || q > CO_MAX_QUAD || npan < 1) return -1;
+    if (N < 1 || N > CO_MAX_MODES || q < 1 || q > CO_MAX_QUAD || !(tol > 0.0)) return -1;
     int np[CO_MAX_MODES];
     for (int i = 0; i < N; ++i) {
         np[i] = co_nparams(pdists[i].type);
@@ -735,47 +872,71 @@ int co_get_coal_ints_numerical_converged(const co_dist *pdists, int N, const co_
         acc[k_][m_] += (v_);       \
         mag[k_][m_] += fabs(v_);   \
     } while (0)
+#define ADDM(k_, m_, v_, mg_) \
+    do {                      \
+        acc[k_][m_] += (v_);  \
+        mag[k_][m_] += (mg_); \
+    } while (0)
     static const double gam_of_kind[4] = {0.0, 1.0, 4.0 / 3.0, 0.0};
     for (int j = 0; j < N; ++j) {
         const co_dist *dj = &pdists[j];
         const double kj = co_shape(dj);
         /* self collisions: S_1 + S_2 - R_jj = (-s0 / 2, 0, sab); T_m moves to the next mode */
         double m0, m1, m2, m3;
-        const double s0 = co_conv_pair(kf, dj, dj, 0, 0, &m0, npan, q, xg, wg), sab = co_conv_pair(kf, dj, dj, 1, 1, &m1, npan, q, xg, wg);
-#define ADDM(k_, m_, v_, mg_) \
-    do {                      \
-        acc[k_][m_] += (v_);  \
-        mag[k_][m_] += (mg_); \
-    } while (0)
+        const double s0 = co_conv_pair(kf, dj, dj, 0, 0, &m0, NULL), sab = co_conv_pair(kf, dj, dj, 1, 1, &m1, NULL);
         ADDM(j, 0, -0.5 * s0, 0.5 * m0);
         ADDM(j, 2, sab, m1);
-        if (j < N - 1 && dj->n > 0.0 && dj->type == CO_LOGNORMAL) {
-            double T[3];
-            co_conv_T_lognormal(pdists, N, j, kf, q, xg, wg, T);
+        if (j < N - 1 && dj->n > 0.0) {
+            double T[3] = {0.0, 0.0, 0.0};
+            if (dj->type == CO_LOGNORMAL) {
+                const double totals[3] = {0.5 * s0, co_conv_pair(kf, dj, dj, 1, 0, NULL, NULL),
+                                          co_conv_pair(kf, dj, dj, 2, 0, NULL, NULL) + sab};
+                co_conv_T_lognormal(pdists, N, j, kf, q, xg, wg, tol, totals, T);
+            } else {
+                /* homogeneous kernels: T_m = 1/2 s0 E_{Gamma(2k + gamma)}[s^m (1 - w)] (the kernel's homogeneity absorbed
+                 * in the weight); Long: T_m = 1/2 n^2 E_{Gamma(2k)}[s^m (1 - w) G(s)] */
+                const int lng = kf->kind == CO_KF_LONG;
+                const double A = 2.0 * kj + gam_of_kind[kf->kind], pref = lng ? 0.5 * dj->n * dj->n : 0.5 * s0;
+                co_T_ctx c = {pdists, N, j, kf, kj, A, co_lgam(A), dj->theta, log(dj->theta)};
+                double tlo, thi, marks[CO_CONV_MAX_MARKS], tolS[3];
+                int nm = 0;
+                co_conv_range_top(A, 2.0, &tlo, &thi);
+                for (int m = 0; m < N; ++m) /* the other modes' cores */
+                    if (m != j)
+                        nm = co_core_marks(co_ln_mean(&pdists[m]), co_core_width(&pdists[m]), (thi - tlo) / CO_CONV_NINIT, dj->theta, marks, nm);
+                if (lng) { /* kinks of G */
+                    marks[nm++] = co_conv_t_of_s(kf->p[0], dj->theta);
+                    marks[nm++] = co_conv_t_of_s(2.0 * kf->p[0], dj->theta);
+                }
+                if (lng) {
+                    const double totals[3] = {0.5 * s0, co_conv_pair(kf, dj, dj, 1, 0, NULL, NULL),
+                                              co_conv_pair(kf, dj, dj, 2, 0, NULL, NULL) + sab};
+                    for (int m = 0; m < 3; ++m) tolS[m] = totals[m] / pref;
+                } else {
+                    tolS[0] = 1.0;
+                    tolS[1] = A * dj->theta;
+                    tolS[2] = A * (A + 1.0) * dj->theta * dj->theta;
+                }
+                co_conv_adaptive(tlo, thi, marks, nm, 3, NULL, 0, tol, tolS, CO_CONV_BUDGET, co_T_node, &c, T);
+                if (!lng) { /* the mass below t_lo (1e-13 of the weight; a sizeable part of it for a shape clamped to eps) */
+                    const double u_lo = exp(tlo);
+                    T[0] += co_one_minus_w(pdists, N, j, u_lo * dj->theta, tlo + c.lth) * exp(A * tlo - co_lgam(A + 1.0));
+                }
+                for (int m = 0; m < 3; ++m) T[m] *= pref;
+            }
             for (int m = 0; m < 3; ++m) {
                 ADD(j, m, -T[m]);
                 ADD(j + 1, m, T[m]);
             }
-        } else if (j < N - 1 && dj->n > 0.0) {
-            co_T_ctx c = {pdists, N, j, kf, kj, {0.0, 0.0, 0.0}};
-            double pref;
-            if (kf->kind == CO_KF_LONG) {
-                const double brk[2] = {kf->p[0], 2.0 * kf->p[0]};
-                co_conv_rule(2.0 * kj, dj->theta, brk, 2, npan, q, xg, wg, co_T_node, &c);
-                pref = 0.5 * dj->n * dj->n;
-            } else { /* T_m = 1/2 s0 E_{Gamma(2k + gamma)}[s^m (1 - w)]: the kernel's homogeneity absorbed in the weight */
-                co_conv_rule(2.0 * kj + gam_of_kind[kf->kind], dj->theta, NULL, 0, npan, q, xg, wg, co_T_node, &c);
-                pref = 0.5 * s0;
-            }
-            for (int m = 0; m < 3; ++m) {
-                ADD(j, m, -pref * c.T[m]);
-                ADD(j + 1, m, pref * c.T[m]);
-            }
         }
         for (int k = j + 1; k < N; ++k) {
             const co_dist *dk = &pdists[k];
-            const double p0 = co_conv_pair(kf, dj, dk, 0, 0, &m0, npan, q, xg, wg), sa = co_conv_pair(kf, dj, dk, 1, 0, &m1, npan, q, xg, wg),
-                         saa = co_conv_pair(kf, dj, dk, 2, 0, &m2, npan, q, xg, wg), sab2 = co_conv_pair(kf, dj, dk, 1, 1, &m3, npan, q, xg, wg);
+            co_H_grid hg;
+            const int mixed = (dj->type == CO_LOGNORMAL) != (dk->type == CO_LOGNORMAL);
+            if (mixed && kf->kind == CO_KF_HYDRODYNAMIC)
+                co_conv_H_grid(dj->type == CO_LOGNORMAL ? dk : dj, dj->type == CO_LOGNORMAL ? dj : dk, tol, &hg);
+            const double p0 = co_conv_pair(kf, dj, dk, 0, 0, &m0, &hg), sa = co_conv_pair(kf, dj, dk, 1, 0, &m1, &hg),
+                         saa = co_conv_pair(kf, dj, dk, 2, 0, &m2, &hg), sab2 = co_conv_pair(kf, dj, dk, 1, 1, &m3, &hg);
             ADDM(j, 0, -p0, m0);
             ADDM(j, 1, -sa, m1);
             ADDM(j, 2, -saa, m2);
@@ -796,7 +957,7 @@ int co_get_coal_ints_numerical_converged(const co_dist *pdists, int N, const co_
 }
 
 /* rhs_coal!(NumericalCoalStyle(), ...) in converged mode, one parcel / a batch (as co_rhs_coal_numerical[_batch]) */
-int co_rhs_coal_numerical_converged(const co_params *p, const co_kernel_func *kf_normalized, int q, int npan,
+int co_rhs_coal_numerical_converged(const co_params *p, const co_kernel_func *kf_normalized, int q, double tol,
                                     const double *mom, double *dmom, double *scale) {
     double mom_norms[CO_MAX_MODES * 3], mn[CO_MAX_MODES * 3], ci[CO_MAX_MODES * 3];
     co_dist pdists[CO_MAX_MODES];
@@ -809,7 +970,7 @@ int co_rhs_coal_numerical_converged(const co_params *p, const co_kernel_func *kf
             return -1;
         off += p->NProgMoms[i];
     }
-    if (co_get_coal_ints_numerical_converged(pdists, p->N, kf_normalized, q, npan, ci, scale) < 0) return -1;
+    if (co_get_coal_ints_numerical_converged(pdists, p->N, kf_normalized, q, tol, ci, scale) < 0) return -1;
     for (int i = 0; i < nmom; ++i) {
         dmom[i] = ci[i] * mom_norms[i];
         if (scale) scale[i] *= mom_norms[i];
@@ -817,7 +978,7 @@ int co_rhs_coal_numerical_converged(const co_params *p, const co_kernel_func *kf
     return nmom;
 }
 
-int co_rhs_coal_numerical_converged_batch(const co_params *p, const co_kernel_func *kf_normalized, int q, int npan,
+int co_rhs_coal_numerical_converged_batch(const co_params *p, const co_kernel_func *kf_normalized, int q, double tol,
                                           long n_parcels, long ld, const double *mom, double *dmom, double *scale,
                                           int n_threads) {
     int nmom = 0;
@@ -830,7 +991,7 @@ int co_rhs_coal_numerical_converged_batch(const co_params *p, const co_kernel_fu
     for (long i = 0; i < n_parcels; ++i) {
         double m[CO_MAX_MODES * 3], d[CO_MAX_MODES * 3], s[CO_MAX_MODES * 3];
         for (int k = 0; k < nmom; ++k) m[k] = mom[(size_t)k * ld + i];
-        if (co_rhs_coal_numerical_converged(p, kf_normalized, q, npan, m, d, scale ? s : NULL) < 0) {
+        if (co_rhs_coal_numerical_converged(p, kf_normalized, q, tol, m, d, scale ? s : NULL) < 0) {
 #ifdef _OPENMP
 #pragma omp atomic write
 #endif

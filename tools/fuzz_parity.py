@@ -26,7 +26,7 @@ def random_config(rng, wild=False):
     else:
         thr = []
         for i in range(N):
-            finite = i < N - 1 and dist[i] != 3 and rng.random() < 0.6
+            finite = i < N - 1 and rng.random() < 0.6  # (any closure family, Lognormal included)
             thr.append(float(10.0 ** rng.uniform(-11.0, -6.5)) if finite else INF)
         thr = tuple(thr)
     kc = np.zeros((N, N, P, P))

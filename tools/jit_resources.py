@@ -34,9 +34,11 @@ def main():
     L = pkg.lib()
     for name in a.workloads:
         before = set(glob.glob(os.path.join(dump, "*.co")))
-        if name == "cfg4q":
-            d = pkg.NumericalPlan.make_desc([1, 1, 1], pkg.HydrodynamicKernelFunction(1e2 * np.pi), bench.NORMS, 10,
-                                            kernel_func_is_normalized=False)
+        if name in ("cfg4q", "cfg4q_converged"):
+            conv = name.endswith("converged")
+            d = pkg.NumericalPlan.make_desc([1, 1, 1], pkg.HydrodynamicKernelFunction(1e2 * np.pi), bench.NORMS,
+                                            8 if conv else 10, kernel_func_is_normalized=False,
+                                            **({"quad_mode": pkg.QUAD_CONVERGED} if conv else {}))
             keep = None
         else:
             spec = bench.workload_spec(name)
