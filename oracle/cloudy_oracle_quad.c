@@ -523,6 +523,10 @@ static const double CO_GK_WG[15] = {0.0, 0.129484966168869693270611432679082, 0.
                                     0.0, 0.381830050505118944950369775488975, 0.0, 0.279705391489276667901467771423780,
                                     0.0, 0.129484966168869693270611432679082, 0.0};
 static _Thread_local long co_conv_nodes_; /* integrand evaluations of the adaptive rules since the last reset */
+static _Thread_local long co_conv_rule_nodes_[CO_MAX_MODES]; /* ... of the T_m rule of each mode in the last call */
+void co_conv_rule_node_counts(long *out) {
+    for (int i = 0; i < CO_MAX_MODES; ++i) out[i] = co_conv_rule_nodes_[i];
+}
 long co_conv_node_count(int reset) {
     const long n = co_conv_nodes_;
     if (reset) co_conv_nodes_ = 0;
@@ -886,7 +890,9 @@ int co_get_coal_ints_numerical_converged(const co_dist *pdists, int N, const co_
         const double s0 = co_conv_pair(kf, dj, dj, 0, 0, &m0, NULL), sab = co_conv_pair(kf, dj, dj, 1, 1, &m1, NULL);
         ADDM(j, 0, -0.5 * s0, 0.5 * m0);
         ADDM(j, 2, sab, m1);
+        co_conv_rule_nodes_[j] = 0;
         if (j < N - 1 && dj->n > 0.0) {
+            const long nodes_before = co_conv_nodes_;
             double T[3] = {0.0, 0.0, 0.0};
             if (dj->type == CO_LOGNORMAL) {
                 const double totals[3] = {0.5 * s0, co_conv_pair(kf, dj, dj, 1, 0, NULL, NULL),
@@ -928,6 +934,7 @@ int co_get_coal_ints_numerical_converged(const co_dist *pdists, int N, const co_
                 ADD(j, m, -T[m]);
                 ADD(j + 1, m, T[m]);
             }
+            co_conv_rule_nodes_[j] = co_conv_nodes_ - nodes_before;
         }
         for (int k = j + 1; k < N; ++k) {
             const co_dist *dk = &pdists[k];
