@@ -270,11 +270,13 @@ struct ConvMarks {
         q[m] = -(I[m] + 1);
         v[m] = value(m);
     }
-    __device__ __forceinline__ double next(double lim) {  // the smallest mark > lim; +inf: none
+    // the smallest mark > lim; +inf: none.  Lanes with need = false run through it without changing anything (the caller
+    // keeps every lane on one path: conv_adaptive)
+    __device__ __forceinline__ double next(double lim, bool need) {
         double r = INFINITY;
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
-            while (v[m] <= lim) {
+            while (need && v[m] <= lim) {
                 ++q[m];
                 v[m] = value(m);
             }
@@ -298,32 +300,42 @@ __device__ __forceinline__ void conv_adaptive(double tlo, double thi, ConvMarks<
     double cur = tlo, a0 = tlo, h = 0.0;
     int io = 1, L = 0;
     unsigned i = 0;
-    bool fresh = true;
-#pragma unroll 1
-    for (;;) {
-        if (fresh) {  // the next initial panel
-            if (!(cur < thi)) break;
-            double own = fma(h0, double(io), tlo);
-            while (own <= cur + gap) {
-                ++io;
-                own = fma(h0, double(io), tlo);
-            }
-            double nxt = fmin(thi, own);
-            nxt = fmin(nxt, mk.next(cur + gap));
-            if (nxt > thi - gap) nxt = thi;
-            a0 = cur;
-            h = nxt - cur;
-            cur = nxt;
-            L = 0;
-            i = 0;
-            fresh = false;
+    bool busy = true;
+    // The next initial panel [cur, nxt) for the lanes with need = true (busy = false: their range is exhausted); the others
+    // run through the same instructions and keep their state -- no branch around it, see the end of the loop body.
+    const auto next_panel = [&](bool need) {
+        const bool go = need && cur < thi;
+        const double lim = cur + gap;
+        int io2 = io;
+        double own = fma(h0, double(io2), tlo);
+        while (need && own <= lim) {
+            ++io2;
+            own = fma(h0, double(io2), tlo);
         }
+        double nxt = fmin(thi, own);
+#ifndef CLOUDY_CONV_PROBE_NO_MARKS  // (timing experiments only)
+        nxt = fmin(nxt, mk.next(lim, need));
+#endif
+        nxt = nxt > thi - gap ? thi : nxt;
+        io = io2;
+        a0 = go ? cur : a0;
+        h = go ? nxt - cur : h;
+        cur = go ? nxt : cur;
+        L = go ? 0 : L;
+        i = go ? 0u : i;
+        busy = need ? go : busy;
+    };
+    next_panel(true);
+#pragma unroll 1
+    while (busy) {
         const double w = ldexp(h, -L), hw = 0.5 * w, c = fma(w, double(i), a0) + hw;
         double K[NEST], G[NEST];
 #pragma unroll
         for (int e = 0; e < NEST; ++e) K[e] = G[e] = 0.0;
         --budget;
-#pragma unroll 1
+        // (unrolled: the Kronrod nodes and weights become literals.  As a loop every node waited for three scalar loads of
+        // its constants: 7 % of the kernel's time at two waves per SIMD)
+#pragma unroll
         for (int g = 0; g < 15; ++g) {
             double ve[NEST];
             est(fma(hw, kGKX[g], c), ve);
@@ -347,7 +359,11 @@ __device__ __forceinline__ void conv_adaptive(double tlo, double thi, ConvMarks<
             // (a NaN estimate accepts: the NaN reaches the output)
             if (fabs(K[e] - G[e]) * hw > kConvTol * fmax(fabs(fma(K[e], hw, acc_o)), kConvFloor * sc_o)) ok = false;
         }
-        if (ok || L == kConvLMax || budget <= 0) {
+#ifdef CLOUDY_CONV_PROBE_ACCEPT_ALL
+        ok = true;
+#endif
+        const bool accept = ok || L == kConvLMax || budget <= 0;
+        if (accept) {
             if (TWO_PASS) {
                 double Kf[NOUT];
 #pragma unroll
@@ -370,16 +386,18 @@ __device__ __forceinline__ void conv_adaptive(double tlo, double thi, ConvMarks<
                         if (o == est_idx[e]) out[o] = fma(K[e], hw, out[o]);
                 }
             }
-            ++i;
-            while (L > 0 && !(i & 1u)) {
-                i >>= 1;
-                --L;
-            }
-            if (L == 0) fresh = true;
-        } else {
-            ++L;
-            i <<= 1;
         }
+        // The step of the tree walk as straight-line code: accepted -> the next sibling, climbing while it is a right
+        // child's successor (trailing zeros of the index); rejected -> the left child; then the next initial panel for the
+        // lanes that have finished theirs, as predicated code every lane runs through.  (Written with branches -- accept /
+        // reject / new panel each jumping back to the top -- the loop had three back edges, which the compiler turns into
+        // three NESTED loops: lanes that had accepted then waited for the lanes still bisecting, and a wave of 64 different
+        // parcels ran 1.75 x the trips of its busiest lane.)
+        const unsigned ni = accept ? i + 1u : i << 1;
+        const int up = accept ? min((int)__builtin_ctz(ni), L) : 0;
+        i = ni >> up;
+        L = accept ? L - up : L + 1;
+        next_panel(accept && L == 0);
     }
 }
 
@@ -696,6 +714,7 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
         }
     }
     // ---- phase 2: T_m, the self collisions weighting_fn hands to mode j + 1
+#ifndef CLOUDY_ABLATE_CONV_T  // (timing experiment only: the closed forms alone)
 #pragma unroll
     for (int j = 0; j < N - 1; ++j) {
         if (!(nj_[j] > 0.0)) continue;
@@ -787,6 +806,7 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
             acc[j + 1][2] += T2;
         }
     }
+#endif
 }
 
 }  // namespace cloudy
