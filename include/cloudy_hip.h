@@ -151,7 +151,7 @@ typedef struct cloudy_plan_desc {
      * non-smooth sets -- closed forms for Q and R, one ADAPTIVE Gauss-Kronrod (7, 15) rule per mode for the weighting_fn
      * split (relative tolerance 1e-9, as the reference's quadgk(rtol); quad_order is then only the points per panel of
      * the inner rule a Lognormal mode's self-collision integral needs, 8 suffice) -- within 1e-9 of scale of the
-     * adaptive result, at ~8 x the cost of the 10-point rule.  kernel_c, tensor_p,
+     * adaptive result, at ~5 x the cost of the 10-point rule.  kernel_c, tensor_p,
      * dist_thresholds and threshold_style are ignored (the style has no thresholds: weighting_fn splits the self
      * collisions, Coalescence.jl:624-642).  Monodisperse modes: CLOUDY_EINVAL (no normed_density_func method).
      * Shape parameters: the per-parcel Gauss-Laguerre rules are staged for 0 < k <= max(k_range[1], 1), the range
