@@ -397,7 +397,43 @@ def test_converged_mode_reaches_the_adaptive_golden_values_on_the_device(gpu_clo
             res[mode] = float(np.max(np.abs(ci - np.array(c["coal_ints"])) / scale))
         worst = max(worst, res[1])
         print(f"{c['name']:36s} converged {res[1]:.1e}   10-point rule {res[0]:.1e}   (of scale, vs adaptive)")
-    assert n_cases >= 24 and worst <= 1e-8, worst
+    assert n_cases >= 32 and worst <= 1e-8, worst
+
+
+def test_converged_mode_on_random_multi_scale_mixtures_on_the_device(gpu_cloudy, oracle):
+    """the mixtures a fixed composite rule got wrong (tests/test_numerical_oracle.py, same draw): random 2-3 mode Gamma /
+    Exponential mixtures with scales 3.5 decades and number densities 3 decades apart, shapes 1e-3 ... 10, the four kernel
+    functions, one batch per (N, kernel family) through cloudy_get_coal_ints.  Device against the same-rule oracle at the
+    same tolerance: <= 1e-11 of scale (the adaptive decisions may flip on a rounding difference; an accepted panel is good to
+    ~1e-14, so that is all a flip can move); device against the oracle at tolerance 1e-13: <= 1e-8."""
+    cloudy, O = gpu_cloudy, oracle
+    rng = np.random.default_rng(11)
+    mk = {0: cloudy.ConstantKernelFunction, 1: cloudy.LinearKernelFunction, 2: cloudy.HydrodynamicKernelFunction,
+          3: cloudy.LongKernelFunction}
+    worst_same, worst_ref, n_mix = 0.0, 0.0, 0
+    for N in (2, 3):
+        for kind in range(4):
+            prm = {0: (0.7,), 1: (5e-3,), 2: (0.3,), 3: (float(10 ** rng.uniform(-1, 1)), 9.0, 5.0)}[kind]
+            kf, okf = mk[kind](*prm), O.kernel_func(kind, *prm)
+            n = 48
+            planes = np.zeros((3 * N, n))
+            for p in range(n):
+                for i in range(N):
+                    k = float(rng.choice([rng.uniform(0.05, 1.0), rng.uniform(1, 10), rng.uniform(1, 10), 10 ** rng.uniform(-3, -1)]))
+                    planes[3 * i:3 * i + 3, p] = (10 ** rng.uniform(-1, 2), 10 ** rng.uniform(-2, 1.5), k)
+            got = cloudy.get_coal_ints(cloudy.NumericalCoalStyle(), ([1] * N, dev(cloudy, planes)), kf, quad_order=8,
+                                       quad_mode=cloudy.QUAD_CONVERGED).to_numpy()
+            for p in range(n):
+                pd = [O.make_dist(O.GAMMA, *planes[3 * i:3 * i + 3, p]) for i in range(N)]
+                same, sc = O.get_coal_ints_numerical_converged(pd, okf, 8, O.CONV_TOL, with_scale=True)
+                ref = O.get_coal_ints_numerical_converged(pd, okf, 8, 1e-13)
+                sc = np.maximum(sc, 1e-300)
+                worst_same = max(worst_same, float(np.max(np.abs(got[:, p] - same) / sc)))
+                worst_ref = max(worst_ref, float(np.max(np.abs(got[:, p] - ref) / sc)))
+                n_mix += 1
+    print(f"{n_mix} random multi-scale mixtures on the device: max |hip - oracle(same tolerance)| / scale = {worst_same:.1e}, "
+          f"max |hip - oracle(tol 1e-13)| / scale = {worst_ref:.1e}")
+    assert worst_same <= TOL_CONVERGED and worst_ref <= 1e-8
 
 
 def test_converged_mode_fused_ssprk33_and_full_size_properties(gpu_cloudy, oracle):
