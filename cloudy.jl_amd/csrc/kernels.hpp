@@ -1190,6 +1190,25 @@ __device__ __forceinline__ void rhs_physical(const KArgs<N, P> &A, const double 
     }
 }
 
+// The same for a state kept in NORMALISED units (all-Inf plans inside the fused SSPRK33 integrator): d(mom / norms)/dt is
+// coal_ints itself, so the six correctly rounded "./ norms" and the six ".* norms" of every evaluation
+// (box_model_helpers.jl:31, :52) are paid once per call, on load and store -- 30 of ~265 instructions per evaluation.  The
+// stage values then differ from the reference's physical-unit sequence by roundings (1e-16 relative per operation), far
+// inside the stepping tolerance; the single-launch operator keeps the reference's sequence.
+template <int N, int P, bool SPEC>
+__device__ __forceinline__ void rhs_normalised(const KArgs<N, P> &A, const double (&un)[N][3], double (&f)[N][3]) {
+    double nn[N], th[N], kk[N], acc[N][3];
+#pragma unroll
+    for (int m = 0; m < N; ++m) invert_closure(A.dist_type[m], un[m][0], un[m][1], un[m][2], A.kmin, A.kmax, nn[m], th[m], kk[m]);
+    coal_ints_parcel<N, P, MODE_ALLINF, false, SPEC>(A, nullptr, nn, th, kk, acc);
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        f[m][0] = acc[m][0];
+        f[m][1] = acc[m][1];
+        f[m][2] = (A.np[m] == 3) ? acc[m][2] : 0.0;
+    }
+}
+
 // BS: workgroup size (256; 512 for thresholded plans with N <= 2 and one thresholded mode, as coal_rhs_sorted_kernel)
 template <int N, int P, int MODE, typename TIO, bool SPEC = false, int BS = kBlock>
 __device__ __forceinline__ void ssprk33_body(const KArgs<N, P> *__restrict__ Ag, const double *__restrict__ nodes, size_t n,
@@ -1203,6 +1222,11 @@ __device__ __forceinline__ void ssprk33_body(const KArgs<N, P> *__restrict__ Ag,
     // a parcel stay for the barriers; the lane -> parcel map is the natural one (coalesced loads and stores).
     const bool valid = i < n;
     if (MODE == MODE_ALLINF && !valid) return;
+#ifdef CLOUDY_SSPRK33_PHYSICAL_STATE  // (A/B switch: the reference's sequence, normalising in every evaluation)
+    constexpr bool kNormalisedState = false;
+#else
+    constexpr bool kNormalisedState = MODE == MODE_ALLINF;  // see rhs_normalised
+#endif
     double u[N][3], up[N][3], f[N][3];
 #pragma unroll
     for (int m = 0; m < N; ++m) {
@@ -1210,6 +1234,10 @@ __device__ __forceinline__ void ssprk33_body(const KArgs<N, P> *__restrict__ Ag,
         u[m][0] = valid ? (double)u_in[(size_t)(off + 0) * ld + i] : 0.0;
         u[m][1] = valid ? (double)u_in[(size_t)(off + 1) * ld + i] : 0.0;
         u[m][2] = (valid && A.np[m] == 3) ? (double)u_in[(size_t)(off + 2) * ld + i] : 0.0;
+        if (kNormalisedState) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) u[m][q] = div_by_const(u[m][q], A.norm[3 * m + q], A.inv_norm[3 * m + q]);
+        }
     }
 #pragma unroll 1
     for (int step = 0; step < n_steps; ++step) {
@@ -1222,7 +1250,10 @@ __device__ __forceinline__ void ssprk33_body(const KArgs<N, P> *__restrict__ Ag,
             size_t opaque_zero = 0;  // launder an OFFSET, not the pointer: the pointer keeps its global address space
             if (!SPEC) asm volatile("" : "+s"(opaque_zero));  // (compile-time plan constants need no loads at all)
             const KArgs<N, P> *Ap = Ag + opaque_zero;
-            rhs_physical<N, P, MODE, SPEC, BS>(*Ap, nodes, valid, u, f);
+            if (kNormalisedState)
+                rhs_normalised<N, P, SPEC>(*Ap, u, f);
+            else
+                rhs_physical<N, P, MODE, SPEC, BS>(*Ap, nodes, valid, u, f);
             // OrdinaryDiffEq SSPRK33: u = uprev + dt k;  u = (3 uprev + u + dt k)/4;  u = (uprev + 2u + 2dt k)/3
             // (wave-uniform branch on the stage OUTSIDE the element loops: selects per element would triple the work)
             if (stage == 0) {
@@ -1249,6 +1280,10 @@ __device__ __forceinline__ void ssprk33_body(const KArgs<N, P> *__restrict__ Ag,
 #pragma unroll
     for (int m = 0; m < N; ++m) {
         const int off = A.off[m];
+        if (kNormalisedState) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) u[m][q] *= A.norm[3 * m + q];
+        }
         u_out[(size_t)(off + 0) * ld + i] = (TIO)u[m][0];
         u_out[(size_t)(off + 1) * ld + i] = (TIO)u[m][1];
         if (A.np[m] == 3) u_out[(size_t)(off + 2) * ld + i] = (TIO)u[m][2];
