@@ -214,7 +214,9 @@ int cloudy_coal_rhs_host(const cloudy_plan *plan, size_t n_parcels, size_t ld, c
  * (solve(prob, SSPRK33(), dt = ...), test/examples/Analytical/box_single_gamma.jl:35-36), fused around the RHS:
  * each parcel's moments stay in registers over all stages and steps (one read + one write of the state per call,
  * no per-stage launches).  u_out_dev may equal u_in_dev.  NumericalCoalStyle plans are served as well (the Numerical
- * drivers integrate the same way, test/examples/Numerical/n_particles_gamma.jl:39-40). */
+ * drivers integrate the same way, test/examples/Numerical/n_particles_gamma.jl:39-40).  Plans without a finite threshold
+ * keep the state in normalised units (mom ./ norms) between load and store: the stage values differ from rhs!'s
+ * normalise-in-every-call sequence by roundings only. */
 int cloudy_ssprk33_steps(const cloudy_plan *plan, size_t n_parcels, size_t ld, const void *u_in_dev, void *u_out_dev,
                          double dt, int n_steps, void *stream);
 
