@@ -597,8 +597,7 @@ __device__ __forceinline__ double conv_long_G_mid(const QArgs &Q, double k, doub
 // -- weighting_fn stays outside the inner integral (a function of s alone) and the hydrodynamic kink sits on the boundary
 // t = 0.  Outer: the adaptive rule over ln s in [mu - 8.5 sigma, mu + 8.5 sigma + (gamma + 2) sigma^2 + ln 2] (budget
 // kConvBudgetLn), marks at the other modes' cores (and ln x_t, ln 2 x_t for Long); inner: kLnPanels2 panels of nq
-// Gauss-Legendre points over t in [0, max(ln s - mu, 0) + 12 sigma].  (The Long kernel's jumps x = x_t, y = x_t are curves in
-// (ln s, t): that combination converges algebraically.)  totals[m]: T_m with 1 - w = 1 (closed form), the estimate's scale.
+// Gauss-Legendre points over t in [0, max(ln s - mu, 0) + 12 sigma], split at the Long kernel's jump.  totals[m]: T_m with 1 - w = 1 (closed form), the estimate's scale.
 constexpr int kLnPanels2 = 12;
 template <int N, int KIND>
 __device__ __forceinline__ void conv_T_lognormal(const QArgs &Q, const double *__restrict__ tab, double n, double mu, double sg,
@@ -626,11 +625,26 @@ __device__ __forceinline__ void conv_T_lognormal(const QArgs &Q, const double *_
     }
     const auto node = [&](double ls, double (&vals)[3]) {
         const double s = exp_fin(ls);
-        const double Tm = fmax(ls - mu, 0.0) + 12.0 * sg, h2 = Tm * (1.0 / double(kLnPanels2));
+        const double Tm = fmax(ls - mu, 0.0) + 12.0 * sg;
+        // the Long kernel jumps where the larger particle x = s / (1 + e^-t) crosses x_t: at t_b = ln(x_t / (s - x_t)) for
+        // x_t < s < 2 x_t (below, both stay under x_t; above, x >= s / 2 >= x_t) -- the inner panels are split there
+        double tb = 0.0;
+        int n1 = 0;
+        if (KIND == KF_LONG && s > Q.kf[0] && s < 2.0 * Q.kf[0]) {
+            tb = log_pos(Q.kf[0] / (s - Q.kf[0]));
+            if (tb > 0.0 && tb < Tm) {
+                n1 = (int)(double(kLnPanels2) * (tb / Tm) + 0.5);
+                n1 = n1 < 1 ? 1 : n1 > kLnPanels2 - 1 ? kLnPanels2 - 1 : n1;
+            }
+        }
         double G2 = 0.0;
 #pragma unroll 1
         for (int i2 = 0; i2 < kLnPanels2; ++i2) {
-            const double tc = h2 * (double(i2) + 0.5);
+            // panel i2 of the first piece [0, t_b] (n1 panels) or of the second [t_b, Tm] (the rest); n1 = 0: one piece
+            const bool first = i2 < n1;
+            const double a = first ? 0.0 : (n1 ? tb : 0.0), b = first ? tb : Tm;
+            const double h2 = (b - a) / double(first ? n1 : kLnPanels2 - n1);
+            const double tc = fma(h2, double(first ? i2 : i2 - n1) + 0.5, a);
 #pragma unroll 1
             for (int g2 = 0; g2 < nq; ++g2) {
                 const double t = fma(0.5 * h2, tab[g2], tc);

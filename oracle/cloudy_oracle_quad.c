@@ -803,8 +803,7 @@ static void co_T_node(double t, double *vals, void *v) {
  * with weighting_fn outside the inner integral (it depends on s alone) and the kink of the hydrodynamic kernel on the
  * boundary t = 0.  Outer: the adaptive rule over ln s in [mu - 8.5 sigma, mu + 8.5 sigma + (gamma + 2) sigma^2 + ln 2]
  * (budget CO_CONV_BUDGET_LN), marks at the other modes' cores (and ln x_t, ln 2 x_t for Long); inner: CO_LN_PAN2
- * panels of q Gauss-Legendre points over t in [0, max(ln s - mu, 0) + 12 sigma].  (The Long kernel's jumps x = x_t,
- * y = x_t are curves in (ln s, t): that combination converges algebraically.) */
+ * panels of q Gauss-Legendre points over t in [0, max(ln s - mu, 0) + 12 sigma], split at the Long kernel's jump (co_TL_node). */
 #define CO_LN_PAN2 12
 typedef struct {
     const co_dist *pdists;
@@ -815,16 +814,33 @@ typedef struct {
 static void co_TL_node(double ls, double *vals, void *v) {
     const co_TL_ctx *c = (const co_TL_ctx *)v;
     const double mu = c->pdists[c->j].theta, sg = c->pdists[c->j].k, c2 = 1.0 / (2.0 * sg * sg), nrm = c2 / M_PI;
-    const double s = exp(ls), Tm = fmax(ls - mu, 0.0) + 12.0 * sg, h2 = Tm / CO_LN_PAN2;
-    double G2 = 0.0;
-    for (int i2 = 0; i2 < CO_LN_PAN2; ++i2)
-        for (int g2 = 0; g2 < c->q; ++g2) {
-            const double t = h2 * (i2 + 0.5) + 0.5 * h2 * c->xg[g2];
-            const double spm = log1p(exp(-t)); /* softplus(-t); softplus(t) = t + softplus(-t) */
-            const double lx = ls - spm, ly = ls - t - spm;
-            const double dx = lx - mu, dy = ly - mu;
-            G2 += (0.5 * h2 * c->wg[g2]) * co_kernel_func_eval(c->kf, exp(lx), exp(ly)) * exp(-(dx * dx + dy * dy) * c2);
+    const double s = exp(ls), Tm = fmax(ls - mu, 0.0) + 12.0 * sg;
+    /* the Long kernel jumps where the larger particle x = s / (1 + e^-t) crosses x_t: at t_b = ln(x_t / (s - x_t)) for
+     * x_t < s < 2 x_t (below, both stay under x_t; above, x >= s / 2 >= x_t) -- the inner panels are split there */
+    double tb = 0.0;
+    int n1 = 0;
+    if (c->kf->kind == CO_KF_LONG && s > c->kf->p[0] && s < 2.0 * c->kf->p[0]) {
+        tb = log(c->kf->p[0] / (s - c->kf->p[0]));
+        if (tb > 0.0 && tb < Tm) {
+            n1 = (int)(CO_LN_PAN2 * (tb / Tm) + 0.5);
+            n1 = n1 < 1 ? 1 : n1 > CO_LN_PAN2 - 1 ? CO_LN_PAN2 - 1 : n1;
         }
+    }
+    double G2 = 0.0;
+    for (int seg = 0; seg < 2; ++seg) {
+        const int np = seg == 0 ? n1 : CO_LN_PAN2 - n1;
+        const double a = seg == 0 ? 0.0 : (n1 ? tb : 0.0), b = seg == 0 ? tb : Tm;
+        if (np == 0) continue;
+        const double h2 = (b - a) / np;
+        for (int i2 = 0; i2 < np; ++i2)
+            for (int g2 = 0; g2 < c->q; ++g2) {
+                const double t = a + h2 * (i2 + 0.5) + 0.5 * h2 * c->xg[g2];
+                const double spm = log1p(exp(-t)); /* softplus(-t); softplus(t) = t + softplus(-t) */
+                const double lx = ls - spm, ly = ls - t - spm;
+                const double dx = lx - mu, dy = ly - mu;
+                G2 += (0.5 * h2 * c->wg[g2]) * co_kernel_func_eval(c->kf, exp(lx), exp(ly)) * exp(-(dx * dx + dy * dy) * c2);
+            }
+    }
     const double val = co_one_minus_w(c->pdists, c->N, c->j, s, ls) * (2.0 * nrm * G2);
     vals[0] = val;
     vals[1] = val * s;

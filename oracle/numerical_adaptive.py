@@ -70,6 +70,8 @@ CASES = [
     dict(name="3gamma_hydro_scales_apart", kf=(2, [0.3]), pdists=[(1, 29.7, 9.82, 0.80), (1, 0.291, 0.01738, 9.92), (1, 0.9275, 0.01466, 0.985)]),
     dict(name="3gamma_long_scales_apart", kf=(3, [0.3, 9.0, 5.0]), pdists=[(1, 21.26, 0.3454, 4.334), (1, 5.59, 24.65, 0.75), (1, 0.1831, 0.2123, 1.5)]),
     dict(name="2gamma_hydro_small_neighbour", kf=(2, [0.3]), pdists=[(1, 5.0, 2.0, 0.75), (1, 1.0, 0.03, 4.0)]),
+    # a Lognormal mode that is NOT the last one under the Long kernel: its T_m is the 2-D rule with the kernel's jump inside
+    dict(name="lognormal_gamma_long", kf=(3, LONG), pdists=[(3, 80.0, -1.5, 0.7), (1, 2.0, 2.0, 3.0)]),
     dict(name="gamma_narrow_lognormal_constant", kf=(0, [0.7]), pdists=[(1, 2.02, 0.17, 1.5), (3, 79.6, -1.888, 0.15)]),
 ]
 

@@ -9,7 +9,7 @@ What pins the oracle here:
   * exactness for polynomial kernels: for one mode the Numerical and Analytical closures coincide, so the fixed rule
     must reproduce co_get_coal_ints (all thresholds Inf) to rounding; for several modes the sums over modes must;
   * the adaptive-quadrature restatement of the reference integrals (oracle/cloudy_oracle_adaptive.c, driven by
-    oracle/numerical_adaptive.py -> tests/golden/numerical_adaptive.json, 34 cases at 1e-10, two of them cross-checked with
+    oracle/numerical_adaptive.py -> tests/golden/numerical_adaptive.json, 35 cases at 1e-10, two of them cross-checked with
     mpmath): the discretisation error of the FIXED rule is reported and bounded per kernel family, and the CONVERGED mode
     (csrc/quad_conv.hpp, restated in cloudy_oracle_quad.c) must reach the adaptive values to <= 1e-8 of scale.
 """
