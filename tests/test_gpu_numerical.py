@@ -434,6 +434,34 @@ def test_converged_mode_on_random_multi_scale_mixtures_on_the_device(gpu_cloudy,
     print(f"{n_mix} random multi-scale mixtures on the device: max |hip - oracle(same tolerance)| / scale = {worst_same:.1e}, "
           f"max |hip - oracle(tol 1e-13)| / scale = {worst_ref:.1e}")
     assert worst_same <= TOL_CONVERGED and worst_ref <= 1e-8
+    # the same with Lognormal modes in either position (2-D rule of a Lognormal T_m, the Gamma-Lognormal P(Y' < X') grid)
+    worst_same, worst_ref, n_mix = 0.0, 0.0, 0
+    for types in ([3, 1], [1, 3], [3, 3], [1, 3, 1]):
+        for kind in range(4):
+            prm = {0: (0.7,), 1: (5e-3,), 2: (0.3,), 3: (float(10 ** rng.uniform(-1, 1)), 9.0, 5.0)}[kind]
+            kf, okf = mk[kind](*prm), O.kernel_func(kind, *prm)
+            n, N = 12, len(types)
+            planes = np.zeros((3 * N, n))
+            for p in range(n):
+                for i, t in enumerate(types):
+                    if t == 3:
+                        planes[3 * i:3 * i + 3, p] = (10 ** rng.uniform(-1, 2), rng.uniform(-3, 2),
+                                                      rng.choice([rng.uniform(0.2, 1.0), rng.uniform(0.03, 0.2)]))
+                    else:
+                        planes[3 * i:3 * i + 3, p] = (10 ** rng.uniform(-1, 2), 10 ** rng.uniform(-2, 1.5), rng.uniform(0.3, 10.0))
+            got = cloudy.get_coal_ints(cloudy.NumericalCoalStyle(), (types, dev(cloudy, planes)), kf, quad_order=8,
+                                       quad_mode=cloudy.QUAD_CONVERGED).to_numpy()
+            for p in range(n):
+                pd = [O.make_dist(O.LOGNORMAL if t == 3 else O.GAMMA, *planes[3 * i:3 * i + 3, p]) for i, t in enumerate(types)]
+                same, sc = O.get_coal_ints_numerical_converged(pd, okf, 8, O.CONV_TOL, with_scale=True)
+                ref = O.get_coal_ints_numerical_converged(pd, okf, 8, 1e-13)
+                sc = np.maximum(sc, 1e-300)
+                worst_same = max(worst_same, float(np.max(np.abs(got[:, p] - same) / sc)))
+                worst_ref = max(worst_ref, float(np.max(np.abs(got[:, p] - ref) / sc)))
+                n_mix += 1
+    print(f"{n_mix} random mixtures with Lognormal modes on the device: max |hip - oracle(same tolerance)| / scale = "
+          f"{worst_same:.1e}, max |hip - oracle(tol 1e-13)| / scale = {worst_ref:.1e}")
+    assert worst_same <= TOL_CONVERGED and worst_ref <= 1e-8
 
 
 def test_converged_mode_fused_ssprk33_and_full_size_properties(gpu_cloudy, oracle):
