@@ -117,6 +117,9 @@ end
 
 Plan of `make_box_model_rhs(NumericalCoalStyle())`: `kernel_func_normalized` is what the drivers put in
 `p.kernel_func` (`get_normalized_kernel_func(kernel, norms)`, test/examples/Numerical/n_particles_gamma.jl:35).
+`quad_mode = 0`: one fixed `quad_order`-point Gauss rule per distribution; `quad_mode = 1` (converged): closed forms plus an
+adaptive Gauss-Kronrod rule per mode, within 1e-9 of scale of the reference's nested `quadgk` (`quad_order` is then only the
+points per panel of the inner rule a Lognormal mode needs; 8 suffice).
 """
 function numerical_plan(pdists, kernel_func_normalized, norms; quad_order = 10, quad_mode = 0)
     d = new_desc()
