@@ -490,6 +490,12 @@ def test_converged_mode_fused_ssprk33_and_full_size_properties(gpu_cloudy, oracl
     mass, mag = d[1] + d[4] + d[7], np.abs(d[1]) + np.abs(d[4]) + np.abs(d[7])
     assert np.max(np.abs(mass) / np.maximum(mag, 1e-300)) < 1e-9
     assert np.all(d[0] + d[3] + d[6] <= 0.0) and np.all(d[0] <= 0.0) and np.all(d[8] >= 0.0)
+    # a slice of the batch evaluated alone equals the same parcels inside the full batch, bit for bit: every lane walks its
+    # own panels (no wave-level decisions), so sharding a batch over GPUs cannot change a result
+    sl = slice(7_000_003, 7_050_003)
+    ms, dms = dev(cloudy, np.ascontiguousarray(mom[:, sl])), cloudy.DeviceArray.zeros(9, 50_000)
+    rhs(dms, ms, par, 0.0)
+    assert np.array_equal(dms.to_numpy(), d[:, sl])
     rhs(dm, dev(cloudy, 2.0 * mom), par, 0.0)
     d2 = dm.to_numpy()
     assert np.max(np.abs(d2 - 4.0 * d) / np.maximum(np.abs(4.0 * d), 1e-300)) < 1e-12
