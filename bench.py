@@ -512,14 +512,14 @@ def cfg4q_par(pkg, quad_order=10):
     evaluated by a 10-point Gauss rule per distribution (NumericalCoalStyle plan), 9 moments."""
     kf = pkg.get_normalized_kernel_func(pkg.HydrodynamicKernelFunction(1e2 * np.pi), NORMS)
     pd = tuple(pkg.GammaPrimitiveParticleDistribution(1.0, 1.0, 1.0) for _ in range(3))
-    return pkg.ODEParameters(pd, None, (3, 3, 3), NORMS, kernel_func=kf, quad_order=quad_order)
+    return pkg.ODEParameters(pd, None, (3, 3, 3), NORMS, kernel_func=kf, quad_order=quad_order, quad_mode=pkg.QUAD_FIXED)
 
 
 def _cfg4q_variant(pkg, rank, world, measured, n=CFG4Q_PARCELS, reps=3):
     import ctypes as C
 
     par = cfg4q_par(pkg)
-    plan = pkg.numerical_plan([1, 1, 1], par.kernel_func, NORMS, 10)
+    plan = pkg.numerical_plan([1, 1, 1], par.kernel_func, NORMS, 10, quad_mode=pkg.QUAD_FIXED)
     mom = synth_moments(3, n, SEED + 1000 * rank)
     m, dm = pkg.DeviceArray.from_numpy(mom), pkg.DeviceArray.zeros(9, n)
     L = pkg.lib()

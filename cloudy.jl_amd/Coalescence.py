@@ -114,13 +114,16 @@ def kernel_func_code(kf):
 
 class NumericalPlan(Plan):
     """Plan of a NumericalCoalStyle operator: get_coal_ints(::NumericalCoalStyle, pdists, kernel_func)
-    (Coalescence.jl:470-489) with a fixed `quad_order`-point Gauss rule per distribution (csrc/quad.hpp).
+    (Coalescence.jl:470-489).  quad_mode = QUAD_CONVERGED (the default): closed forms + one adaptive Gauss-Kronrod rule
+    per mode (csrc/quad_conv.hpp), within 1e-8 of the reference's nested quadgk(rtol = 1e-8); QUAD_FIXED: one
+    `quad_order`-point Gauss rule per distribution (csrc/quad.hpp; BASELINE configs[3] "10-pt Gauss quadrature").
+    quad_order = 0: the mode's default (8 / 10).
     `kernel_func` is the normalised kernel function the reference passes in p.kernel_func
     (get_normalized_kernel_func(kernel, norms), Numerical/n_particles_gamma.jl:35)."""
 
     @staticmethod
-    def make_desc(dist_types, kernel_func, norms, quad_order=10, k_range=(EPS, 10.0), device=-1, dtype=0, specialize=0,
-                  kernel_func_is_normalized=True, quad_mode=0):
+    def make_desc(dist_types, kernel_func, norms, quad_order=0, k_range=(EPS, 10.0), device=-1, dtype=0, specialize=0,
+                  kernel_func_is_normalized=True, quad_mode=1):
         L = _lib.lib()
         d = _lib.PlanDesc()
         L.cloudy_plan_desc_init(C.byref(d))
@@ -142,8 +145,8 @@ class NumericalPlan(Plan):
         d.quad_mode = int(quad_mode)
         return d
 
-    def __init__(self, dist_types, kernel_func, norms, quad_order=10, k_range=(EPS, 10.0), device=-1, dtype=0,
-                 specialize=0, kernel_func_is_normalized=True, quad_mode=0):
+    def __init__(self, dist_types, kernel_func, norms, quad_order=0, k_range=(EPS, 10.0), device=-1, dtype=0,
+                 specialize=0, kernel_func_is_normalized=True, quad_mode=1):
         L = _lib.lib()
         d = NumericalPlan.make_desc(dist_types, kernel_func, norms, quad_order, k_range, device, dtype, specialize,
                                     kernel_func_is_normalized, quad_mode)
@@ -154,8 +157,8 @@ class NumericalPlan(Plan):
         self.dtype = int(dtype)
         self.N = self.n_modes = N
         self.P = self.tensor_p = 1
-        self.quad_order = int(quad_order)
         self.quad_mode = int(quad_mode)
+        self.quad_order = int(quad_order) or (8 if self.quad_mode == 1 else 10)
         self.all_inf = True
         self.numerical = True
         self.nmom = L.cloudy_plan_nmom(h)
@@ -168,11 +171,13 @@ _numerical_plans = {}
 QUAD_FIXED, QUAD_CONVERGED = 0, 1   # cloudy_plan_desc.quad_mode
 
 
-def numerical_plan(dist_types, kernel_func, norms, quad_order=10, k_range=(EPS, 10.0), dtype=0, specialize=0, quad_mode=0):
-    """Cached NumericalPlan (one per distinct configuration).  quad_mode: QUAD_FIXED = one quad_order-point Gauss rule
-    per distribution; QUAD_CONVERGED = the integrals split along the kernel function's non-smooth sets (closed forms +
-    one adaptive Gauss-Kronrod rule per mode, csrc/quad_conv.hpp; quad_order = points per panel of the inner rule of a
-    Lognormal mode)."""
+def numerical_plan(dist_types, kernel_func, norms, quad_order=0, k_range=(EPS, 10.0), dtype=0, specialize=0,
+                   quad_mode=QUAD_CONVERGED):
+    """Cached NumericalPlan (one per distinct configuration).  quad_mode: QUAD_CONVERGED (default) = the integrals split
+    along the kernel function's non-smooth sets (closed forms + one adaptive Gauss-Kronrod rule per mode,
+    csrc/quad_conv.hpp; quad_order = points per panel of the inner rule of a Lognormal mode, default 8) -- the mode that
+    meets the reference's quadgk(rtol = 1e-8) answer; QUAD_FIXED = one quad_order-point Gauss rule per distribution
+    (default 10), the explicit opt-in BASELINE configs[3] words."""
     key = (tuple(int(t) for t in dist_types), kernel_func, tuple(norms), int(quad_order), tuple(k_range), int(dtype),
            int(specialize), int(quad_mode))
     if key not in _numerical_plans:
@@ -237,11 +242,11 @@ class CoalescenceData:
         return self._plans[key]
 
 
-def get_coal_ints(cs, pdists, coal_data, ts=None, out=None, stream=None, k_range=(EPS, 10.0), quad_order=10,
-                  quad_mode=0):
+def get_coal_ints(cs, pdists, coal_data, ts=None, out=None, stream=None, k_range=(EPS, 10.0), quad_order=0,
+                  quad_mode=QUAD_CONVERGED):
     """get_coal_ints(::AnalyticalCoalStyle, pdists, coal_data[, ::MovingThreshold])  (Coalescence.jl:115-185) and
     get_coal_ints(::NumericalCoalStyle, pdists, kernel_func) (:470-489; third argument = the normalised kernel
-    function, integrals by the fixed `quad_order`-point rule), batched: `pdists` = (dist_types, params) with params a
+    function; quad_mode / quad_order as numerical_plan), batched: `pdists` = (dist_types, params) with params a
     (3N, n) device array of (n, theta, k) in normalised units.  Returns the (nmom, n) device array of normalised
     tendencies."""
     dist_types, params = pdists

@@ -31,8 +31,8 @@ def _numerical_plan_for(par, dtype=0):
     if tuple(nparams(d) for d in par.pdists) != tuple(par.NProgMoms):
         raise ValueError("NProgMoms must equal nparams of p.pdists")
     return numerical_plan([d.type_id for d in par.pdists], par.kernel_func, par.norms,
-                          quad_order=getattr(par, "quad_order", 10), k_range=getattr(par, "k_range", (EPS, 10.0)),
-                          dtype=dtype, quad_mode=getattr(par, "quad_mode", 0))
+                          quad_order=getattr(par, "quad_order", 0), k_range=getattr(par, "k_range", (EPS, 10.0)),
+                          dtype=dtype, quad_mode=getattr(par, "quad_mode", 1))  # default: converged mode
 
 
 def _plan_for(par, dtype=0):

@@ -229,7 +229,8 @@ void cloudy_plan_desc_init(cloudy_plan_desc *d) {
     d->dtype = CLOUDY_F64;
     d->device = -1;
     d->coal_style = CLOUDY_ANALYTICAL_COAL;
-    d->quad_order = 10;
+    d->quad_order = 0;                     // the mode's default: 8 (CONVERGED) / 10 (FIXED)
+    d->quad_mode = CLOUDY_QUAD_CONVERGED;  // the drop-in default meets the reference's quadgk(rtol = 1e-8) answer
 }
 
 }  // extern "C"
@@ -256,8 +257,8 @@ int build_host_plan(const cloudy_plan_desc *d, cloudy_plan **out, std::vector<do
             return fail(CLOUDY_EINVAL, "kernel_func %d is not a CoalescenceKernelFunction family", d->kernel_func);
         if (d->quad_mode != CLOUDY_QUAD_FIXED && d->quad_mode != CLOUDY_QUAD_CONVERGED)
             return fail(CLOUDY_EINVAL, "quad_mode %d is neither CLOUDY_QUAD_FIXED nor CLOUDY_QUAD_CONVERGED", d->quad_mode);
-        if (d->quad_order < 2 || d->quad_order > CLOUDY_MAX_QUAD)
-            return fail(CLOUDY_EUNSUPPORTED, "quad_order %d outside 2..%d", d->quad_order, CLOUDY_MAX_QUAD);
+        if (d->quad_order != 0 && (d->quad_order < 2 || d->quad_order > CLOUDY_MAX_QUAD))
+            return fail(CLOUDY_EUNSUPPORTED, "quad_order %d outside 2..%d (0 = the mode's default)", d->quad_order, CLOUDY_MAX_QUAD);
         if (d->dtype == CLOUDY_F32_FAST)
             return fail(CLOUDY_EUNSUPPORTED, "CLOUDY_F32_FAST is the single-precision Simpson pass of threshold plans");
         for (int i = 0; i < N; ++i)
@@ -329,19 +330,20 @@ int build_host_plan(const cloudy_plan_desc *d, cloudy_plan **out, std::vector<do
                 delete p;
                 return fail(CLOUDY_EINVAL, "kernel_func_params[%d] is NaN", k);
             }
+        const int quad_order = d->quad_order ? d->quad_order : (d->quad_mode == CLOUDY_QUAD_CONVERGED ? 8 : 10);
         if (d->quad_mode == CLOUDY_QUAD_CONVERGED) {
             // quad_conv.hpp: quad_order Gauss-Legendre points per panel of the inner rule of a Lognormal mode's T_m (the
             // adaptive rules carry their own Gauss-Kronrod nodes)
             h.q.mode = QUAD_CONVERGED;
-            h.q.nq = d->quad_order;
+            h.q.nq = quad_order;
             h.q.deg = 0;
             h.q.t_scale = 0.0;
-            h.qtab.assign((size_t)2 * d->quad_order, 0.0);
-            quad_host::legendre_rule(d->quad_order, h.qtab.data(), h.qtab.data() + d->quad_order);
+            h.qtab.assign((size_t)2 * quad_order, 0.0);
+            quad_host::legendre_rule(quad_order, h.qtab.data(), h.qtab.data() + quad_order);
         } else {
             // start-value table of the per-parcel Gauss-Laguerre rules over k in (0, max(k_range[1], 1)] (Exponential: k = 1)
             std::string msg;
-            if (!quad_host::build_table(d->quad_order, std::fmax(d->k_range[1], 1.0), h.q, h.qtab, msg)) {
+            if (!quad_host::build_table(quad_order, std::fmax(d->k_range[1], 1.0), h.q, h.qtab, msg)) {
                 delete p;
                 return fail(CLOUDY_EUNSUPPORTED, "%s", msg.c_str());
             }

@@ -199,8 +199,8 @@ __device__ __forceinline__ double conv_one_minus_w(const ConvLogDensity (&lg)[N]
 // between two implementations moves the result by that much, not by tol.
 // Lanes walk their own panel trees in ONE flat loop (a new initial panel is just another state of it): a wave runs for as
 // long as its lane with the most panel evaluations.
-constexpr int kConvNInit = 16, kConvLMax = 12, kConvIMax = 12, kConvBudget = 8192, kConvBudgetLn = 1024;
-constexpr double kConvTol = 1e-9, kConvFloor = 1e-10;
+constexpr int kConvNInit = 12, kConvLMax = 12, kConvIMax = 12, kConvBudget = 8192, kConvBudgetLn = 1024;
+constexpr double kConvTol = 1e-8, kConvFloor = 1e-10;
 __device__ static const double kGKX[15] = {-0.991455371120812639206854697526329, -0.949107912342758524526189684047851,
                                            -0.864864423359769072789712788640926, -0.741531185599394439863864773280788,
                                            -0.586087235467691130294144838258730, -0.405845151377397166906606412076961,

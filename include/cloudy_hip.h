@@ -143,15 +143,17 @@ typedef struct cloudy_plan_desc {
                                                 (plan creation fails otherwise), -1 = off */
     /* ---- NumericalCoalStyle plans (make_box_model_rhs(NumericalCoalStyle()), Coalescence.jl:470-708) ----
      * coal_style = CLOUDY_NUMERICAL_COAL: the integrals of the kernel FUNCTION p.kernel_func over the densities, where
-     * the reference nests adaptive quadgk(rtol = 1e-8).  quad_mode = CLOUDY_QUAD_FIXED: each by one fixed quad_order-point
-     * Gauss rule per distribution (generalised Gauss-Laguerre for Gamma / Exponential modes, Gauss-Hermite in ln x for
-     * Lognormal modes; tensor product over a pair of modes after the substitution x' = x - y) -- exact for the constant
-     * and linear kernels up to the weighting_fn split, a discretisation for the hydrodynamic and Long kernels (1e-4 ...
-     * 4e-2 of scale at 10 points).  quad_mode = CLOUDY_QUAD_CONVERGED: the integrals split along the kernel function's
-     * non-smooth sets -- closed forms for Q and R, one ADAPTIVE Gauss-Kronrod (7, 15) rule per mode for the weighting_fn
-     * split (relative tolerance 1e-9, as the reference's quadgk(rtol); quad_order is then only the points per panel of
-     * the inner rule a Lognormal mode's self-collision integral needs, 8 suffice) -- within 1e-9 of scale of the
-     * adaptive result, at ~5 x the cost of the 10-point rule.  kernel_c, tensor_p,
+     * the reference nests adaptive quadgk(rtol = 1e-8).  quad_mode = CLOUDY_QUAD_CONVERGED (THE DEFAULT: the drop-in
+     * answers within north_star's 1e-8 of the reference): the integrals split along the kernel function's non-smooth
+     * sets -- closed forms for Q and R, one ADAPTIVE Gauss-Kronrod (7, 15) rule per mode for the weighting_fn split
+     * (relative tolerance 1e-8, the reference's own quadgk(rtol); quad_order is then only the points per panel of the
+     * inner rule a Lognormal mode's self-collision integral needs, default 8) -- within 1e-9 of scale of the adaptive
+     * result.  quad_mode = CLOUDY_QUAD_FIXED (explicit opt-in; BASELINE configs[3] "via 10-pt Gauss
+     * quadrature"): each integral by one fixed quad_order-point Gauss rule per distribution (generalised Gauss-Laguerre
+     * for Gamma / Exponential modes, Gauss-Hermite in ln x for Lognormal modes; tensor product over a pair of modes after
+     * the substitution x' = x - y; default 10 points) -- exact for the constant and linear kernels up to the weighting_fn
+     * split, a discretisation for the hydrodynamic and Long kernels (1e-4 ... 4e-2 of scale at 10 points), several
+     * times faster.  kernel_c, tensor_p,
      * dist_thresholds and threshold_style are ignored (the style has no thresholds: weighting_fn splits the self
      * collisions, Coalescence.jl:624-642).  Monodisperse modes: CLOUDY_EINVAL (no normed_density_func method).
      * Shape parameters: the per-parcel Gauss-Laguerre rules are staged for 0 < k <= max(k_range[1], 1), the range
@@ -161,17 +163,17 @@ typedef struct cloudy_plan_desc {
     int32_t kernel_func;                     /* CLOUDY_KFUNC_* */
     int32_t kernel_func_is_normalized;       /* 0: library applies get_normalized_kernel_func(kernel, norms), :124-154 */
     int32_t quad_order;                      /* FIXED: points per distribution; CONVERGED: Gauss-Legendre points per
-                                                panel; 2..CLOUDY_MAX_QUAD; default 10 */
+                                                panel; 2..CLOUDY_MAX_QUAD; 0 (default) = 10 (FIXED) / 8 (CONVERGED) */
     double kernel_func_params[3];            /* physical units unless kernel_func_is_normalized */
     int32_t thresholds_are_normalized;       /* FixedThreshold only: 1 = dist_thresholds are already divided by norms[1],
                                                 i.e. the CoalescenceData.dist_thresholds FIELD (Coalescence.jl:78-84) rather
                                                 than the constructor argument -- a host that builds the plan from an
                                                 existing CoalescenceData passes its fields through unchanged */
-    int32_t quad_mode;                       /* NumericalCoalStyle: CLOUDY_QUAD_FIXED (default) / CLOUDY_QUAD_CONVERGED */
+    int32_t quad_mode;                       /* NumericalCoalStyle: CLOUDY_QUAD_CONVERGED (default) / CLOUDY_QUAD_FIXED */
 } cloudy_plan_desc;
 
 /* fills defaults: k_range = (eps, 10), n_bins_per_log_unit = 15, norms = (1, 1), thresholds = +Inf,
- * dtype = F64, device = -1, coal_style = ANALYTICAL, quad_order = 10 */
+ * dtype = F64, device = -1, coal_style = ANALYTICAL, quad_mode = CONVERGED, quad_order = 0 (the mode's default) */
 void cloudy_plan_desc_init(cloudy_plan_desc *desc);
 
 int cloudy_plan_create(const cloudy_plan_desc *desc, cloudy_plan **out);

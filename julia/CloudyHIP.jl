@@ -113,15 +113,16 @@ function create(d::Ref{PlanDesc})
 end
 
 """
-    numerical_plan(pdists, kernel_func_normalized, norms; quad_order = 10, quad_mode = 0)
+    numerical_plan(pdists, kernel_func_normalized, norms; quad_order = 0, quad_mode = 1)
 
 Plan of `make_box_model_rhs(NumericalCoalStyle())`: `kernel_func_normalized` is what the drivers put in
 `p.kernel_func` (`get_normalized_kernel_func(kernel, norms)`, test/examples/Numerical/n_particles_gamma.jl:35).
-`quad_mode = 0`: one fixed `quad_order`-point Gauss rule per distribution; `quad_mode = 1` (converged): closed forms plus an
-adaptive Gauss-Kronrod rule per mode, within 1e-9 of scale of the reference's nested `quadgk` (`quad_order` is then only the
-points per panel of the inner rule a Lognormal mode needs; 8 suffice).
+`quad_mode = 1` (converged, the default -- the drop-in meets the reference's `quadgk(rtol = 1e-8)` answer): closed forms plus an
+adaptive Gauss-Kronrod rule per mode (`quad_order` is then only the points per panel of the inner rule a Lognormal mode needs;
+0 = the default, 8).  `quad_mode = 0`: one fixed `quad_order`-point Gauss rule per distribution (0 = 10 points): faster, 1e-4 ... 4e-2
+of scale away from the reference for the hydrodynamic and Long kernels -- the explicit opt-in.
 """
-function numerical_plan(pdists, kernel_func_normalized, norms; quad_order = 10, quad_mode = 0)
+function numerical_plan(pdists, kernel_func_normalized, norms; quad_order = 0, quad_mode = 1)
     d = new_desc()
     d[].n_modes = length(pdists)
     d[].dist_type = pad(map(dist_code, pdists), MAX_MODES, Int32(0))

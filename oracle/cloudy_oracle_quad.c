@@ -495,7 +495,7 @@ static void co_conv_range_top(double A, double top, double *tlo, double *thi);
  * at depth CO_CONV_LMAX, or once the rule has spent its budget of panel evaluations; the accepted value is K15.  With tol = 1e-9 the accepted K15 values are good to
  * ~1e-14 of scale (G7 is the estimate's accuracy, K15 has 1.6 x its order), so a decision that flips on a rounding
  * difference between two implementations moves the result by that much, not by tol. */
-#define CO_CONV_NINIT 16
+#define CO_CONV_NINIT 12
 #define CO_CONV_LMAX 12
 #define CO_CONV_IMAX 12
 #define CO_CONV_FLOOR 1e-10

@@ -54,7 +54,7 @@ def numerical_case(cloudy, oracle, dist_types, kname, nq=10, k_range=None):
     npm = tuple({0: 2, 1: 3, 3: 3}[t] for t in dist_types)
     extra = {"k_range": k_range} if k_range else {}
     par = cloudy.ODEParameters(pd, None, npm, NORMS, kernel_func=cloudy.get_normalized_kernel_func(kf, NORMS),
-                               quad_order=nq, **extra)
+                               quad_order=nq, quad_mode=cloudy.QUAD_FIXED, **extra)
     op = oracle.make_params(list(dist_types), np.zeros((1, 1)), (INF,) * len(dist_types), norms=NORMS,
                             **({"k_range": k_range} if k_range else {}))
     return par, op, oracle.get_normalized_kernel_func(okf, NORMS)
@@ -153,8 +153,8 @@ def test_ahead_of_time_kernels_params_input_and_float_planes(gpu_cloudy, oracle)
     mom = bench.synth_moments(3, 2000, seed=5)
     want, scale, noise = oracle.rhs_coal_numerical_batch(op, okf, 10, mom, with_noise=True)
     kf = par.kernel_func
-    jit = cloudy.NumericalPlan([1, 1, 1], kf, NORMS, 10, specialize=1)
-    aot = cloudy.NumericalPlan([1, 1, 1], kf, NORMS, 10, specialize=-1)
+    jit = cloudy.NumericalPlan([1, 1, 1], kf, NORMS, 10, specialize=1, quad_mode=cloudy.QUAD_FIXED)
+    aot = cloudy.NumericalPlan([1, 1, 1], kf, NORMS, 10, specialize=-1, quad_mode=cloudy.QUAD_FIXED)
     assert jit.specialized and not aot.specialized
     m = dev(cloudy, mom)
     outs = []
@@ -168,7 +168,7 @@ def test_ahead_of_time_kernels_params_input_and_float_planes(gpu_cloudy, oracle)
     params = cloudy.DeviceArray.zeros(9, mom.shape[1])
     cloudy._lib.check(L.cloudy_update_dist_from_moments(cd.plan([1, 1, 1]).handle, mom.shape[1], mom.shape[1], m.ptr,
                                                         params.ptr, None))
-    ci = cloudy.get_coal_ints(cloudy.NumericalCoalStyle(), ([1, 1, 1], params), kf).to_numpy()
+    ci = cloudy.get_coal_ints(cloudy.NumericalCoalStyle(), ([1, 1, 1], params), kf, quad_mode=cloudy.QUAD_FIXED).to_numpy()
     norms9 = np.tile([NORMS[0], NORMS[0] * NORMS[1], NORMS[0] * NORMS[1] ** 2], 3)[:, None]
     assert_same_rule(ci * norms9, want, scale, noise, "get_coal_ints on parameter planes")
     # float planes: final rounding only
@@ -194,10 +194,11 @@ def test_shape_parameter_outside_the_staged_rule_range_gives_nan_not_a_wrong_ans
     prm[2, bad1] = rng.uniform(10.5, 50.0, bad1.sum())      # above k_range[1] = 10
     prm[5, bad2] = -1.0                                     # not a shape parameter at all
     pd = cloudy.DeviceArray.from_numpy(prm)
-    got = cloudy.get_coal_ints(cloudy.NumericalCoalStyle(), ([1, 1], pd), kf).to_numpy()
+    got = cloudy.get_coal_ints(cloudy.NumericalCoalStyle(), ([1, 1], pd), kf, quad_mode=cloudy.QUAD_FIXED).to_numpy()
     bad = bad1 | bad2
     assert np.all(np.isnan(got[:, bad]).any(axis=0)) and np.all(np.isfinite(got[:, ~bad]))
-    wide = cloudy.get_coal_ints(cloudy.NumericalCoalStyle(), ([1, 1], pd), kf, k_range=(2.3e-16, 50.0)).to_numpy()
+    wide = cloudy.get_coal_ints(cloudy.NumericalCoalStyle(), ([1, 1], pd), kf, k_range=(2.3e-16, 50.0),
+                                quad_mode=cloudy.QUAD_FIXED).to_numpy()
     assert np.all(np.isfinite(wide[:, ~bad2])) and np.all(np.isnan(wide[:, bad2]).any(axis=0))
     ok = ~bad
     assert np.allclose(wide[:, ok], got[:, ok], rtol=1e-9, atol=0.0)   # (two tables, same nodes after the Newton steps)
@@ -206,7 +207,7 @@ def test_shape_parameter_outside_the_staged_rule_range_gives_nan_not_a_wrong_ans
 def test_numerical_plan_status_codes(gpu_cloudy):
     cloudy = gpu_cloudy
     L, E = cloudy.lib(), cloudy._lib
-    plan = cloudy.NumericalPlan([1, 1], cloudy.LinearKernelFunction(5e-3), NORMS, 10)
+    plan = cloudy.NumericalPlan([1, 1], cloudy.LinearKernelFunction(5e-3), NORMS, 10, quad_mode=cloudy.QUAD_FIXED)
     u = cloudy.DeviceArray.zeros(6, 64)
     assert L.cloudy_ssprk33_steps(plan.handle, 64, 64, u.ptr, u.ptr, 1.0, 1, None) == 0   # served (empty boxes stay empty)
     assert L.cloudy_rainshaft_ssprk33_steps(plan.handle, 4, 16, 64, u.ptr, u.ptr, 100.0, 1.0, 1, None) == E.EINVAL  # no velocities
@@ -239,7 +240,7 @@ def test_fused_ssprk33_of_numerical_plans_vs_oracle_stepping(gpu_cloudy, oracle,
     if specialize == 0:
         cloudy.solve_ssprk33(par, u, dt, n_steps, coal_type=cloudy.NumericalCoalStyle())
     else:
-        plan = cloudy.NumericalPlan(dist_types, par.kernel_func, NORMS, 10, specialize=specialize)
+        plan = cloudy.NumericalPlan(dist_types, par.kernel_func, NORMS, 10, specialize=specialize, quad_mode=cloudy.QUAD_FIXED)
         assert not plan.specialized
         cloudy._lib.check(cloudy.lib().cloudy_ssprk33_steps(plan.handle, n, n, u.ptr, u.ptr, dt, n_steps, None))
     got = u.to_numpy()
@@ -265,7 +266,7 @@ def test_cfg4q_full_size_properties(gpu_cloudy):
     mom = bench.synth_moments(3, n, seed=bench.SEED, degenerate_frac=0.0)
     kf = cloudy.HydrodynamicKernelFunction(1e2 * np.pi)
     mk = lambda e: cloudy.ODEParameters(tuple(cloudy.GammaPrimitiveParticleDistribution(1.0, 1.0, 1.0) for _ in range(3)),
-                                        None, (3, 3, 3), NORMS,
+                                        None, (3, 3, 3), NORMS, quad_mode=cloudy.QUAD_FIXED,
                                         kernel_func=cloudy.get_normalized_kernel_func(cloudy.HydrodynamicKernelFunction(e), NORMS))
     rhs = cloudy.make_box_model_rhs(cloudy.NumericalCoalStyle())
     m, dm = dev(cloudy, mom), cloudy.DeviceArray.zeros(9, n)
@@ -398,6 +399,55 @@ def test_converged_mode_reaches_the_adaptive_golden_values_on_the_device(gpu_clo
         worst = max(worst, res[1])
         print(f"{c['name']:36s} converged {res[1]:.1e}   10-point rule {res[0]:.1e}   (of scale, vs adaptive)")
     assert n_cases >= 32 and worst <= 1e-8, worst
+
+
+def test_default_numerical_drop_in_is_the_converged_mode_and_meets_the_reference_tolerance(gpu_cloudy, oracle):
+    """the line the shim promises stays unchanged -- make_box_model_rhs(NumericalCoalStyle()) with the
+    reference's own ODE parameters, no quad_* field anywhere -- must answer within north_star's 1e-8 of the reference's nested
+    quadgk.  Every golden case goes through the DEFAULT operator as moments (norms = (1, 1)); the plan behind it is the
+    converged one; cloudy_plan_desc_init itself says CONVERGED; the 10-point rule is reachable only by asking for it."""
+    import json
+    import os
+
+    cloudy, O = gpu_cloudy, oracle
+    d = cloudy._lib.PlanDesc()
+    cloudy.lib().cloudy_plan_desc_init(C.byref(d))
+    assert d.quad_mode == cloudy.QUAD_CONVERGED == 1 and d.quad_order == 0
+    with open(os.path.join(os.path.dirname(__file__), "golden", "numerical_adaptive.json")) as f:
+        gold = json.load(f)
+    mkk = {0: cloudy.ConstantKernelFunction, 1: cloudy.LinearKernelFunction, 2: cloudy.HydrodynamicKernelFunction,
+           3: cloudy.LongKernelFunction}
+    mkd = {0: lambda: cloudy.ExponentialPrimitiveParticleDistribution(1.0, 1.0),
+           1: lambda: cloudy.GammaPrimitiveParticleDistribution(1.0, 1.0, 1.0),
+           3: lambda: cloudy.LognormalPrimitiveParticleDistribution(1.0, 1.0, 1.0)}
+    rhs = cloudy.make_box_model_rhs(cloudy.NumericalCoalStyle())
+    worst, worst_fixed, n_cases = 0.0, 0.0, 0
+    for c in gold["cases"]:
+        types = [int(dd[0]) for dd in c["pdists"]]
+        npm = tuple(2 if t == 0 else 3 for t in types)
+        od = [O.make_dist(int(t), n, th, k) for t, n, th, k in c["pdists"]]
+        mom = np.array([O.moment(dd, float(q)) for dd, np_ in zip(od, npm) for q in range(np_)])[:, None].repeat(4, axis=1)
+        par = cloudy.ODEParameters(tuple(mkd[t]() for t in types), None, npm, (1.0, 1.0), kernel_func=mkk[c["kf"][0]](*c["kf"][1]))
+        assert not hasattr(par, "quad_mode") and not hasattr(par, "quad_order")
+        m, dm = dev(cloudy, mom), cloudy.DeviceArray.zeros(*mom.shape)
+        rhs(dm, m, par, 0.0)
+        got = dm.to_numpy()[:, 0]
+        Q, R, S = (np.abs(np.array(c[x])) for x in "QRS")
+        scale = np.concatenate([[Q[mo, :, k].sum() + R[mo, :, k].sum() + S[mo, 0, k] + (S[mo, 1, k - 1] if k else 0.0)
+                                 for mo in range(npm[k])] for k in range(len(types))])
+        # (a Lognormal closure inverted from its moments carries the conditioning of sigma^2 = ln(M0 M2 / M1^2))
+        err = float(np.max(np.abs(got - np.array(c["coal_ints"])) / scale))
+        worst = max(worst, err)
+        par.quad_mode = cloudy.QUAD_FIXED          # the explicit opt-in (BASELINE configs[3]: "10-pt Gauss quadrature")
+        rhs(dm, m, par, 0.0)
+        worst_fixed = max(worst_fixed, float(np.max(np.abs(dm.to_numpy()[:, 0] - np.array(c["coal_ints"])) / scale)))
+        n_cases += 1
+    from cloudy_jl_amd.box_model import _numerical_plan_for
+    par = cloudy.ODEParameters((mkd[1](), mkd[1]()), None, (3, 3), (1.0, 1.0), kernel_func=cloudy.LinearKernelFunction(5e-3))
+    plan = _numerical_plan_for(par)
+    assert plan.quad_mode == cloudy.QUAD_CONVERGED and plan.quad_order == 8
+    print(f"default drop-in: worst {worst:.1e} of scale over {n_cases} golden cases (10-point opt-in: {worst_fixed:.1e})")
+    assert n_cases >= 32 and worst <= 1e-8 and worst_fixed > 1e-4
 
 
 def test_converged_mode_on_random_multi_scale_mixtures_on_the_device(gpu_cloudy, oracle):

@@ -639,7 +639,7 @@ def test_cfg0_single_box_tsit5_fixed_step(gpu_cloudy, oracle):
     mv = cloudy.CoalescenceData(kern, (3, 3), (0.9, 1.0), bench.NORMS, cloudy.MovingThreshold()).plan([1, 1])
     z6 = cloudy.DeviceArray.zeros(6, 8)
     assert L.cloudy_tsit5_steps(mv.handle, 8, 8, z6.ptr, z6.ptr, 1.0, 1, None) == E.EUNSUPPORTED
-    npl = cloudy.NumericalPlan([1, 1], cloudy.LinearKernelFunction(5e-3), bench.NORMS, 10)
+    npl = cloudy.NumericalPlan([1, 1], cloudy.LinearKernelFunction(5e-3), bench.NORMS)
     assert L.cloudy_tsit5_steps(npl.handle, 8, 8, z6.ptr, z6.ptr, 1.0, 1, None) == E.EUNSUPPORTED
     assert L.cloudy_tsit5_steps(cd.plan([1]).handle, 8, 8, z6.ptr, z6.ptr, 1.0, -1, None) == E.EINVAL
 

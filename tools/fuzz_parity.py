@@ -249,8 +249,8 @@ def check_numerical_config(pkg, cfg, n, seed):
     mom = moments_for(cfg["dist"], n, seed)
     tio = np.float64 if cfg["dtype"] == 0 else np.float32
     mom_in = mom.astype(tio).astype(np.float64)
-    jit = pkg.NumericalPlan(cfg["dist"], kfn, cfg["norms"], cfg["nq"], k_range=cfg["k_range"], dtype=cfg["dtype"], specialize=1)
-    aot = pkg.NumericalPlan(cfg["dist"], kfn, cfg["norms"], cfg["nq"], k_range=cfg["k_range"], dtype=cfg["dtype"], specialize=-1)
+    jit = pkg.NumericalPlan(cfg["dist"], kfn, cfg["norms"], cfg["nq"], k_range=cfg["k_range"], dtype=cfg["dtype"], specialize=1, quad_mode=0)
+    aot = pkg.NumericalPlan(cfg["dist"], kfn, cfg["norms"], cfg["nq"], k_range=cfg["k_range"], dtype=cfg["dtype"], specialize=-1, quad_mode=0)
     a, b = run(pkg, jit, mom_in, tio), run(pkg, aot, mom_in, tio)
     want, scale, noise = O.rhs_coal_numerical_batch(op, okf, cfg["nq"], mom_in, with_noise=True)
     keep = np.ones(mom.shape[1], dtype=bool)

@@ -38,7 +38,7 @@ def main():
             conv = name.endswith("converged")
             d = pkg.NumericalPlan.make_desc([1, 1, 1], pkg.HydrodynamicKernelFunction(1e2 * np.pi), bench.NORMS,
                                             8 if conv else 10, kernel_func_is_normalized=False,
-                                            **({"quad_mode": pkg.QUAD_CONVERGED} if conv else {}))
+                                            quad_mode=pkg.QUAD_CONVERGED if conv else pkg.QUAD_FIXED)
             keep = None
         else:
             spec = bench.workload_spec(name)

@@ -33,7 +33,7 @@ def main():
             if waves.endswith("L0"):
                 os.environ["CLOUDY_HIP_JIT_QUAD_LICM"] = "0"
             try:
-                plan = pkg.NumericalPlan([1] * N, kfn, bench.NORMS, nq, specialize=1)
+                plan = pkg.NumericalPlan([1] * N, kfn, bench.NORMS, nq, specialize=1, quad_mode=pkg.QUAD_FIXED)
             except pkg.CloudyError as e:
                 print(f"N={N} {type(kf).__name__} nq={nq} waves={waves or 'auto'}: {e}")
                 continue
@@ -45,7 +45,7 @@ def main():
                   f"{n / ms.value * 1e3:.3e} parcel-RHS/s", flush=True)
         if quick:
             continue
-        aot = pkg.NumericalPlan([1] * N, kfn, bench.NORMS, nq, specialize=-1)
+        aot = pkg.NumericalPlan([1] * N, kfn, bench.NORMS, nq, specialize=-1, quad_mode=pkg.QUAD_FIXED)
         pkg._lib.check(L.cloudy_coal_rhs(aot.handle, n, n, m.ptr, dm.ptr, None))
         ms = C.c_float()
         pkg._lib.check(L.cloudy_time_coal_rhs(aot.handle, n, n, m.ptr, dm.ptr, None, 2, C.byref(ms)))
