@@ -343,7 +343,7 @@ __device__ __forceinline__ void conv_adaptive(double tlo, double thi, ConvMarks<
 #pragma unroll
             for (int e = 0; e < NEST; ++e) {
                 K[e] = fma(wk, ve[e], K[e]);
-                G[e] = fma(wg, ve[e], G[e]);
+                if (g & 1) G[e] = fma(wg, ve[e], G[e]);  // (the Gauss nodes are the odd ones; a zero weight is not a no-op for the compiler)
             }
         }
         bool ok = true;
@@ -682,6 +682,221 @@ __device__ __forceinline__ void conv_T_lognormal(const QArgs &Q, const double *_
     T2 = T[2] * pref;
 }
 
+// ---- ONE walk over all the Gamma-weight rules of a parcel (round 4) ----
+// A wave runs a rule for as long as its lane with the most panel evaluations; run rule by rule, a wave of the cfg4q batch
+// keeps 0.69 of its lanes busy (tools/conv_lab: 48 evaluations per parcel on average, 69 for the slowest lanes of a wave).
+// Here a lane that has finished the rule of mode j goes straight on to the rule of its next mode while its neighbours
+// still work on theirs: the bound becomes the lanes' TOTAL evaluations (0.81).  Everything a rule needs is prepared
+// before the loop, in straight-line code every lane runs through together (ConvRule: ~12 doubles per rule); the switch
+// inside the loop is a handful of selects.  (Round 3 tried this with the rules' set-up -- lgamma, two logarithms, the marks
+// -- inside the loop: 328 registers and the set-up executed, masked, in almost every trip: slower.)  The arithmetic of
+// every rule is that of conv_adaptive<3, 3, false> with the node function below: results are bit-identical to running
+// the rules one after the other.
+template <int NM>
+struct ConvRule {
+    bool valid;
+    double A, lgA, th, lnth, tlo, thi;
+    double kj, lgB, rB, ex1, ex2;  // Long: the shape, -ln B(k, k), B(k+1, k+1) / B(k, k), the kinks of G in the rule's variable
+    double sc[3];                  // Long: the scale of each output (T_m with 1 - w = 1, over the prefactor)
+    double mc[NM], mw[NM];         // the other modes' cores (ln mean size, width)
+    int mI[NM];
+};
+
+template <int N, int KIND>
+__device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensity (&lg)[N],
+                                              const ConvRule<(N > 1 ? N - 1 : 1)> (&rb)[(N > 1 ? N - 1 : 1)],
+                                              double (&Traw)[(N > 1 ? N - 1 : 1)][3]) {
+    constexpr int NM = N > 1 ? N - 1 : 1, NR = NM;
+    // ---- the state of the rule in hand
+    int j = -1;
+    double A = 1.0, lgA = 0.0, thj = 1.0, lnthj = 0.0, tlo = 0.0, thi = 0.0, kj = 1.0, lgB = 0.0, rB = 0.0;
+    double scaleS[3] = {1.0, 1.0, 1.0}, out[3] = {0.0, 0.0, 0.0};
+    ConvLogDensity own, oth[NM];
+    ConvMarks<NM> mk;
+    double h0 = 0.0, gap = 0.0, cur = 0.0, a0 = 0.0, h = 0.0;
+    int io = 1, L = 0, budget = kConvBudget;
+    unsigned i = 0;
+    bool busy = true;
+    own = lg[0];
+#pragma unroll
+    for (int sl = 0; sl < NM; ++sl) oth[sl] = lg[0];
+    mk.shift = 0.0;
+    mk.extra[0] = mk.extra[1] = mk.extra[2] = INFINITY;
+#pragma unroll
+    for (int sl = 0; sl < NM; ++sl) {
+        mk.c[sl] = 0.0;
+        mk.w[sl] = 1.0;
+        mk.I[sl] = 0;
+        mk.q[sl] = 0;
+        mk.v[sl] = INFINITY;
+    }
+    // the next valid rule after j for the lanes with need = true (busy = false: none left); selects only
+    const auto next_rule = [&](bool need) {
+        int jn = NR;
+#pragma unroll
+        for (int r = NR - 1; r >= 0; --r)
+            if (rb[r].valid && r > j) jn = r;
+        const bool go = need && jn < NR;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const bool sel = go && jn == r;
+            A = sel ? rb[r].A : A;
+            lgA = sel ? rb[r].lgA : lgA;
+            thj = sel ? rb[r].th : thj;
+            lnthj = sel ? rb[r].lnth : lnthj;
+            tlo = sel ? rb[r].tlo : tlo;
+            thi = sel ? rb[r].thi : thi;
+            if (KIND == KF_LONG) {
+                kj = sel ? rb[r].kj : kj;
+                lgB = sel ? rb[r].lgB : lgB;
+                rB = sel ? rb[r].rB : rB;
+                mk.extra[1] = sel ? rb[r].ex1 : mk.extra[1];
+                mk.extra[2] = sel ? rb[r].ex2 : mk.extra[2];
+                scaleS[0] = sel ? rb[r].sc[0] : scaleS[0];
+                scaleS[1] = sel ? rb[r].sc[1] : scaleS[1];
+                scaleS[2] = sel ? rb[r].sc[2] : scaleS[2];
+            }
+#pragma unroll
+            for (int sl = 0; sl < NM; ++sl) {
+                mk.c[sl] = sel ? rb[r].mc[sl] : mk.c[sl];
+                mk.w[sl] = sel ? rb[r].mw[sl] : mk.w[sl];
+                mk.I[sl] = sel ? rb[r].mI[sl] : mk.I[sl];
+            }
+            // the densities of the rule's own mode (r) and of the others, ascending (slot sl is mode sl < r ? sl : sl + 1)
+#pragma unroll
+            for (int m = 0; m < N; ++m)
+                if (m == r) {
+                    own.a = sel ? lg[m].a : own.a;
+                    own.b = sel ? lg[m].b : own.b;
+                    own.c = sel ? lg[m].c : own.c;
+                    own.lognormal = sel ? lg[m].lognormal : own.lognormal;
+                } else {
+                    const int sl = m < r ? m : m - 1;
+#pragma unroll
+                    for (int s2 = 0; s2 < NM; ++s2)
+                        if (s2 == sl) {
+                            oth[s2].a = sel ? lg[m].a : oth[s2].a;
+                            oth[s2].b = sel ? lg[m].b : oth[s2].b;
+                            oth[s2].c = sel ? lg[m].c : oth[s2].c;
+                            oth[s2].lognormal = sel ? lg[m].lognormal : oth[s2].lognormal;
+                        }
+                }
+        }
+        if (go) {
+            j = jn;
+            mk.shift = lnthj;
+            h0 = (thi - tlo) * (1.0 / double(kConvNInit));
+            gap = 1e-7 * (thi - tlo);
+#pragma unroll
+            for (int sl = 0; sl < NM; ++sl) {
+                mk.q[sl] = -(mk.I[sl] + 1);
+                mk.v[sl] = mk.value(sl);
+            }
+            if (KIND != KF_LONG) {
+                scaleS[0] = 1.0;
+                scaleS[1] = A * thj;
+                scaleS[2] = A * (A + 1.0) * thj * thj;
+            }
+            cur = tlo;
+            a0 = tlo;
+            io = 1;
+            L = 0;
+            i = 0u;
+            budget = kConvBudget;
+            out[0] = out[1] = out[2] = 0.0;
+        }
+        busy = need ? go : busy;
+    };
+    // as in conv_adaptive; need = false: no change.  Returns true for the lanes whose rule has no panel left.
+    const auto next_panel = [&](bool need) -> bool {
+        const bool go = need && cur < thi;
+        const double lim = cur + gap;
+        int io2 = io;
+        double ownp = fma(h0, double(io2), tlo);
+        while (need && ownp <= lim) {
+            ++io2;
+            ownp = fma(h0, double(io2), tlo);
+        }
+        double nxt = fmin(thi, ownp);
+        nxt = fmin(nxt, mk.next(lim, need));
+        nxt = nxt > thi - gap ? thi : nxt;
+        io = io2;
+        a0 = go ? cur : a0;
+        h = go ? nxt - cur : h;
+        cur = go ? nxt : cur;
+        L = go ? 0 : L;
+        i = go ? 0u : i;
+        return need && !go;
+    };
+    next_rule(true);
+    (void)next_panel(busy);
+#pragma unroll 1
+    while (busy) {
+        const double w = ldexp(h, -L), hw = 0.5 * w, c = fma(w, double(i), a0) + hw;
+        double K[3] = {0.0, 0.0, 0.0}, G[3] = {0.0, 0.0, 0.0};
+        --budget;
+#pragma unroll
+        for (int g = 0; g < 15; ++g) {
+            const ConvNode nd = conv_node(fma(hw, kGKX[g], c), A, lgA);
+            const double s = nd.u * thj, ls = nd.lu + lnthj;
+            const double ow = own(s, ls);
+            double up = 0.0, den = 1.0;
+#pragma unroll
+            for (int sl = 0; sl < NM; ++sl) {
+                const double rho = exp_fin(fmin(oth[sl](s, ls) - ow, 700.0));
+                den += rho;
+                up += sl >= j ? rho : 0.0;
+            }
+            double hh = nd.wt * (up * recip_fast(den));
+            if (KIND == KF_LONG) {
+                const double xt = Q.kf[0];
+                double Gs;
+                if (s <= xt)
+                    Gs = Q.kf[1] * (s * s) * ((kj + 1.0) / fma(2.0, kj, 1.0));
+                else if (s >= 2.0 * xt)
+                    Gs = Q.kf[2] * s;
+                else
+                    Gs = conv_long_G_mid(Q, kj, lgB, rB, s);
+                hh *= Gs;
+            }
+            const double v0 = hh, v1 = hh * s, v2 = (hh * s) * s;
+            const double wk = kGKWK[g], wg = kGKWG[g];
+            K[0] = fma(wk, v0, K[0]);
+            K[1] = fma(wk, v1, K[1]);
+            K[2] = fma(wk, v2, K[2]);
+            if (g & 1) {  // the Gauss nodes
+                G[0] = fma(wg, v0, G[0]);
+                G[1] = fma(wg, v1, G[1]);
+                G[2] = fma(wg, v2, G[2]);
+            }
+        }
+        bool ok = true;
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+            if (fabs(K[e] - G[e]) * hw > kConvTol * fmax(fabs(fma(K[e], hw, out[e])), kConvFloor * scaleS[e])) ok = false;
+        const bool accept = ok || L == kConvLMax || budget <= 0;
+        if (accept) {
+#pragma unroll
+            for (int e = 0; e < 3; ++e) out[e] = fma(K[e], hw, out[e]);
+        }
+        const unsigned ni = accept ? i + 1u : i << 1;
+        const int upl = accept ? min((int)__builtin_ctz(ni), L) : 0;
+        i = ni >> upl;
+        L = accept ? L - upl : L + 1;
+        const bool done = next_panel(accept && L == 0);
+        // the rule of this lane is finished: park its sums and take the next one (selects; lanes with done = false pass through)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const bool st = done && j == r;
+            Traw[r][0] = st ? out[0] : Traw[r][0];
+            Traw[r][1] = st ? out[1] : Traw[r][1];
+            Traw[r][2] = st ? out[2] : Traw[r][2];
+        }
+        next_rule(done);
+        (void)next_panel(done && busy);
+    }
+}
+
 // get_coal_ints(::NumericalCoalStyle, ...) for the parcel of this lane in converged mode: acc[k][m], normalised units,
 // kernel constants INCLUDED.  tab: nq Gauss-Legendre nodes on [-1, 1], then nq weights.
 template <int N, int KIND>
@@ -729,88 +944,92 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
     }
     // ---- phase 2: T_m, the self collisions weighting_fn hands to mode j + 1
 #ifndef CLOUDY_ABLATE_CONV_T  // (timing experiment only: the closed forms alone)
+    if (N > 1) {
+        constexpr int NM = N > 1 ? N - 1 : 1;
+        constexpr double gam = KIND == KF_LINEAR ? 1.0 : KIND == KF_HYDRODYNAMIC ? 4.0 / 3.0 : 0.0;
+        // the rules of the Gamma-family modes: everything prepared here, walked in ONE loop (conv_T_merged)
+        ConvRule<NM> rb[NM];
+        double Traw[NM][3], prefj[NM];
+        bool any_gamma = false;
 #pragma unroll
-    for (int j = 0; j < N - 1; ++j) {
-        if (!(nj_[j] > 0.0)) continue;
-        {
+        for (int j = 0; j < N - 1; ++j) {
+            ConvRule<NM> &r = rb[j];
+            Traw[j][0] = Traw[j][1] = Traw[j][2] = 0.0;
+            r.valid = !lnj_[j] && nj_[j] > 0.0;
+            r.A = r.lgA = r.th = 1.0;
+            r.lnth = r.tlo = r.thi = r.kj = r.lgB = r.rB = 0.0;
+            r.ex1 = r.ex2 = INFINITY;
+            r.sc[0] = r.sc[1] = r.sc[2] = 1.0;
+#pragma unroll
+            for (int sl = 0; sl < NM; ++sl) {
+                r.mc[sl] = 0.0;
+                r.mw[sl] = 1.0;
+                r.mI[sl] = 0;
+            }
+            prefj[j] = 0.0;
+            if (lnj_[j]) continue;  // (wave-uniform: the closure family of a mode is a plan constant) -> conv_T_lognormal below
+            any_gamma = true;
+            const double (&pr)[4] = selfpr[j];
+            const double kj = kj_[j], thj = thj_[j], lnthj = lnthj_[j];
+            const double Ash = fma(2.0, kj, gam);  // homogeneous kernels: T_m = 1/2 s0 E_{Gamma(2k + gamma)}[s^m (1 - w)]
+            prefj[j] = KIND == KF_LONG ? 0.5 * (nj_[j] * nj_[j]) : 0.5 * pr[0];
+            r.A = Ash;
+            r.lgA = lgamma_pos(Ash);
+            r.th = thj;
+            r.lnth = lnthj;
+            conv_range(Ash, 2.0, r.lgA, r.tlo, r.thi);
+            // marks: the other modes' cores; Long: s = x_t and 2 x_t (kinks of G)
+            r.ex1 = KIND == KF_LONG ? log_pos(Q.kf[0] / thj) : INFINITY;
+            r.ex2 = KIND == KF_LONG ? log_pos(2.0 * Q.kf[0] / thj) : INFINITY;
+            {
+                ConvMarks<NM> mk;
+                int slot = 0;
+#pragma unroll
+                for (int m = 0; m < N; ++m)
+                    if (m != j) {
+#pragma unroll
+                        for (int sl = 0; sl < N - 1; ++sl)
+                            if (sl == slot) {
+                                mk.shift = lnthj;
+                                mk.core(sl, cm[m], wm[m], (r.thi - r.tlo) * (1.0 / double(kConvNInit)));
+                                r.mc[sl] = cm[m];
+                                r.mw[sl] = wm[m];
+                                r.mI[sl] = mk.I[sl];
+                            }
+                        ++slot;
+                    }
+            }
+            r.kj = kj;
+            if (KIND == KF_LONG) {
+                r.lgB = lgamma_pos(2.0 * kj) - 2.0 * lgkj_[j];  // -ln B(k, k)
+                r.rB = kj / (2.0 * fma(2.0, kj, 1.0));           // B(k+1, k+1) / B(k, k)
+                // (totals: T_m with 1 - w = 1 -- half the self-collision integrals of orders 0, 1, 2 -- the estimates' scale)
+                const double rp = 1.0 / prefj[j];
+                r.sc[0] = (0.5 * pr[0]) * rp;
+                r.sc[1] = pr[1] * rp;
+                r.sc[2] = (pr[2] + pr[3]) * rp;
+            }
+        }
+        if (any_gamma) conv_T_merged<N, KIND>(Q, lg, rb, Traw);
+#pragma unroll
+        for (int j = 0; j < N - 1; ++j) {
+            if (!(nj_[j] > 0.0)) continue;
             const double (&pr)[4] = selfpr[j];
             double T0 = 0.0, T1 = 0.0, T2 = 0.0;
-            // (totals: T_m with 1 - w = 1 -- half the self-collision integrals of orders 0, 1, 2 -- the estimates' scale)
-            const double totals[3] = {0.5 * pr[0], pr[1], pr[2] + pr[3]};
             if (lnj_[j]) {  // wave-uniform
+                const double totals[3] = {0.5 * pr[0], pr[1], pr[2] + pr[3]};
                 conv_T_lognormal<N, KIND>(Q, tab, nj_[j], thj_[j], kj_[j], cm, wm, lg, j, totals, T0, T1, T2);
             } else {
-                constexpr double gam = KIND == KF_LINEAR ? 1.0 : KIND == KF_HYDRODYNAMIC ? 4.0 / 3.0 : 0.0;
-                const double kj = kj_[j], thj = thj_[j], lnthj = lnthj_[j];
-                const double Ash = fma(2.0, kj, gam);  // homogeneous kernels: T_m = 1/2 s0 E_{Gamma(2k + gamma)}[s^m (1 - w)]
-                const double pref = KIND == KF_LONG ? 0.5 * (nj_[j] * nj_[j]) : 0.5 * pr[0];
-                const double lgA = lgamma_pos(Ash);
-                double tlo, thi;
-                conv_range(Ash, 2.0, lgA, tlo, thi);
-                // marks: the other modes' cores; Long: s = x_t and 2 x_t (kinks of G)
-                ConvMarks<(N > 1 ? N - 1 : 1)> mk;
-                mk.shift = lnthj;
-                mk.extra[0] = INFINITY;
-                mk.extra[1] = KIND == KF_LONG ? log_pos(Q.kf[0] / thj) : INFINITY;
-                mk.extra[2] = KIND == KF_LONG ? log_pos(2.0 * Q.kf[0] / thj) : INFINITY;
-                {
-                    int slot = 0;
-#pragma unroll
-                    for (int m = 0; m < N; ++m)
-                        if (m != j) {
-#pragma unroll
-                            for (int sl = 0; sl < N - 1; ++sl)
-                                if (sl == slot)
-                                    mk.core(sl, cm[m], wm[m], (thi - tlo) * (1.0 / double(kConvNInit)));
-                            ++slot;
-                        }
-                }
-                double lgB = 0.0, rB = 0.0;
-                if (KIND == KF_LONG) {
-                    lgB = lgamma_pos(2.0 * kj) - 2.0 * lgkj_[j];  // -ln B(k, k)
-                    rB = kj / (2.0 * fma(2.0, kj, 1.0));           // B(k+1, k+1) / B(k, k)
-                }
-                const auto node = [&](double t, double (&vals)[3]) {
-                    const ConvNode nd = conv_node(t, Ash, lgA);
-                    const double s = nd.u * thj, ls = nd.lu + lnthj;
-                    double hh = nd.wt * conv_one_minus_w<N>(lg, j, s, ls);
-                    if (KIND == KF_LONG) {
-                        const double xt = Q.kf[0];
-                        double G;
-                        if (s <= xt)
-                            G = Q.kf[1] * (s * s) * ((kj + 1.0) / fma(2.0, kj, 1.0));
-                        else if (s >= 2.0 * xt)
-                            G = Q.kf[2] * s;
-                        else
-                            G = conv_long_G_mid(Q, kj, lgB, rB, s);
-                        hh *= G;
-                    }
-                    vals[0] = hh;
-                    vals[1] = hh * s;
-                    vals[2] = (hh * s) * s;
-                };
-                const int est_idx[3] = {0, 1, 2};
-                double scaleS[3];
-                if (KIND == KF_LONG) {
-                    const double rp = 1.0 / pref;
-                    scaleS[0] = totals[0] * rp;
-                    scaleS[1] = totals[1] * rp;
-                    scaleS[2] = totals[2] * rp;
-                } else {
-                    scaleS[0] = 1.0;
-                    scaleS[1] = Ash * thj;
-                    scaleS[2] = Ash * (Ash + 1.0) * thj * thj;
-                }
-                double T[3] = {0.0, 0.0, 0.0};
-                conv_adaptive<3, 3, false>(tlo, thi, mk, est_idx, scaleS, kConvBudget, node, node, T);
+                double T[3] = {Traw[j][0], Traw[j][1], Traw[j][2]};
                 if (KIND != KF_LONG) {
                     // the mass below t_lo (1e-13 of the weight; a sizeable part of it for a shape clamped to eps)
+                    const double Ash = rb[j].A, tlo = rb[j].tlo;
                     const double u_lo = exp_fin(tlo);
-                    T[0] = fma(conv_one_minus_w<N>(lg, j, u_lo * thj, tlo + lnthj), exp_fin(fma(Ash, tlo, -lgamma_pos(Ash + 1.0))), T[0]);
+                    T[0] = fma(conv_one_minus_w<N>(lg, j, u_lo * thj_[j], tlo + lnthj_[j]), exp_fin(fma(Ash, tlo, -lgamma_pos(Ash + 1.0))), T[0]);
                 }
-                T0 = T[0] * pref;
-                T1 = T[1] * pref;
-                T2 = T[2] * pref;
+                T0 = T[0] * prefj[j];
+                T1 = T[1] * prefj[j];
+                T2 = T[2] * prefj[j];
             }
             acc[j][0] -= T0;
             acc[j][1] -= T1;
