@@ -162,10 +162,12 @@ int cloudy_comm_create(int world_size, int rank, const void *id, int device, clo
     *out = nullptr;
     if (world_size < 1 || rank < 0 || rank >= world_size) return cfail(CLOUDY_EINVAL, "need 0 <= rank < world_size");
     if (!id) return cfail(CLOUDY_EINVAL, "id is NULL (rank 0 calls cloudy_comm_unique_id and the host distributes it)");
-    int rc = need_rccl();
-    if (rc) return rc;
+    // (the device check comes first, as in cloudy_comm_unique_id: a host without a GPU answers ENODEVICE whether or not
+    // librccl is installed, and never loads the 0.5 GB library)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return cfail(CLOUDY_ENODEVICE, "no HIP device");
+    int rc = need_rccl();
+    if (rc) return rc;
     if (device < 0) (void)hipGetDevice(&device);
     if (device >= ndev) return cfail(CLOUDY_EINVAL, "device %d out of range (%d devices)", device, ndev);
     cloudy_comm *c = new (std::nothrow) cloudy_comm();
@@ -192,10 +194,10 @@ int cloudy_comm_create(int world_size, int rank, const void *id, int device, clo
 int cloudy_comm_create_all(int n_devices, const int *devices, cloudy_comm **comms_out) {
     if (!comms_out || n_devices < 1) return cfail(CLOUDY_EINVAL, "need n_devices >= 1 and comms_out");
     for (int i = 0; i < n_devices; ++i) comms_out[i] = nullptr;
-    int rc = need_rccl();
-    if (rc) return rc;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return cfail(CLOUDY_ENODEVICE, "no HIP device");
+    int rc = need_rccl();
+    if (rc) return rc;
     if (n_devices > 64) return cfail(CLOUDY_EUNSUPPORTED, "n_devices > 64");
     int devs[64];
     for (int i = 0; i < n_devices; ++i) {

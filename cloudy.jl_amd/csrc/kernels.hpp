@@ -102,8 +102,10 @@ __host__ __device__ constexpr int trisym(int p, int q) {
 __device__ __forceinline__ double div_by_const(double x, double d, double r) {
     const double q = x * r;
     // Inf / NaN of the first product must survive: there the residual is NaN, and v_min_f64 (minNum: the non-NaN operand)
-    // turns it into a finite number, so the FMA returns q itself -- one instruction instead of a compare and two selects
-    const double e = __builtin_fmin(fma(-q, d, x), 1.7976931348623157e308);
+    // turns it into a finite number, so the FMA returns q itself -- one instruction instead of a compare and two selects.
+    // A FINITE x whose quotient overflows (q = +-Inf, residual = -+Inf) needs the clamp on the other side as well: the
+    // FMA then adds a finite number to q and returns the Inf Julia's x / d gives (without it: Inf - Inf = NaN).
+    const double e = __builtin_fmax(__builtin_fmin(fma(-q, d, x), 1.7976931348623157e308), -1.7976931348623157e308);
     return fma(e, r, q);
 }
 
@@ -537,8 +539,9 @@ __device__ __forceinline__ void msh_grid_f32(const Grid &grid, double xt, double
 // (X, Y drawn from the size-biased laws x^p f(x) / M_p, which are Lognormal(mu + p sigma^2, sigma) again).  The inner
 // integral is a closed form, Phi((ln(xt - y) - mu - p1 sigma^2) / sigma); the outer one is a kLnNodes-point midpoint rule
 // in v, y = xt / (1 + e^-v): in v the integrand is analytic and decays like a Gaussian on both sides (ln y ~ v for
-// v << 0, ln(xt - y) ~ -v for v >> 0), so the equispaced rule converges geometrically -- measured <= 1e-12 M_p1 M_p2
-// against adaptive quadrature of the reference integrand over sigma in [0.01, 2] (tests/golden/lognormal_adaptive.json).
+// v << 0, ln(xt - y) ~ -v for v >> 0), so the equispaced rule converges geometrically -- measured against adaptive
+// quadrature of the reference integrand over sigma in [0.005, 2], thresholds at 1.8 ... 2.5 e^mu among them
+// (tests/golden/lognormal_adaptive.json; tests/test_oracle_kats.py states the bound).
 // One pass serves all (p1 <= p2): per node one Gaussian, its ratios for the other p2 (M_q ratio recurrence), and M
 // values of Phi.  Every lane does identical work (no data-dependent trip counts).  theta = mu, k = sigma.
 // Output convention of msh_grid: WITHOUT the factors n and M_p2 the caller applies: msh[p1][p2] = Prob * M_p1 / n.
@@ -552,10 +555,22 @@ __device__ __forceinline__ void msh_lognormal(double xt, double mu, double sg, d
     constexpr int M = P + 2;
     constexpr int T = M * (M + 1) / 2;
     const double lxt = log_pos(xt), inv_sg = 1.0 / sg, s2 = sg * sg;
-    double vlo = fmin(0.0, mu - lxt) - 8.5 * sg, vhi = fmax(0.0, lxt - mu) + 8.5 * sg;
+    // The window of v in which the integrand lives, through the exact map v(ln y) = d - ln(1 - e^d), d = ln y - ln xt < 0
+    // (round 4): 8.5 sigma of the density of order 0 on the left; on the right the end of the density of the top order or
+    // the decay of the inner Phi (ln(xt - y) = mu - 8.5 sigma: v = ln(e^delta - 1)), whichever comes first.  ~17 sigma of
+    // ln y whatever ln xt - mu is, so the node spacing scales with sigma (rounds 2-3 took v = ln y - ln xt and v = delta,
+    // true only far from v = 0: for x_t ~ 2 e^mu and sigma <= 0.03 most nodes fell outside the window -- 2.6e-6 at
+    // sigma = 0.01).  Empty window: the integral is below e^-36 M_p1 M_p2 -> h = 0.
+    double vlo = 0.0, vhi = 0.0;
     {
-        const double d = (mu + double(M - 1) * s2 + 8.5 * sg) - lxt;  // upper end of the density of the top order
-        if (d < -1e-9) vhi = fmin(vhi, d - log(-expm1(d)));
+        const double d_lo = fma(-8.5, sg, mu) - lxt, d_hi = (mu + double(M - 1) * s2 + 8.5 * sg) - lxt;
+        const double delta = (lxt - mu) + 8.5 * sg;
+        if (d_lo < -1e-9 && delta > 1e-9) {
+            vlo = d_lo - log(-expm1(d_lo));
+            vhi = delta > 36.0 ? delta : log(expm1(delta));
+            if (d_hi < -1e-9) vhi = fmin(vhi, d_hi - log(-expm1(d_hi)));
+            vhi = fmax(vhi, vlo);
+        }
     }
     const double h = (vhi - vlo) * (1.0 / double(kLnNodes));
     double acc[T];

@@ -51,9 +51,20 @@ class Communicator:
         import torch.distributed as dist
 
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [cls.unique_id() if rank == 0 else None]
+        # Every rank takes part in the broadcast whatever happens on rank 0: a failure there (RCCL not loadable, no
+        # device) travels as ("error", text) and is raised on ALL ranks, so that the callers' next collective is the same
+        # one everywhere (a rank 0 that raised before the broadcast left the others blocked in it).
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = ("id", cls.unique_id())
+            except Exception as e:  # noqa: BLE001 -- whatever it is, the other ranks must hear of it
+                box[0] = ("error", f"{type(e).__name__}: {e}")
         dist.broadcast_object_list(box, src=0, group=group)
-        return cls(world, rank, box[0], device)
+        kind, payload = box[0]
+        if kind != "id":
+            raise _lib.CloudyError(_lib.ECOMM, "rank 0 could not create the RCCL unique id: " + payload)
+        return cls(world, rank, payload, device)
 
     def allreduce_moment_sums(self, plan, arr, stream=None):
         """cloudy_moment_sums_allreduce: plane sums of this rank's (planes, n) device array summed over all ranks."""

@@ -304,13 +304,22 @@ function make_rainshaft_rhs(coal_type::CoalescenceStyle; plan = nothing, stream 
     return rhs
 end
 
-# the hipStream_t of the calling task when AMDGPU.jl is loaded (its arrays are ordered on that stream), else the
-# default stream
-function current_stream()
-    if isdefined(Main, :AMDGPU)
-        return Base.unsafe_convert(Ptr{Cvoid}, Main.AMDGPU.stream())
+# The hipStream_t of the calling task.  Device arrays come from AMDGPU.jl and are ordered on ITS task-local stream; a
+# launch on any other stream (the NULL stream included) would race with the kernels that produced `m`, and `sync = true`
+# would then wait on the wrong stream.  AMDGPU.jl is looked up among the LOADED modules -- it may have been loaded inside
+# the host's own package, where `isdefined(Main, :AMDGPU)` is false -- and when it cannot be found a device array without
+# an explicit `stream = ...` is an error, not a silent launch on the NULL stream.
+function amdgpu_module()
+    for (id, mod) in Base.loaded_modules     # (by name: whichever environment or package loaded it)
+        id.name == "AMDGPU" && return mod
     end
-    return C_NULL
+    return nothing
+end
+function current_stream()
+    mod = amdgpu_module()
+    mod === nothing && error("CloudyHIP: a device array was passed but AMDGPU.jl is not among Base.loaded_modules, so the " *
+                             "stream its kernels are ordered on cannot be determined; pass `stream = <hipStream_t>` explicitly")
+    return Base.unsafe_convert(Ptr{Cvoid}, Base.invokelatest(mod.stream))
 end
 
 """

@@ -456,8 +456,7 @@ static double co_msh_y(int j, void *vctx) {
  * SAME-RULE restatement of what the HIP kernels evaluate (kernels.hpp, msh_lognormal): the inner integral is the closed
  * form of co_partial_moment; the outer one is a CO_LN_NODES-point midpoint rule in v, y = xt / (1 + e^-v) -- in v the
  * integrand is analytic and decays like a Gaussian on both sides (ln y ~ v for v << 0, ln(xt - y) ~ -v for v >> 0), so
- * the equispaced rule converges geometrically; the range covers 8.5 sigma of the density on the left and the decay of
- * the inner Phi (or the end of the density, whichever comes first) on the right.  With p the size-biased laws,
+ * the equispaced rule converges geometrically; the range is the window of co_lognormal_msh_range.  With p the size-biased laws,
  *   result = M_p1 M_p2 sum_nodes h G_p2(ln y) (1 - y/xt) Phi((ln(xt - y) - mu - p1 sigma^2) / sigma),
  *   G_q(l) = exp(-(l - mu - q sigma^2)^2 / (2 sigma^2)) / (sigma sqrt(2 pi)).
  * Error against adaptive quadrature of the reference integrand: <= 1e-12 M_p1 M_p2 (tests/test_oracle_kats.py,
@@ -466,11 +465,23 @@ static double co_msh_y(int j, void *vctx) {
 #define CO_LN_NODES 48
 #define CO_LN_MAXORDER 7 /* M = P + 2 <= 7 orders share one range, as the kernel's single pass over the nodes does */
 static double co_softplus(double x) { return x > 0.0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
+/* The window of v in which the integrand lives, through the EXACT map v(ln y) = d - ln(1 - e^d), d = ln y - ln xt < 0
+ * (round 4): 8.5 sigma of the density of the lowest order on the left, and on the right whichever comes first
+ * of the end of the density of the top order and the decay of the inner Phi, ln(xt - y) = mu - 8.5 sigma, i.e.
+ * v = ln(e^delta - 1), delta = ln xt - mu + 8.5 sigma.  The window is then ~17 sigma wide in ln y whatever ln xt - mu is,
+ * so the node spacing scales with sigma.  (Rounds 2-3 took v = ln y - ln xt on the left -- only true for v << 0 -- and
+ * v = delta on the right: for x_t ~ 2 e^mu most of the 48 nodes then fell outside the window, and the rule was off by
+ * 2.6e-6 at sigma = 0.01, 6e-3 at 0.005.)  An empty window (vhi <= vlo): the integral is below e^-36 of M_p1 M_p2 -> 0. */
 void co_lognormal_msh_range(double mu, double sg, double lxt, int n_orders, double *vlo, double *vhi) {
-    *vlo = fmin(0.0, mu - lxt) - 8.5 * sg;
-    *vhi = fmax(0.0, lxt - mu) + 8.5 * sg;
-    const double d = (mu + (n_orders - 1) * sg * sg + 8.5 * sg) - lxt; /* upper end of the density of the top order */
-    if (d < -1e-9) *vhi = fmin(*vhi, d - log(-expm1(d)));
+    const double d_lo = (mu - 8.5 * sg) - lxt;                            /* lower end of the density (order 0) */
+    const double d_hi = (mu + (n_orders - 1) * sg * sg + 8.5 * sg) - lxt; /* upper end of the density of the top order */
+    const double delta = (lxt - mu) + 8.5 * sg;                           /* where the inner Phi has decayed */
+    *vlo = *vhi = 0.0;
+    if (!(d_lo < -1e-9) || !(delta > 1e-9)) return; /* empty */
+    *vlo = d_lo - log(-expm1(d_lo));
+    *vhi = delta > 36.0 ? delta : log(expm1(delta));
+    if (d_hi < -1e-9) *vhi = fmin(*vhi, d_hi - log(-expm1(d_hi)));
+    if (*vhi < *vlo) *vhi = *vlo;
 }
 double co_moment_source_helper_lognormal(const co_dist *dist, double p1, double p2, double x_threshold, int n_orders) {
     const double mu = dist->theta, sg = dist->k, lxt = log(x_threshold);

@@ -32,9 +32,9 @@ LN2 = math.log(2.0)
 
 CASES = [
     # the reference's own NumericalCoalStyle test configuration (test_Sources_correctness.jl:175-263)
-    dict(name="ref_test_3gamma_linear", kf=(1, [1.0]), pdists=[(1, 10.0, 10.0, 3.0), (1, 20.0, 100.0, 5.0), (1, 2.0, 500.0, 6.0)]),
-    dict(name="3gamma_hydrodynamic", kf=(2, [E_HYDRO]), pdists=[(1, 120.0, 0.02, 2.5), (1, 3.0, 4.0, 3.0), (1, 0.05, 300.0, 4.0)]),
-    dict(name="2gamma_long", kf=(3, LONG), pdists=[(1, 100.0, 0.05, 2.0), (1, 1.0, 5.0, 3.0)]),
+    dict(name="ref_test_3gamma_linear", kf=(1, [1.0]), pdists=[(1, 10.0, 10.0, 3.0), (1, 20.0, 100.0, 5.0), (1, 2.0, 500.0, 6.0)], mp=True),
+    dict(name="3gamma_hydrodynamic", kf=(2, [E_HYDRO]), pdists=[(1, 120.0, 0.02, 2.5), (1, 3.0, 4.0, 3.0), (1, 0.05, 300.0, 4.0)], mp=True),
+    dict(name="2gamma_long", kf=(3, LONG), pdists=[(1, 100.0, 0.05, 2.0), (1, 1.0, 5.0, 3.0)], mp=True),
     dict(name="1gamma_hydrodynamic", kf=(2, [E_HYDRO]), pdists=[(1, 50.0, 0.3, 1.7)], mp=True),
     # test/examples/Numerical/single_particle_exp.jl, n_particles_exp.jl (LinearKernelFunction, Exponential modes)
     dict(name="1exp_linear", kf=(1, [5e-3]), pdists=[(0, 100.0, 0.1, 1.0)]),
@@ -47,15 +47,15 @@ CASES = [
     dict(name="exp_2gamma_long", kf=(3, LONG), pdists=[(0, 200.0, 0.04, 1.0), (1, 8.0, 0.3, 2.5), (1, 0.2, 6.0, 4.0)]),
     dict(name="2gamma_constant", kf=(0, [1e-4]), pdists=[(1, 100.0, 0.1, 2.0), (1, 3.0, 3.0, 3.5)]),
     dict(name="3gamma_hydro_overlapping", kf=(2, [E_HYDRO]), pdists=[(1, 50.0, 0.5, 2.0), (1, 20.0, 1.0, 3.0), (1, 5.0, 2.5, 4.0)]),
-    dict(name="gamma_exp_long_threshold_in_rain", kf=(3, [4.0, LONG[1], LONG[2]]), pdists=[(1, 50.0, 0.3, 3.0), (0, 2.0, 5.0, 1.0)]),
+    dict(name="gamma_exp_long_threshold_in_rain", kf=(3, [4.0, LONG[1], LONG[2]]), pdists=[(1, 50.0, 0.3, 3.0), (0, 2.0, 5.0, 1.0)], mp=True),
     # test/examples/Numerical/n_particles_lognorm.jl: Lognormal(n, log(mass_scale), log(2)), LinearKernelFunction
     dict(name="1lognormal_linear", kf=(1, [5e-3]), pdists=[(3, 100.0, math.log(0.1), LN2)]),
     dict(name="2lognormal_linear", kf=(1, [5e-3]), pdists=[(3, 100.0, math.log(0.1), LN2), (3, 1.0, math.log(10.0), LN2)]),
     dict(name="3lognormal_linear", kf=(1, [5e-3]),
          pdists=[(3, 100.0, math.log(0.1), LN2), (3, 10.0, math.log(1.0), LN2), (3, 1.0, math.log(10.0), LN2)]),
     dict(name="1lognormal_hydrodynamic", kf=(2, [E_HYDRO]), pdists=[(3, 40.0, -0.5, 0.6)]),
-    dict(name="2lognormal_hydrodynamic", kf=(2, [E_HYDRO]), pdists=[(3, 40.0, -1.0, 0.5), (3, 2.0, 1.5, 0.833)]),
-    dict(name="lognormal_gamma_linear", kf=(1, [5e-3]), pdists=[(3, 80.0, -1.5, 0.7), (1, 2.0, 2.0, 3.0)]),
+    dict(name="2lognormal_hydrodynamic", kf=(2, [E_HYDRO]), pdists=[(3, 40.0, -1.0, 0.5), (3, 2.0, 1.5, 0.833)], mp=True),
+    dict(name="lognormal_gamma_linear", kf=(1, [5e-3]), pdists=[(3, 80.0, -1.5, 0.7), (1, 2.0, 2.0, 3.0)], mp=True),
     dict(name="gamma_lognormal_hydrodynamic", kf=(2, [E_HYDRO]), pdists=[(1, 60.0, 0.2, 2.0), (3, 1.5, 1.2, 0.6)]),
     dict(name="1lognormal_long", kf=(3, LONG), pdists=[(3, 30.0, -1.0, 0.7)]),
     dict(name="2lognormal_constant", kf=(0, [1e-4]), pdists=[(3, 100.0, -2.0, 0.833), (3, 3.0, 0.3, 0.833)]),
@@ -63,15 +63,15 @@ CASES = [
     dict(name="gamma_lognormal_gamma_hydro", kf=(2, [E_HYDRO]), pdists=[(1, 100.0, 0.05, 3.0), (3, 5.0, 0.5, 0.5), (1, 0.1, 80.0, 4.0)]),
     # multi-scale mixtures: a narrow or much smaller neighbour puts sharp transitions of weighting_fn inside the bulk of a
     # mode (found by random search: a fixed 48 x 8 composite rule is off by 1e-7 ... 1e-3 of scale on these)
-    dict(name="2gamma_constant_narrow_neighbour", kf=(0, [0.7]), pdists=[(1, 89.5, 0.534, 3.66), (1, 0.2, 0.01737, 9.92)]),
+    dict(name="2gamma_constant_narrow_neighbour", kf=(0, [0.7]), pdists=[(1, 89.5, 0.534, 3.66), (1, 0.2, 0.01737, 9.92)], mp=True),
     dict(name="2gamma_linear_narrow_neighbour", kf=(1, [5e-3]), pdists=[(1, 16.84, 4.809, 1.971), (1, 0.306, 0.1822, 8.599)]),
-    dict(name="3gamma_linear_scales_apart", kf=(1, [5e-3]), pdists=[(1, 0.826, 21.94, 3.676), (1, 2.777, 0.469, 1.396), (1, 0.2078, 0.01068, 8.146)]),
+    dict(name="3gamma_linear_scales_apart", kf=(1, [5e-3]), pdists=[(1, 0.826, 21.94, 3.676), (1, 2.777, 0.469, 1.396), (1, 0.2078, 0.01068, 8.146)], mp=True),
     dict(name="2gamma_constant_small_neighbour", kf=(0, [0.7]), pdists=[(1, 0.946, 0.409, 1.42), (1, 0.1088, 0.01052, 6.567)]),
     dict(name="3gamma_hydro_scales_apart", kf=(2, [0.3]), pdists=[(1, 29.7, 9.82, 0.80), (1, 0.291, 0.01738, 9.92), (1, 0.9275, 0.01466, 0.985)]),
     dict(name="3gamma_long_scales_apart", kf=(3, [0.3, 9.0, 5.0]), pdists=[(1, 21.26, 0.3454, 4.334), (1, 5.59, 24.65, 0.75), (1, 0.1831, 0.2123, 1.5)]),
-    dict(name="2gamma_hydro_small_neighbour", kf=(2, [0.3]), pdists=[(1, 5.0, 2.0, 0.75), (1, 1.0, 0.03, 4.0)]),
+    dict(name="2gamma_hydro_small_neighbour", kf=(2, [0.3]), pdists=[(1, 5.0, 2.0, 0.75), (1, 1.0, 0.03, 4.0)], mp=True),
     # a Lognormal mode that is NOT the last one under the Long kernel: its T_m is the 2-D rule with the kernel's jump inside
-    dict(name="lognormal_gamma_long", kf=(3, LONG), pdists=[(3, 80.0, -1.5, 0.7), (1, 2.0, 2.0, 3.0)]),
+    dict(name="lognormal_gamma_long", kf=(3, LONG), pdists=[(3, 80.0, -1.5, 0.7), (1, 2.0, 2.0, 3.0)], mp=True),
     dict(name="gamma_narrow_lognormal_constant", kf=(0, [0.7]), pdists=[(1, 2.02, 0.17, 1.5), (3, 79.6, -1.888, 0.15)]),
 ]
 
@@ -152,12 +152,28 @@ def mp_matrices(case):
 
 
 def mpmath_only():
-    """`--mpmath-only`: keep the adaptive values of the file, (re)compute the mpmath cross-check of the marked cases"""
+    """`--mpmath-only`: keep the adaptive values of the file, (re)compute the mpmath cross-check of the marked cases.
+    `--mpmath-case=NAME --mpmath-out=FILE`: one case, its figure written to FILE (several cases side by side on the build
+    box: minutes to an hour each); `--mpmath-merge=DIR`: the figures of DIR/*.json into the golden file."""
     path = os.path.join(ROOT, "tests", "golden", "numerical_adaptive.json")
     with open(path) as f:
         out = json.load(f)
+    merge = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--mpmath-merge=")), None)
+    if merge is not None:
+        import glob
+        for fn in sorted(glob.glob(os.path.join(merge, "*.json"))):
+            with open(fn) as f:
+                r = json.load(f)
+            rec = next(x for x in out["cases"] if x["name"] == r["name"])
+            rec["mpmath_max_rel_diff"] = r["mpmath_max_rel_diff"]
+            print(f"{r['name']}: mpmath max rel diff {r['mpmath_max_rel_diff']:.2e} ({r['seconds']:.0f} s)")
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+        return
+    one = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--mpmath-case=")), None)
+    one_out = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--mpmath-out=")), None)
     for c in CASES:
-        if not c.get("mp"):
+        if not c.get("mp") or (one is not None and c["name"] != one):
             continue
         rec = next(r for r in out["cases"] if r["name"] == c["name"])
         t0 = time.time()
@@ -166,6 +182,12 @@ def mpmath_only():
         rec["mpmath_max_rel_diff"] = float(max(diffs))
         print(f"{c['name']}: mpmath (20 digits) vs adaptive, max rel diff over Q, R, S = {max(diffs):.2e}  ({time.time() - t0:.0f} s)",
               flush=True)
+        if one_out is not None:
+            with open(one_out, "w") as f:
+                json.dump(dict(name=c["name"], mpmath_max_rel_diff=float(max(diffs)), seconds=time.time() - t0,
+                               per_matrix=[float(d) for d in diffs]), f)
+    if one is not None:
+        return
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
 
@@ -173,7 +195,7 @@ def mpmath_only():
 def main():
     from oracle import cloudy_oracle as O
 
-    if "--mpmath-only" in sys.argv:
+    if "--mpmath-only" in sys.argv or any(a.startswith("--mpmath-case=") or a.startswith("--mpmath-merge=") for a in sys.argv):
         return mpmath_only()
     with_mp = "--mpmath" in sys.argv
     out = {"_comment": "generated by oracle/numerical_adaptive.py: get_coal_ints(::NumericalCoalStyle) of Coalescence.jl:470-708 "

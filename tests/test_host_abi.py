@@ -185,6 +185,14 @@ def test_julia_shim_ccalls_match_the_header_and_drop_in_branches_exist(cloudy):
     assert re.search(r"function make_rainshaft_rhs\(coal_type::CoalescenceStyle;", src)
     assert re.search(r"function rhs\(m, p, t\)", src) and "m .= max.(m, zero(eltype(m)))" in src and "p.dz" in src
     assert "@warn" in src and "p.specialized ||" in src
+    # the stream of a device array is AMDGPU.jl's task-local one, found among the LOADED modules (not
+    # `isdefined(Main, :AMDGPU)`, false when the host loads AMDGPU.jl inside its own package); no stream -> an error
+    code = "\n".join(l for l in src.splitlines() if not l.lstrip().startswith("#"))
+    assert "Base.loaded_modules" in code and "isdefined(Main, :AMDGPU)" not in code
+    assert re.search(r"mod === nothing && error\(", code) and "return C_NULL\nend" not in code
+    # the drop-in's NumericalCoalStyle plan is the converged mode unless the host asks for the fixed rule
+    assert re.search(r"function numerical_plan\(pdists, kernel_func_normalized, norms; quad_order = 0, quad_mode = 1\)", code)
+    assert "return numerical_plan(par.pdists, par.kernel_func, par.norms)" in code
 
 
 def test_thresholds_are_normalized_flag_reproduces_the_coalescence_data_fields(cloudy):

@@ -5,6 +5,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -61,15 +62,63 @@ def test_allreduce_of_moment_sums_gloo_world2(tmp_path):
     assert p.stdout.count("ok") == 2
 
 
+def test_allreduce_of_moment_sums_gloo_world8(tmp_path):
+    """the same exchange at the world size of the driver's scaling sweep (8 ranks, gloo, CPU): contiguous parcel ranges,
+    the all-reduced sums equal to the sums over the whole batch"""
+    script = tmp_path / "worker8.py"
+    script.write_text(WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr",
+           "127.0.0.1", "--master-port", "29531", str(script)]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert p.stdout.count("ok") == 8
+
+
+FAIL_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, {root!r})
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    dist.init_process_group(backend="gloo")
+    rank = dist.get_rank()
+    # no GPU on this box: cloudy_comm_unique_id fails on rank 0.  Every rank must hear of it through the SAME broadcast and
+    # raise -- then the next collective (bench._comm_setup's all-reduced flag) matches on all ranks.
+    try:
+        pkg.Communicator.from_torch_distributed(0)
+        print("rank", rank, "unexpectedly formed a communicator")
+    except pkg.CloudyError as e:
+        assert "rank 0 could not create the RCCL unique id" in str(e), str(e)
+        import torch
+        flag = torch.tensor([0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        print("rank", rank, "raised consistently")
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+def test_unique_id_failure_on_rank0_reaches_every_rank(tmp_path, cloudy):
+    """rank 0 used to raise BEFORE the broadcast of the unique id and leave the other ranks blocked in it."""
+    if cloudy.device_count() > 0:
+        pytest.skip("needs a box without a HIP device (rank 0 must fail to create the id)")
+    script = tmp_path / "fail_worker.py"
+    script.write_text(FAIL_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", str(script)]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert p.stdout.count("raised consistently") == 2
+
+
 def test_bench_gpus_flag_rejects_mismatched_launch():
     """`--gpus N` under a launcher that started a different number of ranks is an error, not a silent 1-rank run."""
     env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
                        text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE=3" in (p.stderr + p.stdout)
-
-
-import pytest  # noqa: E402
 
 
 @pytest.mark.gpu
@@ -92,6 +141,29 @@ def test_bench_gpus_2_spawns_two_ranks(gpu_cloudy):
     assert [r["rank"] for r in out["roofline"]["per_rank"]] == [0, 1]
     assert all(r["kernel_ms"] > 0 for r in out["roofline"]["per_rank"])
     assert out["mass_rate_residual"] is not None and out["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_gpus_8_on_one_gpu_with_an_empty_jit_cache(gpu_cloudy, tmp_path):
+    """the shape of the driver's 8-GPU run on the one test GPU -- 8 ranks (gloo as the courier, all
+    sharing GPU 0) that hiprtc-compile the SAME plans at the same moment into one EMPTY cache directory (the atomic-rename
+    path of jit.hpp under 8-way contention).  One JSON line, 8 per-rank entries, the all-reduced residual."""
+    import json
+
+    cache = tmp_path / "jit_cache"
+    cache.mkdir()
+    env = dict(os.environ, CLOUDY_BENCH_BACKEND="gloo", CLOUDY_HIP_CACHE_DIR=str(cache))
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--parcels", "200000", "--steps", "3",
+                        "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 8 and out["config"]["global_parcels"] == 1_600_000 and out["scaling"] == "weak"
+    assert [r["rank"] for r in out["roofline"]["per_rank"]] == list(range(8))
+    assert all(r["kernel_ms"] > 0 for r in out["roofline"]["per_rank"])
+    assert out["mass_rate_residual"] is not None and out["value"] > 0
+    files = [f for f in os.listdir(cache) if not f.endswith(".tmp")]
+    assert files and not [f for f in os.listdir(cache) if f.endswith(".tmp")], os.listdir(cache)
 
 
 def test_comm_entry_points_without_a_gpu(cloudy):

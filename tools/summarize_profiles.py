@@ -97,3 +97,48 @@ for name, (prefix, items) in VARIANTS.items():
 latest["kernels"] = kern
 json.dump(latest, open(os.path.join(dst, "measured_latest.json"), "w"), indent=1)
 print(json.dumps(latest, indent=1))
+
+# ---- the per-kernel table of profiles/README.md, written from the files above (no hand-typed numbers) --------------------
+def kernel_table(tag):
+    """profiles/<tag>_kernel_table.md: one row per cloudy kernel of the stats pass -- calls, average / min / max duration
+    (rocprofv3 --kernel-trace --stats), and from the PMC medians of the launch with the largest grid: VALU instructions,
+    active-lane fraction, VALU issue fraction (instructions x 4 cycles / (1024 SIMDs x 2.4 GHz x average duration)), useful
+    fp64 flops as a fraction of the 78.6 TF vector peak, HBM bytes (2 x FETCH_SIZE + WRITE_SIZE) and achieved TB/s."""
+    stats_path = os.path.join(dst, f"{tag}_kernel_stats.csv")
+    if not os.path.exists(stats_path):
+        return
+    pmc = {}
+    for row in rows:
+        if row["kernel"] not in pmc or row["grid_size"] > pmc[row["kernel"]]["grid_size"]:
+            pmc[row["kernel"]] = row
+    lines = [f"<!-- generated by tools/summarize_profiles.py {tag} from {tag}_kernel_stats.csv and {tag}_pmc_per_dispatch_median.json -->",
+             "| kernel | calls | avg µs | min µs | max µs | grid (PMC launch) | VALU insts / lane | active lanes | VALU issue | fp64 peak frac | HBM MB | TB/s |",
+             "|---|---|---|---|---|---|---|---|---|---|---|---|"]
+    for r in csv.DictReader(open(stats_path)):
+        name = r["Name"]
+        if "cloudy" not in name:
+            continue
+        short = name.split("cloudy::")[1].split("(")[0] if "cloudy::" in name else name.split("(")[0]
+        avg = float(r["AverageNs"]) * 1e-3
+        cells = [f"`{short}`", r["Calls"], f"{avg:.2f}", f"{float(r['MinNs']) * 1e-3:.2f}", f"{float(r['MaxNs']) * 1e-3:.2f}"]
+        p = pmc.get(short)
+        if p and "SQ_INSTS_VALU" in p and p.get("SQ_ACTIVE_INST_VALU"):
+            util = p["SQ_THREAD_CYCLES_VALU"] / (p["SQ_ACTIVE_INST_VALU"] * 64.0)
+            flops = (2 * p["SQ_INSTS_VALU_FMA_F64"] + p["SQ_INSTS_VALU_MUL_F64"] + p["SQ_INSTS_VALU_ADD_F64"]) * 64.0 * util
+            issue = p["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.4e9 * avg * 1e-6)
+            cells += [str(p["grid_size"]), f"{p['SQ_INSTS_VALU'] * 64.0 / p['grid_size']:.0f}", f"{util:.2f}", f"{issue:.2f}",
+                      f"{flops / (avg * 1e-6) / 78.6e12:.2f}"]
+        else:
+            cells += [str(p["grid_size"]) if p else "", "", "", "", ""]
+        if p and "FETCH_SIZE" in p and "WRITE_SIZE" in p:
+            b = 2 * p["FETCH_SIZE"] * 1024 + p["WRITE_SIZE"] * 1024
+            cells += [f"{b / 1e6:.1f}", f"{b / (avg * 1e-6) / 1e12:.2f}"]
+        else:
+            cells += ["", ""]
+        lines.append("| " + " | ".join(cells) + " |")
+    with open(os.path.join(dst, f"{tag}_kernel_table.md"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+kernel_table(tag)
