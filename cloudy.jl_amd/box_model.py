@@ -97,11 +97,14 @@ def solve_ssprk33(par, u, dt, n_steps, out=None, stream=None, coal_type=None):
     return o
 
 
-def solve_tsit5(par, u, dt, n_steps, out=None, stream=None):
+def solve_tsit5(par, u, dt, n_steps, out=None, stream=None, coal_type=None):
     """solve(ODEProblem(rhs, u, tspan, par), Tsit5(), dt = dt, adaptive = false) for n_steps fixed steps, on the device
-    (cloudy_tsit5_steps): BASELINE configs[0] names Tsit5; no reference driver uses it (they call SSPRK33).  AnalyticalCoalStyle
-    plans with thresholds Inf or fixed, fp64 planes.  `u` is advanced in place unless `out` is given."""
-    plan = _plan_for(par, dtype_code(u))
+    (cloudy_tsit5_steps): BASELINE configs[0] names Tsit5; no reference driver uses it (they call SSPRK33).  Every plan
+    solve_ssprk33 serves (thresholds Inf / fixed / moving, NumericalCoalStyle through `coal_type`), fp64 or float planes.
+    `u` is advanced in place unless `out` is given."""
+    if coal_type is not None and not isinstance(coal_type, (AnalyticalCoalStyle, NumericalCoalStyle)):
+        raise ValueError("Invalid coal style!")
+    plan = _numerical_plan_for(par, dtype_code(u)) if isinstance(coal_type, NumericalCoalStyle) else _plan_for(par, dtype_code(u))
     uptr, planes, n, ld = as_device(u)
     o = out if out is not None else u
     optr, oplanes, on, old = as_device(o)

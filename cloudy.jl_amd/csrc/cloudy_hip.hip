@@ -32,8 +32,8 @@ struct cloudy_plan {
     JitKernels jit;
     std::string jit_log;   // why not, when jit_on is false
     // thresholded plans compile their fused integrator on the first cloudy_ssprk33_steps call
-    mutable std::once_flag int_once, rs_once, rsint_once;
-    mutable hipFunction_t int_ssprk33 = nullptr, rs_coal = nullptr, rs_int = nullptr;
+    mutable std::once_flag int_once, rs_once, rsint_once, tsit5_once;
+    mutable hipFunction_t int_ssprk33 = nullptr, rs_coal = nullptr, rs_int = nullptr, int_tsit5 = nullptr;
     mutable std::string int_log;
 };
 
@@ -122,6 +122,18 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
         return hipModuleLaunchKernel(plan->rs_int, (unsigned)((n_columns + cpb - 1) / cpb), 1, 1, kRainshaftBlock, 1, 1, 0, r.stream,
                                      args, nullptr);
     }
+    if (r.op == OP_TSIT5) {
+        double dt = r.dt;
+        int n_steps = r.n_steps;
+        if (h.coal_style == CLOUDY_NUMERICAL_COAL) {
+            const unsigned qb = h.q.mode == QUAD_CONVERGED ? (unsigned)kBlock : (unsigned)quad_block(h.q.nq);
+            void *args[] = {&n, &ld, &in, &out, &dt, &n_steps};
+            return hipModuleLaunchKernel(plan->int_tsit5, (unsigned)((n + qb - 1) / qb), 1, 1, qb, 1, 1, 0, r.stream, args, nullptr);
+        }
+        const double *nodes = h.nodes_dev;
+        void *args[] = {&nodes, &n, &ld, &in, &out, &dt, &n_steps};
+        return hipModuleLaunchKernel(plan->int_tsit5, g1, 1, 1, kBlock, 1, 1, 0, r.stream, args, nullptr);
+    }
     if (h.coal_style == CLOUDY_NUMERICAL_COAL) {
         const unsigned qb = h.q.mode == QUAD_CONVERGED ? (unsigned)kBlock : (unsigned)quad_block(h.q.nq);
         if (r.op == OP_SSPRK33) {
@@ -182,7 +194,14 @@ int run(const cloudy_plan *plan, const LaunchReq &r) {
     DeviceGuard guard(plan->h.device);
     if (guard.err != hipSuccess) return fail_hip(guard.err, "selecting the plan's device");
     bool use_jit = plan->jit_on && r.input_kind == IN_MOMENTS && r.physical_out &&
-                   (r.op == OP_COAL || (r.op == OP_SSPRK33 && !r.rainshaft) || r.op == OP_RAINSHAFT_SSPRK33);
+                   (r.op == OP_COAL || (r.op == OP_SSPRK33 && !r.rainshaft) || r.op == OP_RAINSHAFT_SSPRK33 || r.op == OP_TSIT5);
+    if (use_jit && r.op == OP_TSIT5) {
+        std::call_once(plan->tsit5_once, [&] { (void)jit_get_tsit5(plan->h, plan->int_tsit5, plan->int_log); });
+        use_jit = plan->int_tsit5 != nullptr;  // otherwise the ahead-of-time integrator (tensor plans)
+    }
+    if (!use_jit && r.op == OP_TSIT5 && plan->h.coal_style == CLOUDY_NUMERICAL_COAL)
+        return fail(CLOUDY_EUNSUPPORTED, "cloudy_tsit5_steps of a NumericalCoalStyle plan runs the kernel compiled for the plan "
+                                         "(hiprtc); plan-time compilation is off or failed: %s", plan->int_log.c_str());
     if (use_jit && r.op == OP_RAINSHAFT_SSPRK33) {
         std::call_once(plan->rsint_once,
                        [&] { (void)jit_get_rainshaft_integrator(plan->h, plan->rs_int, plan->int_log); });
@@ -588,6 +607,7 @@ int cloudy_jit_selfcheck(const cloudy_plan_desc *d, const char *arch) {
     if (ok && !numerical) ok = jit_compile(jit_source(p->h, 2), a, false, code, log);  // rainshaft cell body
     if (ok && !numerical && p->h.n_vel > 0 && p->h.mode != MODE_MOVING)
         ok = jit_compile(jit_source(p->h, 3), a, true, code, log);                     // fused column integrator
+    if (ok && p->h.dtype != CLOUDY_F32_FAST) ok = jit_compile(jit_source(p->h, 4), a, true, code, log);  // cloudy_tsit5_steps
     delete p;
     if (!ok) return fail(CLOUDY_EUNSUPPORTED, "plan-time compilation failed: %.440s", log.c_str());
     return CLOUDY_OK;
@@ -706,9 +726,9 @@ int cloudy_tsit5_steps(const cloudy_plan *plan, size_t n, size_t ld, const void 
     int rc = check_batch(plan, n, ld, u_in_dev, u_out_dev);
     if (rc) return rc;
     if (n_steps < 0 || !(dt == dt)) return fail(CLOUDY_EINVAL, "n_steps must be >= 0 and dt not NaN");
-    if (plan->h.coal_style != CLOUDY_ANALYTICAL_COAL || plan->h.mode == MODE_MOVING || plan->h.dtype != CLOUDY_F64)
-        return fail(CLOUDY_EUNSUPPORTED, "cloudy_tsit5_steps serves fp64 AnalyticalCoalStyle plans with thresholds Inf or "
-                                         "fixed; use cloudy_ssprk33_steps (the integrator of every reference driver)");
+    if (plan->h.dtype == CLOUDY_F32_FAST)
+        return fail(CLOUDY_EUNSUPPORTED, "cloudy_tsit5_steps serves CLOUDY_F64 and CLOUDY_F32 plans (the fused integrators keep "
+                                         "the state in fp64 registers; CLOUDY_F32_FAST is the single-pass operator's mode)");
     LaunchReq r{OP_TSIT5, IN_MOMENTS, 1, 0, n, ld, u_in_dev, u_out_dev, nullptr, (hipStream_t)stream};
     r.dt = dt;
     r.n_steps = n_steps;

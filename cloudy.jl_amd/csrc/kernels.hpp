@@ -546,6 +546,7 @@ __device__ __forceinline__ void msh_grid_f32(const Grid &grid, double xt, double
 // values of Phi.  Every lane does identical work (no data-dependent trip counts).  theta = mu, k = sigma.
 // Output convention of msh_grid: WITHOUT the factors n and M_p2 the caller applies: msh[p1][p2] = Prob * M_p1 / n.
 constexpr int kLnNodes = 48;
+constexpr double kLnSigmaFloor = 1e-8;  // below: the point-mass limit (msh_lognormal)
 __device__ __forceinline__ double norm_cdf(double z) { return 0.5 * erfc(-z * 0.70710678118654752440); }
 __device__ __forceinline__ double softplus_pos(double x) {  // ln(1 + e^x)
     return x > 0.0 ? x + log1p(exp_fin(-x)) : log1p(exp_fin(x));
@@ -596,6 +597,14 @@ __device__ __forceinline__ void msh_lognormal(double xt, double mu, double sg, d
             G *= ratio;
             ratio *= er;
         }
+    }
+    // A closure clamped to sigma = eps (moments with M0 M2 < M1^2: Julia's sqrt throws, a batch cannot) is a point mass
+    // at e^mu: Prob(X + Y < xt) = [2 e^mu < xt].  Below kLnSigmaFloor the rule's own arithmetic (ln y - mu over sigma)
+    // is rounding noise, so the limit is taken instead.
+    if (sg < kLnSigmaFloor) {
+        const double step = (mu + 0.6931471805599453 < lxt) ? 1.0 : 0.0;
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = step;
     }
     // M_p1 / n = exp(p1 mu + p1^2 sigma^2 / 2), by the ratio recurrence of moment_row
     double mp = 1.0, rr = exp(mu + 0.5 * s2);
@@ -1329,60 +1338,43 @@ constexpr double a71 = 0.09646076681806523, a72 = 0.01, a73 = 0.4798896504144996
                  a75 = -3.290069515436081, a76 = 2.324710524099774;
 }  // namespace tsit5
 
-template <int N, int P, int MODE, typename TIO, int BS = kBlock>
-__device__ __forceinline__ void tsit5_body(const KArgs<N, P> *__restrict__ Ag, const double *__restrict__ nodes, size_t n,
-                                           size_t ld, const TIO *u_in, TIO *u_out, double dt, int n_steps) {
+// The tableau itself, for any right-hand side: rhs(state, derivative) on [N][3] register arrays.  u is advanced in place by
+// n_steps steps of size dt; 6 evaluations per step (FSAL: the 7th stage derivative is the next step's first).
+template <int N, class RHS>
+__device__ __forceinline__ void tsit5_advance(double (&u)[N][3], double dt, int n_steps, RHS &&rhs) {
     using namespace tsit5;
-    const KArgs<N, P> &A = *Ag;
-    const size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
-    const bool valid = i < n;
-    if (MODE == MODE_ALLINF && !valid) return;
-    double u[N][3], k1[N][3], k2[N][3], k3[N][3], k4[N][3], k5[N][3], k6[N][3], w[N][3];
-#pragma unroll
-    for (int m = 0; m < N; ++m) {
-        const int off = A.off[m];
-        u[m][0] = valid ? (double)u_in[(size_t)(off + 0) * ld + i] : 0.0;
-        u[m][1] = valid ? (double)u_in[(size_t)(off + 1) * ld + i] : 0.0;
-        u[m][2] = (valid && A.np[m] == 3) ? (double)u_in[(size_t)(off + 2) * ld + i] : 0.0;
-    }
-    // the plan constants through an opaque zero offset per RHS evaluation (see ssprk33_body)
-#define CLOUDY_TSIT5_RHS(state, deriv)                                   \
-    do {                                                                 \
-        size_t oz = 0;                                                   \
-        asm volatile("" : "+s"(oz));                                     \
-        rhs_physical<N, P, MODE, false, BS>(*(Ag + oz), nodes, valid, state, deriv); \
-    } while (0)
-    if (n_steps > 0) CLOUDY_TSIT5_RHS(u, k1);
+    double k1[N][3], k2[N][3], k3[N][3], k4[N][3], k5[N][3], k6[N][3], w[N][3];
+    if (n_steps > 0) rhs(u, k1);
 #pragma unroll 1
     for (int step = 0; step < n_steps; ++step) {
 #pragma unroll
         for (int m = 0; m < N; ++m)
 #pragma unroll
             for (int q = 0; q < 3; ++q) w[m][q] = fma(dt * a21, k1[m][q], u[m][q]);
-        CLOUDY_TSIT5_RHS(w, k2);
+        rhs(w, k2);
 #pragma unroll
         for (int m = 0; m < N; ++m)
 #pragma unroll
             for (int q = 0; q < 3; ++q) w[m][q] = fma(dt, fma(a31, k1[m][q], a32 * k2[m][q]), u[m][q]);
-        CLOUDY_TSIT5_RHS(w, k3);
+        rhs(w, k3);
 #pragma unroll
         for (int m = 0; m < N; ++m)
 #pragma unroll
             for (int q = 0; q < 3; ++q) w[m][q] = fma(dt, fma(a41, k1[m][q], fma(a42, k2[m][q], a43 * k3[m][q])), u[m][q]);
-        CLOUDY_TSIT5_RHS(w, k4);
+        rhs(w, k4);
 #pragma unroll
         for (int m = 0; m < N; ++m)
 #pragma unroll
             for (int q = 0; q < 3; ++q)
                 w[m][q] = fma(dt, fma(a51, k1[m][q], fma(a52, k2[m][q], fma(a53, k3[m][q], a54 * k4[m][q]))), u[m][q]);
-        CLOUDY_TSIT5_RHS(w, k5);
+        rhs(w, k5);
 #pragma unroll
         for (int m = 0; m < N; ++m)
 #pragma unroll
             for (int q = 0; q < 3; ++q)
                 w[m][q] = fma(dt, fma(a61, k1[m][q], fma(a62, k2[m][q], fma(a63, k3[m][q], fma(a64, k4[m][q], a65 * k5[m][q])))),
                               u[m][q]);
-        CLOUDY_TSIT5_RHS(w, k6);
+        rhs(w, k6);
 #pragma unroll
         for (int m = 0; m < N; ++m)
 #pragma unroll
@@ -1390,13 +1382,50 @@ __device__ __forceinline__ void tsit5_body(const KArgs<N, P> *__restrict__ Ag, c
                 u[m][q] = fma(dt, fma(a71, k1[m][q], fma(a72, k2[m][q], fma(a73, k3[m][q], fma(a74, k4[m][q],
                                                                                             fma(a75, k5[m][q], a76 * k6[m][q]))))),
                               u[m][q]);
-        if (step + 1 < n_steps) CLOUDY_TSIT5_RHS(u, k1);  // FSAL: the 7th stage derivative is the next step's first
+        if (step + 1 < n_steps) rhs(u, k1);  // FSAL
     }
-#undef CLOUDY_TSIT5_RHS
+}
+
+// Every plan family the SSPRK33 integrator serves (round 4): thresholds Inf (state kept in NORMALISED units between load
+// and store, as ssprk33_body: the tableau is linear in the state), fixed or MOVING (the workgroup re-ranks its parcels in
+// every evaluation), fp64 or float planes; SPEC: compiled for the plan (jit.hpp part 4), no loads of plan constants.
+template <int N, int P, int MODE, typename TIO, bool SPEC = false, int BS = kBlock>
+__device__ __forceinline__ void tsit5_body(const KArgs<N, P> *__restrict__ Ag, const double *__restrict__ nodes, size_t n,
+                                           size_t ld, const TIO *u_in, TIO *u_out, double dt, int n_steps) {
+    const KArgs<N, P> &A = *Ag;
+    const size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
+    const bool valid = i < n;
+    if (MODE == MODE_ALLINF && !valid) return;
+    constexpr bool kNormalisedState = MODE == MODE_ALLINF;  // see rhs_normalised
+    double u[N][3];
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        const int off = A.off[m];
+        u[m][0] = valid ? (double)u_in[(size_t)(off + 0) * ld + i] : 0.0;
+        u[m][1] = valid ? (double)u_in[(size_t)(off + 1) * ld + i] : 0.0;
+        u[m][2] = (valid && A.np[m] == 3) ? (double)u_in[(size_t)(off + 2) * ld + i] : 0.0;
+        if (kNormalisedState) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) u[m][q] = div_by_const(u[m][q], A.norm[3 * m + q], A.inv_norm[3 * m + q]);
+        }
+    }
+    // the plan constants through an opaque zero offset per RHS evaluation (see ssprk33_body); none when compiled for the plan
+    tsit5_advance<N>(u, dt, n_steps, [&](const double (&state)[N][3], double (&deriv)[N][3]) {
+        size_t oz = 0;
+        if (!SPEC) asm volatile("" : "+s"(oz));
+        if (kNormalisedState)
+            rhs_normalised<N, P, SPEC>(*(Ag + oz), state, deriv);
+        else
+            rhs_physical<N, P, MODE, SPEC, BS>(*(Ag + oz), nodes, valid, state, deriv);
+    });
     if (!valid) return;
 #pragma unroll
     for (int m = 0; m < N; ++m) {
         const int off = A.off[m];
+        if (kNormalisedState) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) u[m][q] *= A.norm[3 * m + q];
+        }
         u_out[(size_t)(off + 0) * ld + i] = (TIO)u[m][0];
         u_out[(size_t)(off + 1) * ld + i] = (TIO)u[m][1];
         if (A.np[m] == 3) u_out[(size_t)(off + 2) * ld + i] = (TIO)u[m][2];
@@ -1407,7 +1436,7 @@ template <int N, int P, int MODE, typename TIO, int BS = kBlock>
 __global__ void __launch_bounds__(BS)
     tsit5_kernel(const KArgs<N, P> *__restrict__ Ag, const double *__restrict__ nodes, size_t n, size_t ld, const TIO *u_in,
                  TIO *u_out, double dt, int n_steps) {
-    tsit5_body<N, P, MODE, TIO, BS>(Ag, nodes, n, ld, u_in, u_out, dt, n_steps);
+    tsit5_body<N, P, MODE, TIO, false, BS>(Ag, nodes, n, ld, u_in, u_out, dt, n_steps);
 }
 
 // ---- diagnostics / the callers either side of the operator ---------------------------------------

@@ -35,22 +35,19 @@ hipError_t launch_int_io(const HostPlan &h, const LaunchReq &r) {
                                h.nodes_dev, r.n, r.ld, in, out, r.dt, r.n_steps);
         break;
     }
-    case OP_TSIT5: {  // cloudy_tsit5_steps: fp64 planes, thresholds Inf or fixed
+    case OP_TSIT5: {  // cloudy_tsit5_steps: thresholds Inf, fixed or moving; fp64 or float planes
         if (!h.kargs_dev) return hipErrorNotInitialized;
-        if constexpr (sizeof(TIO) == 8) {
-            const KArgs<N, P> *Ad = static_cast<const KArgs<N, P> *>(h.kargs_dev);
-            const unsigned g = grid_for(r.n, heavy);
-            if (h.mode == MODE_ALLINF)
-                hipLaunchKernelGGL((tsit5_kernel<N, P, MODE_ALLINF, TIO>), dim3(g), dim3(kBlock), 0, r.stream, Ad, h.nodes_dev,
-                                   r.n, r.ld, in, out, r.dt, r.n_steps);
-            else if (h.mode == MODE_FIXED)
-                hipLaunchKernelGGL((tsit5_kernel<N, P, MODE_FIXED, TIO>), dim3(g), dim3(kBlock), 0, r.stream, Ad, h.nodes_dev,
-                                   r.n, r.ld, in, out, r.dt, r.n_steps);
-            else
-                return hipErrorInvalidValue;
-        } else {
-            return hipErrorInvalidValue;
-        }
+        const KArgs<N, P> *Ad = static_cast<const KArgs<N, P> *>(h.kargs_dev);
+        const unsigned g = grid_for(r.n, heavy);
+        if (h.mode == MODE_ALLINF)
+            hipLaunchKernelGGL((tsit5_kernel<N, P, MODE_ALLINF, TIO>), dim3(g), dim3(kBlock), 0, r.stream, Ad, h.nodes_dev,
+                               r.n, r.ld, in, out, r.dt, r.n_steps);
+        else if (h.mode == MODE_FIXED)
+            hipLaunchKernelGGL((tsit5_kernel<N, P, MODE_FIXED, TIO>), dim3(g), dim3(kBlock), 0, r.stream, Ad, h.nodes_dev,
+                               r.n, r.ld, in, out, r.dt, r.n_steps);
+        else
+            hipLaunchKernelGGL((tsit5_kernel<N, P, MODE_MOVING, TIO>), dim3(g), dim3(kBlock), 0, r.stream, Ad, h.nodes_dev,
+                               r.n, r.ld, in, out, r.dt, r.n_steps);
         break;
     }
     case OP_RAINSHAFT_SSPRK33: {

@@ -291,6 +291,52 @@ __device__ __forceinline__ void quad_ssprk33_body(const KArgs<N, 1> &A, const QA
     }
 }
 
+// cloudy_tsit5_steps of a NumericalCoalStyle plan (round 4): the tableau of tsit5_advance (kernels.hpp) around the same
+// right-hand side as quad_ssprk33_body.  Plan-time compiled only (jit.hpp part 4).
+template <int N, int KIND, int NQ, typename TIO, bool CONV = false>
+__device__ __forceinline__ void quad_tsit5_body(const KArgs<N, 1> &A, const QArgs &Q, const double *__restrict__ tab,
+                                                size_t n, size_t ld, const TIO *u_in, TIO *u_out, double dt, int n_steps) {
+    constexpr int QB = NQ ? quad_block(NQ) : kBlock;
+    const size_t i = (size_t)blockIdx.x * QB + threadIdx.x;
+    if (i >= n) return;
+    double u[N][3];
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        const int off = A.off[m];
+        u[m][0] = (double)u_in[(size_t)(off + 0) * ld + i];
+        u[m][1] = (double)u_in[(size_t)(off + 1) * ld + i];
+        u[m][2] = (A.np[m] == 3) ? (double)u_in[(size_t)(off + 2) * ld + i] : 0.0;
+    }
+    const double ksc = CONV ? 1.0 : kf_scale<KIND>(Q);
+    tsit5_advance<N>(u, dt, n_steps, [&](const double (&state)[N][3], double (&f)[N][3]) {
+        double nn[N], th[N], kk[N], acc[N][3];
+#pragma unroll
+        for (int m = 0; m < N; ++m) {  // mom ./ mom_norms, update_dist_from_moments (as load_parcel)
+            const double m0 = div_by_const(state[m][0], A.norm[3 * m + 0], A.inv_norm[3 * m + 0]);
+            const double m1 = div_by_const(state[m][1], A.norm[3 * m + 1], A.inv_norm[3 * m + 1]);
+            const double m2 = div_by_const(state[m][2], A.norm[3 * m + 2], A.inv_norm[3 * m + 2]);
+            invert_closure(A.dist_type[m], m0, m1, m2, A.kmin, A.kmax, nn[m], th[m], kk[m]);
+        }
+        if (CONV)
+            conv_coal_ints<N, KIND>(A, Q, tab, nn, th, kk, acc);
+        else
+            quad_coal_ints<N, KIND, NQ>(A, Q, tab, nn, th, kk, acc);
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+            f[m][0] = acc[m][0] * (ksc * A.out_scale[3 * m + 0]);
+            f[m][1] = acc[m][1] * (ksc * A.out_scale[3 * m + 1]);
+            f[m][2] = (A.np[m] == 3) ? acc[m][2] * (ksc * A.out_scale[3 * m + 2]) : 0.0;
+        }
+    });
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        const int off = A.off[m];
+        u_out[(size_t)(off + 0) * ld + i] = (TIO)u[m][0];
+        u_out[(size_t)(off + 1) * ld + i] = (TIO)u[m][1];
+        if (A.np[m] == 3) u_out[(size_t)(off + 2) * ld + i] = (TIO)u[m][2];
+    }
+}
+
 // ahead-of-time instance: run-time point count, the rule arrays in scratch (the plan-time compiled kernel of jit.hpp
 // has them in registers)
 template <int N, int KIND, typename TIO, bool CONV = false>

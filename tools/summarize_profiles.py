@@ -72,6 +72,7 @@ VARIANTS = {   # bench variant -> (kernel name prefix, items per launch in the b
     "cfg3a_fused_ssprk33": ("cloudy_jit_ssprk33_n2p3_f64", 10_000_000),
     "rainshaft_ssprk33_columns": (("cloudy_jit_rainshaft_ssprk33_n2p3_f64", "rainshaft_ssprk33_kernel<2, 3, 1, double>"), 10_000_000),
     "cfg4q_converged": ("cloudy_jit_quad_n3c8_hydro_f64", 12_500_000),
+    "cfg0_tsit5": ("cloudy_jit_tsit5_n1p2_f64", 10_000_000),
     "cfg3b_f32_fast": ("cloudy_jit_sorted_n2p3_f32fast", 10_000_000),
     "cfg5_f32_planes": ("cloudy_jit_sorted_rs_n2p3_f32", 12_500_000),
     "cfg5_f32_fast": ("cloudy_jit_sorted_rs_n2p3_f32fast", 12_500_000),
