@@ -931,6 +931,22 @@ def main():
             del mv, dmv
 
     if more_variants:
+        # CLOUDY_F64_RELAXED (opt-in): fp64 planes and arithmetic, the incomplete-gamma series / continued fraction of the
+        # threshold kernels stopped at 1e-11 (<= 1e-9 of scale against the oracle: tests/test_gpu_parity.py)
+        for vname, vn in (("cfg3b", n_local), ("cfg4", 12_500_000)):
+            wlv = make_workload(vname, vn, seed=SEED + 1000 * rank)
+            planv = wlv["coal_data"].plan(wlv["dist_types"], dtype=3)
+            mv = pkg.DeviceArray.from_numpy(wlv["mom"])
+            dmv = pkg.DeviceArray.zeros(planv.nmom, vn)
+            msv = _event_ms(pkg, planv, mv, dmv, 3)
+            variants[vname + "_f64_relaxed"] = {
+                "workload": f"{vname} with CLOUDY_F64_RELAXED (series / continued fraction of P(a, z) cut at 1e-11)",
+                "value": vn * world / (msv * 1e-3), "unit": "parcel-RHS/s", "kernel_ms": msv,
+                "speedup_vs_default_dtype": (variants[vname]["kernel_ms"] / msv) if vname in variants and "kernel_ms" in variants[vname] else None,
+            }
+            del mv, dmv
+
+    if more_variants:
         # BASELINE configs[4]: Long's kernel pieces (cfg3b thresholds) + sedimentation flux, float planes
         n5 = 12_500_000
         wl5 = make_workload("cfg3b", n5, seed=SEED + 1000 * rank)

@@ -169,6 +169,7 @@ _numerical_plans = {}
 
 
 QUAD_FIXED, QUAD_CONVERGED = 0, 1   # cloudy_plan_desc.quad_mode
+F64, F32, F32_FAST, F64_RELAXED = 0, 1, 2, 3   # cloudy_plan_desc.dtype (F64_RELAXED: fp64 planes, incomplete-gamma series cut at 1e-11)
 
 
 def numerical_plan(dist_types, kernel_func, norms, quad_order=0, k_range=(EPS, 10.0), dtype=0, specialize=0,

@@ -20,7 +20,8 @@ from .ParticleDistributions import (ExponentialPrimitiveParticleDistribution, Ga
                                     LognormalPrimitiveParticleDistribution, MonodispersePrimitiveParticleDistribution,
                                     compute_thresholds, get_moments, get_standard_N_q, nparams, pack_params, update_dist_from_moments)
 from .Coalescence import (CoalescenceData, NumericalPlan, Plan, get_coal_ints, get_finite_2d_integrals,
-                          kernel_func_code, numerical_plan, QUAD_CONVERGED, QUAD_FIXED)
+                          kernel_func_code, numerical_plan, QUAD_CONVERGED, QUAD_FIXED, F64, F32, F32_FAST,
+                          F64_RELAXED)
 from .Sedimentation import (get_sedimentation_flux, make_rainshaft_rhs, rainshaft_sources, rhs_condensation,
                             solve_rainshaft_ssprk33)
 from .box_model import ODEParameters, make_box_model_rhs, rhs_coal, solve_ssprk33, solve_tsit5

@@ -285,7 +285,7 @@ int build_host_plan(const cloudy_plan_desc *d, cloudy_plan **out, std::vector<do
                 return fail(CLOUDY_EINVAL, "no method normed_density_func for a Monodisperse distribution "
                                            "(weighting_fn, Coalescence.jl:624-642)");
     }
-    if (d->dtype != CLOUDY_F64 && d->dtype != CLOUDY_F32 && d->dtype != CLOUDY_F32_FAST)
+    if (d->dtype != CLOUDY_F64 && d->dtype != CLOUDY_F32 && d->dtype != CLOUDY_F32_FAST && d->dtype != CLOUDY_F64_RELAXED)
         return fail(CLOUDY_EINVAL, "bad dtype");
     if (!(d->norms[0] > 0) || !(d->norms[1] > 0))
         return fail(CLOUDY_EINVAL, "norms must be positive!");  // helper_functions.jl:44-46
@@ -300,7 +300,8 @@ int build_host_plan(const cloudy_plan_desc *d, cloudy_plan **out, std::vector<do
     HostPlan &h = p->h;
     h.N = N;
     h.P = P;
-    h.dtype = d->dtype;
+    h.relaxed = d->dtype == CLOUDY_F64_RELAXED;
+    h.dtype = h.relaxed ? (int)CLOUDY_F64 : d->dtype;
     h.threshold_style = d->threshold_style;
     h.nbpl = d->n_bins_per_log_unit;
     h.kmin = d->k_range[0];

@@ -17,7 +17,8 @@ struct HostPlan {
     int dist_type[CLOUDY_MAX_MODES] = {0}, np[CLOUDY_MAX_MODES] = {0}, off[CLOUDY_MAX_MODES] = {0};
     int finite[CLOUDY_MAX_MODES] = {0}, node_off[CLOUDY_MAX_MODES] = {0}, n_bins[CLOUDY_MAX_MODES] = {0};
     int n_2d[CLOUDY_MAX_MODES] = {0};
-    int n_mom_max = 0, threshold_style = 0, nbpl = 15, mode = 0, dtype = 0;
+    int n_mom_max = 0, threshold_style = 0, nbpl = 15, mode = 0, dtype = 0;  // dtype: the PLANE type (F64 / F32 / F32_FAST)
+    bool relaxed = false;  // desc.dtype == CLOUDY_F64_RELAXED: fp64 planes, series / continued fraction stopped at 1e-11
     double thr[CLOUDY_MAX_MODES] = {0};                 // Coalescence.jl:78-84
     double mom_norm[CLOUDY_MAX_MODES][3] = {{0}};       // helper_functions.jl:40-53, per (mode, order)
     double norms[2] = {1, 1};

@@ -699,6 +699,41 @@ def test_tsit5_serves_every_plan_family_ssprk33_serves(gpu_cloudy, oracle):
     assert (np.abs(g3 - want3)[:, ok3] / np.maximum(np.abs(want3[:, ok3]) + np.abs(wl3["mom"][:, ok3]), 1e-300)).max() < 3e-7
 
 
+def test_f64_relaxed_dtype_error_report(gpu_cloudy, oracle):
+    """CLOUDY_F64_RELAXED (opt-in) stops the power series / continued fraction of the incomplete gamma
+    function at 1e-11 instead of 1e-17 / 1e-16 in the plan-time compiled threshold kernels.  Its error against the fp64
+    oracle must stay <= 1e-9 of scale (an order inside north_star's 1e-8 for the Simpson path); reported per workload, and
+    the default dtype beside it.  Plans without a threshold compute exactly as CLOUDY_F64."""
+    cloudy = gpu_cloudy
+    L = cloudy.lib()
+    for name in ("cfg3b", "cfg4", "moving4"):
+        n = 20000
+        wl = bench.make_workload(name, n, seed=23)
+        want, scale = oracle.rhs_coal_batch(bench.oracle_params(name), wl["mom"], with_scale=True)
+        m = dev(cloudy, wl["mom"])
+        errs = {}
+        for dt_code in (cloudy.F64, cloudy.F64_RELAXED):
+            plan = wl["coal_data"].plan(wl["dist_types"], dtype=dt_code)
+            assert plan.specialized
+            dm = cloudy.DeviceArray.zeros(*wl["mom"].shape)
+            cloudy._lib.check(L.cloudy_coal_rhs(plan.handle, n, n, m.ptr, dm.ptr, None))
+            got = dm.to_numpy()
+            ok = np.isfinite(want) & (scale > 0)
+            assert np.array_equal(np.isfinite(got), np.isfinite(want))
+            errs[dt_code] = float((np.abs(got - want)[ok] / scale[ok]).max())
+        print(f"{name}: max |hip - oracle| / scale: CLOUDY_F64 {errs[cloudy.F64]:.1e}, CLOUDY_F64_RELAXED {errs[cloudy.F64_RELAXED]:.1e}")
+        assert errs[cloudy.F64] < 1e-12 and errs[cloudy.F64_RELAXED] < 1e-9
+    wl = bench.make_workload("cfg3a", 4096, seed=2)
+    m = dev(cloudy, wl["mom"])
+    outs = []
+    for dt_code in (cloudy.F64, cloudy.F64_RELAXED):
+        plan = wl["coal_data"].plan(wl["dist_types"], dtype=dt_code)
+        dm = cloudy.DeviceArray.zeros(*wl["mom"].shape)
+        cloudy._lib.check(L.cloudy_coal_rhs(plan.handle, 4096, 4096, m.ptr, dm.ptr, None))
+        outs.append(dm.to_numpy())
+    assert np.array_equal(outs[0], outs[1], equal_nan=True)
+
+
 @pytest.mark.parametrize("name,tol", [("cfg3a", TOL_POLY), ("cfg3b", TOL_QUAD)])
 def test_fused_ssprk33_batch_vs_oracle_stepping(gpu_cloudy, oracle, name, tol):
     """box_gamma_mixture_long.jl:37-46 pattern on a batch of different boxes, 4 steps.  The synthetic parcels span
