@@ -887,6 +887,16 @@ def main():
             "hbm_GBs": 2 * nmom * 4 * n_local / (ms32 * 1e-3) / 1e9,
             "roofline": _hbm_roofline("cloudy_jit_allinf2_n2p3_f32", 2 * nmom * 4 * n_local, ms32, measured, "cfg3a_f32_planes"),
         }
+        # CLOUDY_F32_FAST on the headline plan: float planes AND packed single-precision arithmetic (csrc/allinf_f32.hpp)
+        planp = wl["coal_data"].plan(wl["dist_types"], dtype=2)
+        msp = _event_ms(pkg, planp, m32, dm32, args.steps)
+        variants["cfg3a_f32_fast_packed"] = {
+            "workload": "cfg3a with CLOUDY_F32_FAST: float planes and packed single-precision arithmetic (v_pk_fma_f32, four "
+                        "parcels per lane); error vs the fp64 oracle reported in tests/test_gpu_parity.py",
+            "value": n_local * world / (msp * 1e-3), "unit": "parcel-RHS/s", "kernel_ms": msp,
+            "hbm_GBs": 2 * nmom * 4 * n_local / (msp * 1e-3) / 1e9,
+            "roofline": _hbm_roofline("cloudy_jit_allinf4_n2p3_f32fast", 2 * nmom * 4 * n_local, msp, measured, "cfg3a_f32_fast_packed"),
+        }
         # CLOUDY_F32_FAST on the threshold workload (single-precision Simpson / incomplete-gamma pass)
         wlb = make_workload("cfg3b", n_local, seed=SEED + 1000 * rank)
         planf = wlb["coal_data"].plan(wlb["dist_types"], dtype=2)

@@ -177,6 +177,11 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
     const bool aligned2 =
         ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & amask) == 0 && (ld % 2 == 0);
     void *args[] = {&n, &ld, &in, &out};
+    if (plan->jit.allinf4_f32 && !h.force_ppl1 && (ld % 4 == 0) &&
+        ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        const unsigned g4 = (unsigned)(((n + 3) / 4 + kBlock - 1) / kBlock);
+        return hipModuleLaunchKernel(plan->jit.allinf4_f32, g4, 1, 1, kBlock, 1, 1, 0, r.stream, args, nullptr);
+    }
     if (aligned2 && !h.force_ppl1) {
         const unsigned g2 = (unsigned)(((n + 1) / 2 + kBlock - 1) / kBlock);
         return hipModuleLaunchKernel(plan->jit.allinf2, g2, 1, 1, kBlock, 1, 1, 0, r.stream, args, nullptr);

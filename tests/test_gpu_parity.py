@@ -699,6 +699,61 @@ def test_tsit5_serves_every_plan_family_ssprk33_serves(gpu_cloudy, oracle):
     assert (np.abs(g3 - want3)[:, ok3] / np.maximum(np.abs(want3[:, ok3]) + np.abs(wl3["mom"][:, ok3]), 1e-300)).max() < 3e-7
 
 
+def test_f32_fast_without_thresholds_is_the_packed_single_precision_kernel(gpu_cloudy, oracle):
+    """CLOUDY_F32_FAST on a plan without thresholds = float planes AND single-precision arithmetic, four
+    parcels per lane as two packed pairs (csrc/allinf_f32.hpp: v_pk_fma_f32).  Error against the fp64 oracle on the float
+    inputs, reported; the fp64-arithmetic CLOUDY_F32 plan beside it (final rounding only).  Shapes away from the clamps:
+    single precision decides k = mean / (M2/M1 - mean) to ~1e-7 / (relative variance), which the report states.  Unaligned
+    or odd-stride batches take the fp64-arithmetic kernels (same results as CLOUDY_F32)."""
+    cloudy = gpu_cloudy
+    L = cloudy.lib()
+    for name in ("cfg2", "cfg3a"):
+        n = 40000
+        wl = bench.make_workload(name, n, seed=19)
+        m32 = wl["mom"].astype(np.float32)
+        want, scale = oracle.rhs_coal_batch(bench.oracle_params(name), m32.astype(np.float64), with_scale=True)
+        prm = oracle.update_dist_batch(bench.oracle_params(name), m32.astype(np.float64))
+        m = dev(cloudy, m32)
+        res = {}
+        for dt_code in (cloudy.F32, cloudy.F32_FAST):
+            plan = wl["coal_data"].plan(wl["dist_types"], dtype=dt_code)
+            assert plan.specialized
+            dm = cloudy.DeviceArray.zeros(*m32.shape, dtype=np.float32)
+            cloudy._lib.check(L.cloudy_coal_rhs(plan.handle, n, n, m.ptr, dm.ptr, None))
+            res[dt_code] = dm.to_numpy().astype(np.float64)
+        ks = prm[2::3]
+        regular = np.isfinite(want).all(axis=0) & (ks > 1e-3).all(axis=0) & (ks < 9.99).all(axis=0) & (scale > 0).all(axis=0)
+        assert regular.mean() > 0.95
+        e32 = (np.abs(res[cloudy.F32] - want) / np.maximum(scale, 1e-300))[:, regular]
+        efast = (np.abs(res[cloudy.F32_FAST] - want) / np.maximum(scale, 1e-300))[:, regular]
+        print(f"{name}: |hip - fp64 oracle| / scale on float planes: CLOUDY_F32 (fp64 arithmetic) max {e32.max():.1e}; "
+              f"CLOUDY_F32_FAST (packed fp32 arithmetic) max {efast.max():.1e}, median {np.median(efast):.1e}, 99.9 % {np.percentile(efast, 99.9):.1e}")
+        assert e32.max() < 2e-7 and np.percentile(efast, 99.9) < 1e-4 and efast.max() < 1e-2
+        # regular parcels: every output finite.  Degenerate ones (~1 % of the batch): a closure clamped to k = eps has
+        # theta = mean / eps ~ 1e14 normalised units, and theta^4 leaves the single-precision range -- those parcels may
+        # come out Inf / NaN where the fp64 arithmetic stays finite (stated, bounded at 1 % of the batch)
+        assert np.isfinite(res[cloudy.F32_FAST][:, regular]).all()
+        lost = np.isfinite(res[cloudy.F32]).all(axis=0) & ~np.isfinite(res[cloudy.F32_FAST]).all(axis=0)
+        print(f"   parcels finite with fp64 arithmetic, not finite in single precision: {lost.sum()} of {n}")
+        assert lost.mean() < 0.01 and not lost[regular].any()
+        # mass conservation of the packed kernel, parcel by parcel (the algebra has no mass term for a single mode)
+        d = res[cloudy.F32_FAST]
+        net = d[1::3].sum(axis=0)
+        mag = np.abs(d[1::3]).sum(axis=0)
+        okm = np.isfinite(net) & (mag > 0) & regular
+        assert not okm.any() or (np.abs(net[okm]) / mag[okm]).max() < 5e-6   # (a single mode has no mass term at all)
+        # odd leading dimension: the 16-B rule fails -> the fp64-arithmetic kernels answer (bit-equal to CLOUDY_F32)
+        n_odd = 1001
+        mo = cloudy.DeviceArray.from_numpy(np.ascontiguousarray(m32[:, :n_odd]))
+        outs = []
+        for dt_code in (cloudy.F32, cloudy.F32_FAST):
+            plan = wl["coal_data"].plan(wl["dist_types"], dtype=dt_code)
+            dmo = cloudy.DeviceArray.zeros(m32.shape[0], n_odd, dtype=np.float32)
+            cloudy._lib.check(L.cloudy_coal_rhs(plan.handle, n_odd, n_odd, mo.ptr, dmo.ptr, None))
+            outs.append(dmo.to_numpy())
+        assert np.array_equal(outs[0], outs[1], equal_nan=True)
+
+
 def test_f64_relaxed_dtype_error_report(gpu_cloudy, oracle):
     """CLOUDY_F64_RELAXED (opt-in) stops the power series / continued fraction of the incomplete gamma
     function at 1e-11 instead of 1e-17 / 1e-16 in the plan-time compiled threshold kernels.  Its error against the fp64

@@ -78,6 +78,7 @@ VARIANTS = {   # bench variant -> (kernel name prefix, items per launch in the b
     "cfg5_f32_fast": ("cloudy_jit_sorted_rs_n2p3_f32fast", 12_500_000),
     "cfg2": ("cloudy_jit_allinf2_n1p2_f64", 1_000_000 // 2),
     "cfg3a_f32_planes": ("cloudy_jit_allinf2_n2p3_f32", 10_000_000 // 2),
+    "cfg3a_f32_fast_packed": ("cloudy_jit_allinf4_n2p3_f32fast", 10_000_000 // 4),
     "cfg3a_aot_kernels": ("coal_rhs_allinf2_kernel<2, 3, double>", 10_000_000 // 2),
 }
 kern = {}
@@ -90,6 +91,7 @@ for name, (prefix, items) in VARIANTS.items():
     util = r["SQ_THREAD_CYCLES_VALU"] / (r["SQ_ACTIVE_INST_VALU"] * 64.0)
     flops = (2 * r["SQ_INSTS_VALU_FMA_F64"] + r["SQ_INSTS_VALU_MUL_F64"] + r["SQ_INSTS_VALU_ADD_F64"]) * 64.0 * util
     n_items = items * 2 if name in ("cfg2", "cfg3a_f32_planes", "cfg3a_aot_kernels") else items   # two parcels per lane
+    n_items = items * 4 if name == "cfg3a_f32_fast_packed" else n_items                            # four parcels per lane
     kern[name] = {"kernel": r["kernel"], "grid_size": r["grid_size"], "fp64_flops_per_item": flops / n_items,
                   "valu_insts_per_item": r["SQ_INSTS_VALU"] * 64.0 / n_items, "lane_utilisation": util}
     t = traffic.get(f'{r["kernel"]}@{r["grid_size"]}')
