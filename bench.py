@@ -580,6 +580,23 @@ def _cfg4q_variant(pkg, rank, world, measured, n=CFG4Q_PARCELS, reps=3):
     rl = _valu_roofline(measured, "cfg4q", n, ms)
     if rl:
         out["roofline"] = rl
+    # BASELINE configs[3] at its FULL size on this one GPU (1e8 parcels = the eight ranks' shards side by side: 7.2 GB in,
+    # 7.2 GB out) -- the N = 1 point of the 8-GPU configuration.  (Eight copies of this rank's shard: a 1e8-parcel draw
+    # on the host would take a minute; tests/test_gpu_numerical.py runs the eight DIFFERENT shards and checks that each,
+    # evaluated alone, equals the same parcels inside the full batch bit for bit.)
+    if world == 1:
+        try:
+            n_full = 8 * n
+            mf, df = pkg.DeviceArray(9, n_full), pkg.DeviceArray(9, n_full)
+            for g in range(8):
+                mf.set_columns(g * n, mom)
+            ms_full = _event_ms(pkg, plan, mf, df, 3)
+            out["full_1e8_on_one_gpu"] = {"workload": f"configs[3] at its full {n_full} parcels in ONE launch on one GPU",
+                                          "value": n_full / (ms_full * 1e-3), "unit": "parcel-RHS/s", "kernel_ms": ms_full,
+                                          "ratio_to_8_launches_of_one_shard": ms_full / (8 * ms)}
+            del mf, df
+        except Exception as e:   # noqa: BLE001 -- e.g. a smaller device: the variant is optional
+            out["full_1e8_on_one_gpu"] = {"skipped": f"{type(e).__name__}: {e}"}
     # the Numerical drivers' time stepping fused around this RHS (cloudy_ssprk33_steps, quad_ssprk33_body): one SSPRK33
     # step = 3 evaluations per call, state in registers
     dt_step = 1e-3
@@ -729,6 +746,88 @@ def _headline_roofline(workload, plan, n_local, nmom, event_ms, per_rank_ms, tra
                           "frac": tf(ms) / FP64_VALU_PEAK_TFLOPS if flops else None} for r, ms in enumerate(per_rank_ms)]}
 
 
+def _one_process(args):
+    """`python bench.py --one-process --gpus N`: ONE process drives the N visible GPUs -- the pattern a single Julia process
+    uses -- instead of one rank per GPU: a plan, a state and a tendency array per device, the launches of a
+    step issued device after device (they run concurrently: each on its own device's NULL stream) and awaited together; the
+    conservation sums through cloudy_comm_create_all (ncclCommInitAll inside libcloudy_hip.so) with the per-device
+    cloudy_moment_sums_allreduce calls bracketed by cloudy_comm_group_start / _end.  Weak scaling as the ranked run: every
+    GPU owns the full per-GPU batch.  (the driver's scaling sweep uses the ranked launch.)"""
+    import ctypes as C
+
+    import __graft_entry__ as ge
+
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)          # RCCL's banner goes to stderr, the line stays alone on stdout
+    pkg = ge.load_package()
+    L = pkg.lib()
+    N = args.gpus
+    if pkg.device_count() < N:
+        raise SystemExit(f"--one-process --gpus {N}: only {pkg.device_count()} HIP device(s) visible")
+    spec = workload_spec(args.workload)
+    n = args.parcels or spec["default_parcels"]
+    devs = []
+    for g in range(N):
+        pkg._lib.check(L.cloudy_set_device(g))
+        wl = make_workload(args.workload, n, seed=SEED + 1000 * g)
+        plan = pkg.Plan([1] * spec["n_modes"], kernel_matrix(spec), spec["thresholds"], NORMS,
+                        pkg.MovingThreshold() if spec.get("moving") else pkg.FixedThreshold(), device=g)
+        devs.append(dict(plan=plan, m=pkg.DeviceArray.from_numpy(wl["mom"]), dm=pkg.DeviceArray.zeros(*wl["mom"].shape),
+                         sums=pkg.DeviceArray(plan.nmom, 1)))
+    nmom = devs[0]["plan"].nmom
+
+    def step():
+        for g, d in enumerate(devs):
+            pkg._lib.check(L.cloudy_coal_rhs(d["plan"].handle, n, n, d["m"].ptr, d["dm"].ptr, None))
+
+    def sync_all():
+        for g in range(N):
+            pkg._lib.check(L.cloudy_set_device(g))
+            pkg._lib.check(L.cloudy_stream_synchronize(None))
+
+    t0 = time.perf_counter()
+    done = 0
+    while done < max(args.warmup, 1) or time.perf_counter() - t0 < WARM_SECONDS:
+        step()
+        done += 1
+        if done % 8 == 0:
+            sync_all()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    wall = time.perf_counter() - t0
+    # the one collective of the path, from one thread driving N communicators
+    comms = (C.c_void_p * N)()
+    pkg._lib.check(L.cloudy_comm_create_all(N, None, comms))
+    pkg._lib.check(L.cloudy_comm_group_start())
+    for g, d in enumerate(devs):
+        pkg._lib.check(L.cloudy_moment_sums_allreduce(d["plan"].handle, comms[g], n, n, nmom, d["dm"].ptr, d["sums"].ptr, None))
+    pkg._lib.check(L.cloudy_comm_group_end())
+    sync_all()
+    gs = [d["sums"].to_numpy().reshape(-1) for d in devs]
+    assert all(np.array_equal(gs[0], x) for x in gs), "the all-reduced sums differ between devices"
+    for g in range(N):
+        L.cloudy_comm_destroy(comms[g])
+    v = pkg.lib().cloudy_comm_rccl_version()
+    np_modes = [3] * spec["n_modes"]
+    mass = sum(gs[0][3 * k + 1] for k in range(spec["n_modes"]))
+    gross = sum(abs(gs[0][3 * k + 1]) for k in range(spec["n_modes"]))
+    out = {"metric": "parcel moment-RHS evals/sec at 1e7 parcels; achieved HBM GB/s vs 8 TB/s peak",
+           "value": n * N * args.steps / wall, "unit": "parcel-RHS/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"{args.workload}: {n} parcels/GPU", "global_parcels": n * N,
+                      "launch": "ONE process driving all GPUs (cloudy_comm_create_all + cloudy_comm_group_start/_end)"},
+           "collective": f"ncclAllReduce(sum, f64, {nmom}) per device inside one group, RCCL {v // 10000}.{v // 100 % 100}.{v % 100}, {N} device(s)",
+           "mass_rate_residual": abs(mass) / max(gross, 1e-300), "np_modes": np_modes}
+    json_out.write(json.dumps(out) + "\n")
+    json_out.flush()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -738,9 +837,13 @@ def main():
     ap.add_argument("--workload", default="cfg3a")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--one-process", action="store_true",
+                    help="one process drives all --gpus devices (cloudy_comm_create_all) instead of one rank per GPU")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.one_process:
+        return _one_process(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return _spawn_ranks(args.gpus, sys.argv[1:])   # before anything touches the GPU
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:

@@ -49,17 +49,31 @@ class DeviceArray:
             _lib.check(_lib.lib().cloudy_stream_synchronize(None))
         return out
 
-    def columns_to_numpy(self, ncols):
-        """the first `ncols` parcels of every plane (one copy per plane): diagnostics on a slice of a big result"""
-        ncols = min(int(ncols), self.shape[1])
+    def columns_to_numpy(self, ncols, lo=0):
+        """parcels [lo, lo + ncols) of every plane (one copy per plane): diagnostics on a slice of a big result"""
+        lo = int(lo)
+        ncols = max(0, min(int(ncols), self.shape[1] - lo))
         out = np.empty((self.shape[0], ncols), dtype=self.dtype)
         L = _lib.lib()
         _lib.check(L.cloudy_stream_synchronize(None))
         for q in range(self.shape[0]):
-            _lib.check(L.cloudy_memcpy_d2h(out[q].ctypes.data, self.ptr + q * self.shape[1] * self.dtype.itemsize,
+            _lib.check(L.cloudy_memcpy_d2h(out[q].ctypes.data, self.ptr + (q * self.shape[1] + lo) * self.dtype.itemsize,
                                            ncols * self.dtype.itemsize, None))
         _lib.check(L.cloudy_stream_synchronize(None))
         return out
+
+    def set_columns(self, lo, a):
+        """upload the host block a (planes, m) into parcels [lo, lo + m) of every plane (the shard of one rank inside a
+        batch that holds every rank's parcels)"""
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        lo = int(lo)
+        if a.shape[0] != self.shape[0] or lo < 0 or lo + a.shape[1] > self.shape[1]:
+            raise ValueError("block does not fit")
+        L = _lib.lib()
+        for q in range(self.shape[0]):
+            _lib.check(L.cloudy_memcpy_h2d(self.ptr + (q * self.shape[1] + lo) * self.dtype.itemsize, a[q].ctypes.data,
+                                           a.shape[1] * self.dtype.itemsize, None))
+        _lib.check(L.cloudy_stream_synchronize(None))
 
     def data_ptr(self):
         return self.ptr

@@ -289,6 +289,44 @@ def test_cfg4q_full_size_properties(gpu_cloudy):
     assert np.max(np.abs(d3 - 3.0 * d) / np.maximum(np.abs(3.0 * d), 1e-300)) < 1e-12
 
 
+def test_configs3_at_its_full_1e8_parcels_on_one_gpu_and_its_shards(gpu_cloudy):
+    """BASELINE configs[3] -- 1e8 parcels, 3 modes, hydrodynamic kernel by the 10-point rule, 9
+    moments -- is worded for 8 GPUs, 1.25e7 parcels each.  Its whole batch fits ONE MI355X (7.2 GB in, 7.2 GB out): the
+    eight ranks' shards (seed + 1000 x rank, as bench.py draws them) are laid side by side, the batch is evaluated in one
+    launch, and the shard rank g would own (shard_range) evaluated ALONE -- its own array, its own leading dimension, as on
+    rank g's GPU -- equals the same parcels inside the full batch bit for bit: sharding the batch changes no result."""
+    cloudy = gpu_cloudy
+    L = cloudy.lib()
+    world, n_shard = 8, 12_500_000
+    n = world * n_shard
+    kf = cloudy.get_normalized_kernel_func(cloudy.HydrodynamicKernelFunction(1e2 * np.pi), NORMS)
+    plan = cloudy.numerical_plan([1, 1, 1], kf, NORMS, 10, quad_mode=cloudy.QUAD_FIXED)
+    m, dm = cloudy.DeviceArray(9, n), cloudy.DeviceArray(9, n)
+    shards = {}
+    for g in range(world):
+        lo, hi = cloudy.shard_range(n, g, world)
+        assert hi - lo == n_shard
+        blk = bench.synth_moments(3, n_shard, bench.SEED + 1000 * g)
+        m.set_columns(lo, blk)
+        if g in (0, 3, 7):
+            shards[g] = blk
+    cloudy._lib.check(L.cloudy_coal_rhs(plan.handle, n, n, m.ptr, dm.ptr, None))
+    cloudy._lib.check(L.cloudy_stream_synchronize(None))
+    for g, blk in shards.items():
+        lo, hi = cloudy.shard_range(n, g, world)
+        inside = dm.columns_to_numpy(n_shard, lo)
+        ms, ds = dev(cloudy, blk), cloudy.DeviceArray.zeros(9, n_shard)
+        cloudy._lib.check(L.cloudy_coal_rhs(plan.handle, n_shard, n_shard, ms.ptr, ds.ptr, None))
+        alone = ds.to_numpy()
+        assert np.array_equal(inside, alone, equal_nan=True), g
+        mass = alone[1] + alone[4] + alone[7]
+        mag = np.abs(alone[1]) + np.abs(alone[4]) + np.abs(alone[7])
+        okm = np.isfinite(mass)
+        assert np.max(np.abs(mass[okm]) / np.maximum(mag[okm], 1e-300)) < 1e-9
+        del ms, ds
+    del m, dm
+
+
 # ---- CONVERGED mode (quad_mode = CLOUDY_QUAD_CONVERGED, csrc/quad_conv.hpp) --------------------------------------------
 TOL_CONVERGED = 1e-11   # HIP vs the same-rule oracle; the oracle vs adaptive quadrature is a CPU test (<= 1e-8 of scale)
 

@@ -166,6 +166,24 @@ def test_bench_gpus_8_on_one_gpu_with_an_empty_jit_cache(gpu_cloudy, tmp_path):
     assert files and not [f for f in os.listdir(cache) if f.endswith(".tmp")], os.listdir(cache)
 
 
+@pytest.mark.gpu
+def test_bench_one_process_mode(gpu_cloudy):
+    """`bench.py --one-process --gpus N` -- one process, N GPUs, cloudy_comm_create_all and the group
+    bracket around the per-device all-reduce (the single-Julia-process pattern).  The test box has one GPU: N = 1 (the
+    ncclCommInitAll path with one device); more devices than visible is an error, not a silent smaller run."""
+    import json
+
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--one-process", "--gpus", "1", "--parcels", "300000",
+                        "--steps", "5", "--warmup", "2"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["config"]["global_parcels"] == 300000 and "ONE process" in out["config"]["launch"]
+    assert out["value"] > 0 and out["mass_rate_residual"] < 1e-9 and "ncclAllReduce" in out["collective"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--one-process", "--gpus", "64", "--parcels", "1000",
+                        "--steps", "1", "--warmup", "1"], capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and "HIP device(s) visible" in (p.stdout + p.stderr)
+
+
 def test_comm_entry_points_without_a_gpu(cloudy):
     """The RCCL-backed entry points validate their arguments and report status codes without a device (no compute, no
     communicator is formed on the CPU box); with a GPU this test only checks the argument errors."""
