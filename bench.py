@@ -584,7 +584,7 @@ def _cfg4q_variant(pkg, rank, world, measured, n=CFG4Q_PARCELS, reps=3):
     # 7.2 GB out) -- the N = 1 point of the 8-GPU configuration.  (Eight copies of this rank's shard: a 1e8-parcel draw
     # on the host would take a minute; tests/test_gpu_numerical.py runs the eight DIFFERENT shards and checks that each,
     # evaluated alone, equals the same parcels inside the full batch bit for bit.)
-    if world == 1:
+    if world == 1 and os.environ.get("CLOUDY_BENCH_SKIP_FULL") != "1":
         try:
             n_full = 8 * n
             mf, df = pkg.DeviceArray(9, n_full), pkg.DeviceArray(9, n_full)

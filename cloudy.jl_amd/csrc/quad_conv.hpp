@@ -1010,7 +1010,30 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
                 r.sc[2] = (pr[2] + pr[3]) * rp;
             }
         }
-        if (any_gamma) conv_T_merged<N, KIND>(Q, lg, rb, Traw);
+        if (any_gamma) {
+            // what the walk does not need waits in the lane's own LDS slots (conflict-free, no barrier: a lane reads what it
+            // wrote): the 3N partial tendencies of phase 1 and the prefactors -- registers the allocator would otherwise
+            // spill around (and, at three waves per SIMD, inside) the loop: 11 x the algorithmic HBM traffic in scratch
+#ifndef CLOUDY_CONV_NO_PARK
+            __shared__ double sh_park[3 * N + (N > 1 ? N - 1 : 1)][kBlock];
+            const int t = threadIdx.x;
+#pragma unroll
+            for (int k = 0; k < N; ++k)
+#pragma unroll
+                for (int m = 0; m < 3; ++m) sh_park[3 * k + m][t] = acc[k][m];
+#pragma unroll
+            for (int j = 0; j < N - 1; ++j) sh_park[3 * N + j][t] = prefj[j];
+#endif
+            conv_T_merged<N, KIND>(Q, lg, rb, Traw);
+#ifndef CLOUDY_CONV_NO_PARK
+#pragma unroll
+            for (int k = 0; k < N; ++k)
+#pragma unroll
+                for (int m = 0; m < 3; ++m) acc[k][m] = sh_park[3 * k + m][t];
+#pragma unroll
+            for (int j = 0; j < N - 1; ++j) prefj[j] = sh_park[3 * N + j][t];
+#endif
+        }
 #pragma unroll
         for (int j = 0; j < N - 1; ++j) {
             if (!(nj_[j] > 0.0)) continue;
