@@ -105,6 +105,8 @@ typedef struct {
     int marks, lmax;
     double floor_, range_eps;
     int imax;
+    int desc;        /* 1: walk the initial panels from thi down to tlo */
+    double tol_skip; /* > 0: skip an initial panel whose rigorous bound is below tol_skip * max(|acc|, floor * scale) */
 } lab_params;
 
 int lab_T_rule(int N, int j, const int *type, const double *th, const double *k, double gam, const lab_params *P, double *T,
@@ -132,21 +134,102 @@ int lab_T_rule(int N, int j, const int *type, const double *th, const double *k,
             }
         }
     double out[3] = {0, 0, 0};
-    double cur = tlo;
-    int io = 1;
-    while (cur < thi) {
-        double nxt = thi, own = tlo + h0 * io;
-        while (own <= cur + gap) {
-            ++io;
-            own = tlo + h0 * io;
+    /* the sorted list of initial edges (same set in either direction) */
+    double edges[256];
+    int ne = 0;
+    {
+        double cur = tlo;
+        int io = 1;
+        edges[ne++] = tlo;
+        while (cur < thi) {
+            double nxt = thi, own = tlo + h0 * io;
+            while (own <= cur + gap) {
+                ++io;
+                own = tlo + h0 * io;
+            }
+            if (own < nxt) nxt = own;
+            for (int m = 0; m < nm; ++m)
+                if (marks[m] > cur + gap && marks[m] < nxt) nxt = marks[m];
+            if (nxt > thi - gap) nxt = thi;
+            cur = nxt;
+            edges[ne++] = nxt;
         }
-        if (own < nxt) nxt = own;
-        for (int m = 0; m < nm; ++m)
-            if (marks[m] > cur + gap && marks[m] < nxt) nxt = marks[m];
-        if (nxt > thi - gap) nxt = thi;
-        const double a0 = cur, h = nxt - cur;
-        cur = nxt;
+    }
+    /* stationary points of concave Gamma-family log ratios */
+    double tst[MAXN];
+    for (int m = 0; m < N; ++m) tst[m] = (r.q2[m] == 0.0 && r.cb[m] < 0.0 && r.q1[m] > 0.0) ? log(-r.q1[m] / r.cb[m]) : -INFINITY;
+    const double tmode = log(A);
+    for (int pi = 0; pi < ne - 1; ++pi) {
+        const int p = P->desc ? ne - 2 - pi : pi;
+        const double a0 = edges[p], b0 = edges[p + 1], h = b0 - a0;
         st->init_panels++;
+        if (P->tol_skip > 0.0) {
+            const double ua = exp(a0), ub = exp(b0);
+            st->edges++;
+            double lw = fmax(A * a0 - ua, A * b0 - ub);
+            if (tmode > a0 && tmode < b0) lw = A * tmode - A;
+            double sup = 0.0;
+            for (int m = j + 1; m < N; ++m) {
+                double l;
+                if (r.q2[m] != 0.0) { /* Lognormal: sup of the quadratic + u(b) */
+                    double tv = -r.q1[m] / (2.0 * r.q2[m]);
+                    tv = fmin(fmax(tv, a0), b0);
+                    l = (r.q2[m] * tv + r.q1[m]) * tv + r.q0[m] + r.cb[m] * ub;
+                } else if (r.cb[m] >= 0.0) {
+                    l = fmax(lrho(&r, m, a0, ua), lrho(&r, m, b0, ub));
+                } else {
+                    const double tc = fmin(fmax(tst[m], a0), b0);
+                    l = lrho(&r, m, tc, exp(tc));
+                }
+                sup += exp(fmin(l, 0.0));
+            }
+            sup = fmin(sup, 1.0);
+            double B = exp(lw - r.lgA) * sup * h;
+            const double sb = ub * r.thj;
+            int skip = 1;
+            for (int o = 0; o < 3; ++o) {
+                if (!(B <= P->tol_skip * fmax(fabs(out[o]), P->floor_ * scaleS[o]))) skip = 0;
+                B *= sb;
+            }
+            if (skip) {
+                st->skipped++;
+                continue;
+            }
+        }
+        if (P->tol_skip < 0.0 && P->desc) {
+            /* termination only: the bound over the WHOLE remaining range [tlo, b0] */
+            const double ts = -P->tol_skip, ua = exp(tlo), ub = exp(b0);
+            st->edges++;
+            double lw = fmax(A * tlo - ua, A * b0 - ub);
+            if (tmode > tlo && tmode < b0) lw = A * tmode - A;
+            double sup = 0.0;
+            for (int m = j + 1; m < N; ++m) {
+                double l;
+                if (r.q2[m] != 0.0) {
+                    double tv = -r.q1[m] / (2.0 * r.q2[m]);
+                    tv = fmin(fmax(tv, tlo), b0);
+                    l = (r.q2[m] * tv + r.q1[m]) * tv + r.q0[m] + r.cb[m] * ub;
+                } else if (r.cb[m] >= 0.0) {
+                    l = fmax(lrho(&r, m, tlo, ua), lrho(&r, m, b0, ub));
+                } else {
+                    const double tc = fmin(fmax(tst[m], tlo), b0);
+                    l = lrho(&r, m, tc, exp(tc));
+                }
+                sup += exp(fmin(l, 0.0));
+            }
+            sup = fmin(sup, 1.0);
+            double B = exp(lw - r.lgA) * sup * (b0 - tlo);
+            const double sb = ub * r.thj;
+            int stop = 1;
+            for (int o = 0; o < 3; ++o) {
+                if (!(B <= ts * fmax(fabs(out[o]), P->floor_ * scaleS[o]))) stop = 0;
+                B *= sb;
+            }
+            if (stop) {
+                st->skipped += ne - 1 - pi;
+                break;
+            }
+        }
         int L = 0;
         unsigned i = 0;
         for (;;) {
