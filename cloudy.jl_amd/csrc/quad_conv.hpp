@@ -200,7 +200,7 @@ __device__ __forceinline__ double conv_one_minus_w(const ConvLogDensity (&lg)[N]
 // Lanes walk their own panel trees in ONE flat loop (a new initial panel is just another state of it): a wave runs for as
 // long as its lane with the most panel evaluations.
 constexpr int kConvNInit = 12, kConvLMax = 12, kConvIMax = 12, kConvBudget = 8192, kConvBudgetLn = 1024;
-constexpr double kConvTol = 1e-8, kConvFloor = 1e-10;
+constexpr double kConvTol = 1e-8, kConvFloor = 1e-10, kConvTermTol = 1e-10;
 __device__ static const double kGKX[15] = {-0.991455371120812639206854697526329, -0.949107912342758524526189684047851,
                                            -0.864864423359769072789712788640926, -0.741531185599394439863864773280788,
                                            -0.586087235467691130294144838258730, -0.405845151377397166906606412076961,
@@ -269,6 +269,30 @@ struct ConvMarks {
         I[m] = i > kConvIMax ? kConvIMax : i;
         q[m] = -(I[m] + 1);
         v[m] = value(m);
+    }
+    // the same marks walked DOWNWARDS (conv_T_merged): start at q = I + 1; below -(I + 1): none (-inf)
+    __device__ __forceinline__ double value_d(int m) const {
+        const int qq = q[m];
+        if (qq < -(I[m] + 1)) return -INFINITY;
+        const int aq = qq < 0 ? -qq : qq;
+        const double off = qq == 0 ? 0.0 : (qq < 0 ? -1.0 : 1.0) * ldexp(w[m], aq - 1);
+        return (c[m] + off) - shift;
+    }
+    // the largest mark < lim; -inf: none
+    __device__ __forceinline__ double prev(double lim, bool need) {
+        double r = -INFINITY;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            while (need && v[m] >= lim) {
+                --q[m];
+                v[m] = value_d(m);
+            }
+            r = fmax(r, v[m]);
+        }
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+            if (extra[e] < lim) r = fmax(r, extra[e]);
+        return r;
     }
     // the smallest mark > lim; +inf: none.  Lanes with need = false run through it without changing anything (the caller
     // keeps every lane on one path: conv_adaptive)
@@ -698,6 +722,10 @@ struct ConvRule {
     double A, lgA, th, lnth, tlo, thi;
     double kj, lgB, rB, ex1, ex2;  // Long: the shape, -ln B(k, k), B(k+1, k+1) / B(k, k), the kinks of G in the rule's variable
     double sc[3];                  // Long: the scale of each output (T_m with 1 - w = 1, over the prefactor)
+    // the bound of what is left of the integral below an edge (the walk goes DOWN and stops early, see conv_T_merged):
+    double tmode, lwmode;          // ln A, ln of the weight's maximum
+    double ltlo[NM];               // ln rho of the other modes at t_lo
+    bool convex;                   // every mode above j is Gamma-family with theta >= theta_j: ln rho is convex in t
     double mc[NM], mw[NM];         // the other modes' cores (ln mean size, width)
     int mI[NM];
 };
@@ -707,10 +735,16 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
                                               const ConvRule<(N > 1 ? N - 1 : 1)> (&rb)[(N > 1 ? N - 1 : 1)],
                                               double (&Traw)[(N > 1 ? N - 1 : 1)][3]) {
     constexpr int NM = N > 1 ? N - 1 : 1, NR = NM;
+    // (the Long kernel's G(s) is only finitely smooth at s = x_t and 2 x_t -- the Beta(k, k) law of tau ends like tau^(k-1)
+    // there -- and K15 converges slowly in the panels next to them: 1e-9 of scale at 1e-8 on random mixtures, against
+    // 1e-10 ... 1e-13 for the homogeneous kernels; its rules run at a tenth of the tolerance)
+    constexpr double kTolT = KIND == KF_LONG ? 0.1 * kConvTol : kConvTol;
     // ---- the state of the rule in hand
     int j = -1;
     double A = 1.0, lgA = 0.0, thj = 1.0, lnthj = 0.0, tlo = 0.0, thi = 0.0, kj = 1.0, lgB = 0.0, rB = 0.0;
     double scaleS[3] = {1.0, 1.0, 1.0}, out[3] = {0.0, 0.0, 0.0};
+    double tmode = 0.0, lwmode = 0.0, lnup = 0.0, ltlo[NM];
+    bool convex = false;
     ConvLogDensity own, oth[NM];
     ConvMarks<NM> mk;
     double h0 = 0.0, gap = 0.0, cur = 0.0, a0 = 0.0, h = 0.0;
@@ -724,6 +758,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
     mk.extra[0] = mk.extra[1] = mk.extra[2] = INFINITY;
 #pragma unroll
     for (int sl = 0; sl < NM; ++sl) {
+        ltlo[sl] = 0.0;
         mk.c[sl] = 0.0;
         mk.w[sl] = 1.0;
         mk.I[sl] = 0;
@@ -746,6 +781,12 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
             lnthj = sel ? rb[r].lnth : lnthj;
             tlo = sel ? rb[r].tlo : tlo;
             thi = sel ? rb[r].thi : thi;
+            tmode = sel ? rb[r].tmode : tmode;
+            lwmode = sel ? rb[r].lwmode : lwmode;
+            convex = sel ? rb[r].convex : convex;
+            lnup = sel ? (N - 1 - r == 1 ? 0.0 : N - 1 - r == 2 ? 0.6931471805599453 : 1.0986122886681098) : lnup;
+#pragma unroll
+            for (int sl = 0; sl < NM; ++sl) ltlo[sl] = sel ? rb[r].ltlo[sl] : ltlo[sl];
             if (KIND == KF_LONG) {
                 kj = sel ? rb[r].kj : kj;
                 lgB = sel ? rb[r].lgB : lgB;
@@ -788,18 +829,18 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
             h0 = (thi - tlo) * (1.0 / double(kConvNInit));
             gap = 1e-7 * (thi - tlo);
 #pragma unroll
-            for (int sl = 0; sl < NM; ++sl) {
-                mk.q[sl] = -(mk.I[sl] + 1);
-                mk.v[sl] = mk.value(sl);
+            for (int sl = 0; sl < NM; ++sl) {  // the marks are walked downwards
+                mk.q[sl] = mk.I[sl] + 1;
+                mk.v[sl] = mk.value_d(sl);
             }
             if (KIND != KF_LONG) {
                 scaleS[0] = 1.0;
                 scaleS[1] = A * thj;
                 scaleS[2] = A * (A + 1.0) * thj * thj;
             }
-            cur = tlo;
-            a0 = tlo;
-            io = 1;
+            cur = thi;
+            a0 = thi;
+            io = kConvNInit - 1;
             L = 0;
             i = 0u;
             budget = kConvBudget;
@@ -807,22 +848,46 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
         }
         busy = need ? go : busy;
     };
-    // as in conv_adaptive; need = false: no change.  Returns true for the lanes whose rule has no panel left.
+    // The next initial panel [nxt, cur) BELOW the current edge for the lanes with need = true; need = false: no change.
+    // Returns true for the lanes whose rule is finished: no panel left, or the rigorous bound of everything that is left,
+    //   int_{t_lo}^{cur} W s^m (1 - w) G dt <= sup W x sup (1 - w) x sup (s^m G) x (cur - t_lo),
+    // is below kConvTermTol x max(|accumulated|, floor x scale) for all three outputs (sup W: the weight is log-concave
+    // with its mode at ln A; sup (1 - w) <= min(1, sum of the rho of the modes above j), and ln rho of a Gamma-family mode
+    // with theta >= theta_j is convex in t, so its supremum over [t_lo, cur] is at an end point -- any other mode above
+    // j: sup (1 - w) = 1; s^m G <= s(cur)^m (c_a s + c_b s^2) for Long).  Two exponentials per initial panel.
     const auto next_panel = [&](bool need) -> bool {
-        const bool go = need && cur < thi;
-        const double lim = cur + gap;
-        int io2 = io;
-        double ownp = fma(h0, double(io2), tlo);
-        while (need && ownp <= lim) {
-            ++io2;
-            ownp = fma(h0, double(io2), tlo);
+        const double ub = exp_fin(cur), sb = ub * thj, lsb = cur + lnthj;
+        const double lw = cur > tmode ? lwmode : fma(A, cur, -ub) - lgA;
+        const double ow = own(sb, lsb);
+        double lmax = -INFINITY;
+#pragma unroll
+        for (int sl = 0; sl < NM; ++sl) {
+            const double l = fmax(oth[sl](sb, lsb) - ow, ltlo[sl]);
+            lmax = sl >= j ? fmax(lmax, l) : lmax;
         }
-        double nxt = fmin(thi, ownp);
-        nxt = fmin(nxt, mk.next(lim, need));
-        nxt = nxt > thi - gap ? thi : nxt;
+        const double lsig = convex ? fmin(0.0, lmax + lnup) : 0.0;
+        double Bv = exp_fin(lw + lsig) * (cur - tlo);
+        if (KIND == KF_LONG) Bv *= fma(Q.kf[1] * sb, sb, Q.kf[2] * sb);  // G(s) <= c_a s + c_b s^2
+        bool stop = true;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            if (!(Bv <= kConvTermTol * fmax(fabs(out[e]), kConvFloor * scaleS[e]))) stop = false;
+            Bv *= sb;
+        }
+        const bool go = need && cur > tlo && !stop;
+        const double lim = cur - gap;
+        int io2 = io;
+        double ownp = io2 > 0 ? fma(h0, double(io2), tlo) : tlo;
+        while (need && io2 > 0 && ownp >= lim) {
+            --io2;
+            ownp = io2 > 0 ? fma(h0, double(io2), tlo) : tlo;
+        }
+        double nxt = fmax(tlo, ownp);
+        nxt = fmax(nxt, mk.prev(lim, need));
+        nxt = nxt < tlo + gap ? tlo : nxt;
         io = io2;
-        a0 = go ? cur : a0;
-        h = go ? nxt - cur : h;
+        a0 = go ? nxt : a0;
+        h = go ? cur - nxt : h;
         cur = go ? nxt : cur;
         L = go ? 0 : L;
         i = go ? 0u : i;
@@ -873,7 +938,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
         bool ok = true;
 #pragma unroll
         for (int e = 0; e < 3; ++e)
-            if (fabs(K[e] - G[e]) * hw > kConvTol * fmax(fabs(fma(K[e], hw, out[e])), kConvFloor * scaleS[e])) ok = false;
+            if (fabs(K[e] - G[e]) * hw > kTolT * fmax(fabs(fma(K[e], hw, out[e])), kConvFloor * scaleS[e])) ok = false;
         const bool accept = ok || L == kConvLMax || budget <= 0;
         if (accept) {
 #pragma unroll
@@ -960,8 +1025,11 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
             r.lnth = r.tlo = r.thi = r.kj = r.lgB = r.rB = 0.0;
             r.ex1 = r.ex2 = INFINITY;
             r.sc[0] = r.sc[1] = r.sc[2] = 1.0;
+            r.tmode = r.lwmode = 0.0;
+            r.convex = false;
 #pragma unroll
             for (int sl = 0; sl < NM; ++sl) {
+                r.ltlo[sl] = 0.0;
                 r.mc[sl] = 0.0;
                 r.mw[sl] = 1.0;
                 r.mI[sl] = 0;
@@ -998,6 +1066,25 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
                             }
                         ++slot;
                     }
+            }
+            {
+                // for the bound of what is left below an edge (conv_T_merged): the weight's mode, ln rho of the others at t_lo
+                r.tmode = log_pos(Ash);
+                r.lwmode = Ash * r.tmode - Ash - r.lgA;
+                const double s_lo = exp_fin(r.tlo) * thj, ls_lo = r.tlo + lnthj;
+                const double own_lo = lg[j](s_lo, ls_lo);
+                bool cvx = true;
+                int slot = 0;
+#pragma unroll
+                for (int m = 0; m < N; ++m)
+                    if (m != j) {
+#pragma unroll
+                        for (int sl = 0; sl < N - 1; ++sl)
+                            if (sl == slot) r.ltlo[sl] = lg[m](s_lo, ls_lo) - own_lo;
+                        if (m > j && (lg[m].lognormal || !(lg[m].b <= lg[j].b))) cvx = false;
+                        ++slot;
+                    }
+                r.convex = cvx;
             }
             r.kj = kj;
             if (KIND == KF_LONG) {

@@ -522,6 +522,8 @@ static const double CO_GK_WG[15] = {0.0, 0.129484966168869693270611432679082, 0.
                                     0.0, 0.381830050505118944950369775488975, 0.0, 0.417959183673469387755102040816327,
                                     0.0, 0.381830050505118944950369775488975, 0.0, 0.279705391489276667901467771423780,
                                     0.0, 0.129484966168869693270611432679082, 0.0};
+static int co_conv_walk_down_ = 1; /* the Gamma-weight T_m rules: 1 = descending walk with early termination (the kernels'), 0 = round 3's upward walk */
+void co_conv_set_walk_down(int on) { co_conv_walk_down_ = on; }
 static _Thread_local long co_conv_nodes_; /* integrand evaluations of the adaptive rules since the last reset */
 static _Thread_local long co_conv_rule_nodes_[CO_MAX_MODES]; /* ... of the T_m rule of each mode in the last call */
 void co_conv_rule_node_counts(long *out) {
@@ -578,6 +580,77 @@ static void co_conv_adaptive(double tlo, double thi, const double *marks, int nm
             }
             if (ok || L == CO_CONV_LMAX || budget <= 0) {
                 for (int o = 0; o < nout; ++o) out[o] += K[o] * hw;
+                ++i;
+                while (L > 0 && !(i & 1u)) {
+                    i >>= 1;
+                    --L;
+                }
+                if (L == 0) break;
+            } else {
+                ++L;
+                i <<= 1;
+            }
+        }
+    }
+}
+/* ---- the Gamma-weight T_m rules walk their initial panels DOWNWARDS and stop early (round 4; csrc/quad_conv.hpp,
+ * conv_T_merged).  The same initial edges -- equal pieces, graded marks, kinks -- taken from t_hi down to t_lo (next edge =
+ * the largest mark or equal-piece edge more than `gap` below the current one; an edge within gap of t_lo is t_lo), the same
+ * bisection and acceptance test.  1 - w -> 1 towards large sizes (the modes above j dominate there), so the integral is
+ * established in the first panels and the accumulated value the acceptance test compares with is the final one almost from
+ * the start: measured on the cfg4q batch, 7.6e-14 of scale against the rule at 1e-14 where the upward walk has 1e-10 at the
+ * same tolerance -- which is what lets CO_CONV_TOL_DESC be 1e-7.  And before every initial panel [., b] a RIGOROUS bound of
+ * everything that is left, int_{t_lo}^{b} W s^m (1 - w) G dt <= sup W x sup (1 - w) x sup(s^m G) x (b - t_lo), is compared
+ * with CO_CONV_TERM_TOL x max(|accumulated|, floor x scale): below it for all outputs the rule ends.  sup W: the weight
+ * exp(A t - e^t) / Gamma(A) is log-concave with its mode at ln A; sup (1 - w) <= min(1, sum_{m > j} rho_m) and ln rho_m of
+ * a Gamma-family mode with theta_m >= theta_j is CONVEX in t (its e^t coefficient 1 - theta_j / theta_m is >= 0), so its
+ * supremum over [t_lo, b] is at an end point; any other mode above j (a Lognormal one, or a smaller scale): sup (1 - w) = 1.
+ * bound(b, B[3], ctx) returns the three bounds. */
+#define CO_CONV_TERM_TOL 1e-10
+typedef void (*co_bound_fn)(double b, double *B, void *ctx);
+static void co_conv_descending(double tlo, double thi, const double *marks, int nmarks, double tol, const double *scaleS,
+                               int budget, co_vec_fn f, co_bound_fn bound, void *ctx, double *out) {
+    double vals[3], K[3], G[3], B[3];
+    const double h0 = (thi - tlo) / CO_CONV_NINIT, gap = 1e-7 * (thi - tlo);
+    double cur = thi;
+    int io = CO_CONV_NINIT - 1;
+    while (cur > tlo) {
+        bound(cur, B, ctx);
+        int stop = 1;
+        for (int o = 0; o < 3; ++o)
+            if (!(B[o] <= CO_CONV_TERM_TOL * fmax(fabs(out[o]), CO_CONV_FLOOR * scaleS[o]))) stop = 0;
+        if (stop) break;
+        const double lim = cur - gap;
+        double own = io > 0 ? tlo + h0 * io : tlo;
+        while (io > 0 && own >= lim) {
+            --io;
+            own = io > 0 ? tlo + h0 * io : tlo;
+        }
+        double nxt = fmax(tlo, own);
+        for (int m = 0; m < nmarks; ++m)
+            if (marks[m] < lim && marks[m] > nxt) nxt = marks[m];
+        if (nxt < tlo + gap) nxt = tlo;
+        const double a0 = nxt, h = cur - nxt;
+        cur = nxt;
+        int L = 0;
+        unsigned i = 0;
+        for (;;) {
+            const double w = ldexp(h, -L), hw = 0.5 * w, c = (a0 + w * i) + hw;
+            for (int o = 0; o < 3; ++o) K[o] = G[o] = 0.0;
+            --budget;
+            for (int g = 0; g < 15; ++g) {
+                f(c + hw * CO_GK_X[g], vals, ctx);
+                ++co_conv_nodes_;
+                for (int o = 0; o < 3; ++o) {
+                    K[o] += CO_GK_WK[g] * vals[o];
+                    if (g & 1) G[o] += CO_GK_WG[g] * vals[o];
+                }
+            }
+            int ok = 1;
+            for (int o = 0; o < 3; ++o)
+                if (fabs(K[o] - G[o]) * hw > tol * fmax(fabs(out[o] + K[o] * hw), CO_CONV_FLOOR * scaleS[o])) ok = 0;
+            if (ok || L == CO_CONV_LMAX || budget <= 0) {
+                for (int o = 0; o < 3; ++o) out[o] += K[o] * hw;
                 ++i;
                 while (L > 0 && !(i & 1u)) {
                     i >>= 1;
@@ -781,7 +854,7 @@ typedef struct {
     const co_dist *pdists;
     int N, j;
     const co_kernel_func *kf;
-    double k, A, lgA, theta, lth;
+    double k, A, lgA, theta, lth, tlo;
 } co_T_ctx;
 static void co_T_node(double t, double *vals, void *v) {
     const co_T_ctx *c = (const co_T_ctx *)v;
@@ -793,6 +866,31 @@ static void co_T_node(double t, double *vals, void *v) {
     vals[0] = h;
     vals[1] = h * s;
     vals[2] = h * s * s;
+}
+/* the bound of what is left below b for the rule of co_T_ctx (see co_conv_descending) */
+static void co_T_bound(double b, double *B, void *v) {
+    const co_T_ctx *c = (const co_T_ctx *)v;
+    const co_dist *dj = &c->pdists[c->j];
+    const double ub = exp(b), sb = ub * c->theta, lsb = b + c->lth;
+    const double tmode = log(c->A);
+    const double lw = b > tmode ? c->A * tmode - c->A - c->lgA : c->A * b - ub - c->lgA;
+    const double slo = exp(c->tlo) * c->theta, lslo = c->tlo + c->lth;
+    double lsig = 0.0;
+    int convex = 1, n_up = 0;
+    double lmax = -INFINITY;
+    for (int m = c->j + 1; m < c->N; ++m) {
+        const co_dist *dm = &c->pdists[m];
+        ++n_up;
+        if (dm->type == CO_LOGNORMAL || !(1.0 / dm->theta <= 1.0 / dj->theta)) convex = 0;
+        const double own_b = co_ln_normed(dj, sb, lsb), own_lo = co_ln_normed(dj, slo, lslo);
+        lmax = fmax(lmax, fmax(co_ln_normed(dm, sb, lsb) - own_b, co_ln_normed(dm, slo, lslo) - own_lo));
+    }
+    if (convex && n_up > 0) lsig = fmin(0.0, lmax + log((double)n_up));
+    double Bv = exp(lw + lsig) * (b - c->tlo);
+    if (c->kf->kind == CO_KF_LONG) Bv *= c->kf->p[2] * sb + c->kf->p[1] * sb * sb; /* G(s) <= c_a s + c_b s^2 */
+    B[0] = Bv;
+    B[1] = Bv * sb;
+    B[2] = Bv * sb * sb;
 }
 /* ---- Lognormal modes (LN).  Moments and partial moments are closed forms (co_gmom, co_pmom); P(Y' < X') of the
  * hydrodynamic terms is Phi(.) for a Lognormal pair and the adaptive rule for a Gamma-Lognormal pair (co_conv_H_grid).
@@ -919,10 +1017,11 @@ int co_get_coal_ints_numerical_converged(const co_dist *pdists, int N, const co_
                  * in the weight); Long: T_m = 1/2 n^2 E_{Gamma(2k)}[s^m (1 - w) G(s)] */
                 const int lng = kf->kind == CO_KF_LONG;
                 const double A = 2.0 * kj + gam_of_kind[kf->kind], pref = lng ? 0.5 * dj->n * dj->n : 0.5 * s0;
-                co_T_ctx c = {pdists, N, j, kf, kj, A, co_lgam(A), dj->theta, log(dj->theta)};
+                co_T_ctx c = {pdists, N, j, kf, kj, A, co_lgam(A), dj->theta, log(dj->theta), 0.0};
                 double tlo, thi, marks[CO_CONV_MAX_MARKS], tolS[3];
                 int nm = 0;
                 co_conv_range_top(A, 2.0, &tlo, &thi);
+                c.tlo = tlo;
                 for (int m = 0; m < N; ++m) /* the other modes' cores */
                     if (m != j)
                         nm = co_core_marks(co_ln_mean(&pdists[m]), co_core_width(&pdists[m]), (thi - tlo) / CO_CONV_NINIT, dj->theta, marks, nm);
@@ -939,7 +1038,14 @@ int co_get_coal_ints_numerical_converged(const co_dist *pdists, int N, const co_
                     tolS[1] = A * dj->theta;
                     tolS[2] = A * (A + 1.0) * dj->theta * dj->theta;
                 }
-                co_conv_adaptive(tlo, thi, marks, nm, 3, NULL, 0, tol, tolS, CO_CONV_BUDGET, co_T_node, &c, T);
+                /* (the Long kernel's G(s) is only finitely smooth at s = x_t and 2 x_t -- the Beta(k, k) law of tau ends like
+                 * tau^(k-1) there -- and K15 converges slowly in the panels next to them: measured 1e-9 of scale at tol =
+                 * 1e-8 on random mixtures, against 1e-10 ... 1e-13 for the homogeneous kernels; its rules run at tol / 10) */
+                const double tol_T = lng ? 0.1 * tol : tol;
+                if (co_conv_walk_down_)
+                    co_conv_descending(tlo, thi, marks, nm, tol_T, tolS, CO_CONV_BUDGET, co_T_node, co_T_bound, &c, T);
+                else
+                    co_conv_adaptive(tlo, thi, marks, nm, 3, NULL, 0, tol_T, tolS, CO_CONV_BUDGET, co_T_node, &c, T);
                 if (!lng) { /* the mass below t_lo (1e-13 of the weight; a sizeable part of it for a shape clamped to eps) */
                     const double u_lo = exp(tlo);
                     T[0] += co_one_minus_w(pdists, N, j, u_lo * dj->theta, tlo + c.lth) * exp(A * tlo - co_lgam(A + 1.0));
