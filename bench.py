@@ -628,8 +628,9 @@ def _cfg4q_converged_variant(pkg, rank, world, measured, fixed_ms, n=CFG4Q_PARCE
     ok = np.isfinite(net)
     out = {"workload": f"cfg4q_converged: the cfg4q batch ({n} parcels/GPU, 3 Gamma modes, hydrodynamic kernel function) "
                        "in converged mode -- the DEFAULT of the NumericalCoalStyle drop-in: region integrals in closed form, an "
-                       "adaptive Gauss-Kronrod (7, 15) rule per mode (relative tolerance 1e-8, the reference's own quadgk "
-                       "rtol) for the weighting_fn split, all the rules of a parcel walked in one loop; error vs nested "
+                       "adaptive Gauss-Kronrod (7, 15) rule per mode for the weighting_fn split (panels walked from large sizes "
+                       "down, |K15 - G7| <= 1e-7 of the accumulated value, ended by a rigorous bound of what is left), all "
+                       "the rules of a parcel walked in one loop; error vs nested "
                        "adaptive quadrature of the reference integrals <= 1e-9 of scale (10-point rule: 3e-4 ... 1e-2)",
            "value": n * world / (ms * 1e-3), "unit": "parcel-RHS/s", "kernel_ms": ms,
            "kernel": f"cloudy_jit_quad_n3c{q}_hydro_f64" if plan.specialized else "coal_rhs_quad_kernel<3, 2, double, true>",

