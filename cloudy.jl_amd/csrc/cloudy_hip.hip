@@ -32,8 +32,9 @@ struct cloudy_plan {
     JitKernels jit;
     std::string jit_log;   // why not, when jit_on is false
     // thresholded plans compile their fused integrator on the first cloudy_ssprk33_steps call
-    mutable std::once_flag int_once, rs_once, rsint_once, tsit5_once;
+    mutable std::once_flag int_once, rs_once, rsint_once, tsit5_once, rsint512_once, rsint1024_once;
     mutable hipFunction_t int_ssprk33 = nullptr, rs_coal = nullptr, rs_int = nullptr, int_tsit5 = nullptr;
+    mutable hipFunction_t rs_int512 = nullptr, rs_int1024 = nullptr;  // the column integrator for 256 < nz <= 512 / 1024
     mutable std::string int_log;
 };
 
@@ -117,10 +118,12 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
         int nz = (int)r.nz, n_steps = r.n_steps;
         size_t n_columns = r.n / r.nz;
         double dt = r.dt, dz = r.dz;
-        const size_t cpb = kRainshaftBlock / r.nz;
+        const int part = jit_rainshaft_part(r.nz);
+        const unsigned bs = (unsigned)jit_rainshaft_block(part);
+        hipFunction_t fn = part == 3 ? plan->rs_int : part == 5 ? plan->rs_int512 : plan->rs_int1024;
+        const size_t cpb = bs / r.nz;
         void *args[] = {&nodes, &nz, &n_columns, &ld, &in, &out, &dt, &dz, &n_steps};
-        return hipModuleLaunchKernel(plan->rs_int, (unsigned)((n_columns + cpb - 1) / cpb), 1, 1, kRainshaftBlock, 1, 1, 0, r.stream,
-                                     args, nullptr);
+        return hipModuleLaunchKernel(fn, (unsigned)((n_columns + cpb - 1) / cpb), 1, 1, bs, 1, 1, 0, r.stream, args, nullptr);
     }
     if (r.op == OP_TSIT5) {
         double dt = r.dt;
@@ -208,10 +211,19 @@ int run(const cloudy_plan *plan, const LaunchReq &r) {
         return fail(CLOUDY_EUNSUPPORTED, "cloudy_tsit5_steps of a NumericalCoalStyle plan runs the kernel compiled for the plan "
                                          "(hiprtc); plan-time compilation is off or failed: %s", plan->int_log.c_str());
     if (use_jit && r.op == OP_RAINSHAFT_SSPRK33) {
-        std::call_once(plan->rsint_once,
-                       [&] { (void)jit_get_rainshaft_integrator(plan->h, plan->rs_int, plan->int_log); });
-        use_jit = plan->rs_int != nullptr && plan->h.mode != MODE_MOVING;  // otherwise the ahead-of-time integrator
+        const int part = jit_rainshaft_part(r.nz);
+        if (part == 3)
+            std::call_once(plan->rsint_once, [&] { (void)jit_get_rainshaft_integrator(plan->h, plan->rs_int, plan->int_log); });
+        else if (part == 5)
+            std::call_once(plan->rsint512_once, [&] { (void)jit_get_rainshaft_integrator(plan->h, plan->rs_int512, plan->int_log, 5); });
+        else
+            std::call_once(plan->rsint1024_once, [&] { (void)jit_get_rainshaft_integrator(plan->h, plan->rs_int1024, plan->int_log, 6); });
+        hipFunction_t fn = part == 3 ? plan->rs_int : part == 5 ? plan->rs_int512 : plan->rs_int1024;
+        use_jit = fn != nullptr && plan->h.mode != MODE_MOVING;  // otherwise the ahead-of-time integrator (nz <= 256)
     }
+    if (!use_jit && r.op == OP_RAINSHAFT_SSPRK33 && r.nz > (size_t)kRainshaftBlock)
+        return fail(CLOUDY_EUNSUPPORTED, "columns of %zu cells run the column integrator compiled for the plan (hiprtc, up to 1024 "
+                                         "cells); plan-time compilation is off or failed: %s", r.nz, plan->int_log.c_str());
     if (use_jit && r.op == OP_COAL && r.rainshaft) {
         std::call_once(plan->rs_once, [&] { (void)jit_get_rainshaft(plan->h, plan->rs_coal, plan->int_log); });
         use_jit = plan->rs_coal != nullptr;
@@ -860,11 +872,10 @@ int cloudy_rainshaft_ssprk33_steps(const cloudy_plan *plan, size_t nz, size_t n_
     if (plan->h.n_vel < 1) return fail(CLOUDY_EINVAL, "plan has no terminal-velocity coefficients (n_vel = 0)");
     if (plan->h.threshold_style != CLOUDY_FIXED_THRESHOLD)
         return fail(CLOUDY_EINVAL, "make_rainshaft_rhs uses FixedThreshold (rainshaft_helpers.jl:70)");
-    if (nz > (size_t)kBlock)
+    if (nz > 1024)
         return fail(CLOUDY_EUNSUPPORTED,
-                    "the fused column integrator keeps a column inside one workgroup: nz <= %d; step taller columns "
-                    "with cloudy_rainshaft_rhs",
-                    kBlock);
+                    "the fused column integrator keeps a column inside one workgroup: nz <= 1024 (256 without plan-time "
+                    "compilation); step taller columns with cloudy_rainshaft_rhs");
     if (n == 0) return CLOUDY_OK;
     LaunchReq r{OP_RAINSHAFT_SSPRK33, IN_MOMENTS, 1, 1, n, ld, u_in_dev, u_out_dev, nullptr, (hipStream_t)stream};
     r.dt = dt;

@@ -1568,7 +1568,10 @@ __global__ void __launch_bounds__(kBlock)
 // Every RHS evaluation first clamps negative moments of its argument to zero IN PLACE (rainshaft_helpers.jl:52 mutates
 // the array the integrator passed), which includes the FSAL evaluation on the final state of each step.
 // (SPEC: the plan constants Ag / Sg are compile-time objects of a kernel compiled for the plan, jit.hpp)
-template <int N, int P, int MODE, typename TIO, bool SPEC = false>
+// BS: workgroup size = cells per workgroup.  256 for columns of up to 256 cells (several columns per workgroup); the
+// plan-time compiled kernel also exists with 512 and 1024 threads for columns of up to 1024 cells, ONE column per
+// workgroup (round 4; taller columns would need a grid-wide exchange of the boundary flux).
+template <int N, int P, int MODE, typename TIO, bool SPEC = false, int BS = kRainshaftBlock>
 __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__restrict__ Ag, const SediArgs *__restrict__ Sg,
                                                        const double *__restrict__ nodes, int nz, size_t n_columns,
                                                        size_t ld, const TIO *u_in, TIO *u_out, double dt, double dz,
@@ -1576,7 +1579,6 @@ __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__rest
     // (workgroup size, 20-cell columns: 384 threads -- a finer ranking, 4 instead of 16 idle lanes -- measured 40 % slower,
     // two six-wave workgroups per CU overlap their per-stage barriers worse than three four-wave ones; 128 threads 8 %
     // slower, the ranking over 128 cells is too coarse)
-    constexpr int BS = kRainshaftBlock;
     __shared__ double sh_flux[N * 3][BS];
     const KArgs<N, P> &A = *Ag;
     const int cpb = BS / nz;       // whole columns per workgroup

@@ -289,13 +289,15 @@ int cloudy_rainshaft_sources(const cloudy_plan *plan, size_t n_cells, size_t ld,
 int cloudy_rainshaft_rhs(const cloudy_plan *plan, size_t nz, size_t n_columns, size_t ld, const void *mom_dev, double dz,
                          void *flux_work_dev, void *rhs_dev, void *stream);
 
-/* n_steps SSPRK33 steps of the rainshaft right-hand side above for n_columns independent columns of nz <= 256 cells
+/* n_steps SSPRK33 steps of the rainshaft right-hand side above for n_columns independent columns of nz <= 1024 cells
  * (what `solve(ODEProblem(rhs, m, tspan, p), SSPRK33(), dt = p.dt)` does in rainshaft_single_gamma.jl:52-53,
  * rainshaft_gamma_mixture.jl:59-60), in ONE launch: a workgroup owns whole columns, the state stays in registers over
  * all stages and steps and the upwind flux of the cell above is exchanged through LDS.  As in the reference, every RHS
  * evaluation first clamps negative moments of its argument to zero in place (rainshaft_helpers.jl:52), including the
  * FSAL evaluation on each step's result, so the returned state is clamped.  u_out_dev may equal u_in_dev.
- * CLOUDY_EUNSUPPORTED for nz > 256 (step those with cloudy_rainshaft_rhs). */
+ * nz <= 256: several columns per 256-thread workgroup; 256 < nz <= 1024 (round 4): one column per workgroup of 512 or 1024
+ * threads, in the kernel compiled for the plan (CLOUDY_EUNSUPPORTED without hiprtc).  CLOUDY_EUNSUPPORTED for nz > 1024:
+ * the reference's cell loop is unbounded in nz (rainshaft_helpers.jl:55-78); step such columns with cloudy_rainshaft_rhs. */
 int cloudy_rainshaft_ssprk33_steps(const cloudy_plan *plan, size_t nz, size_t n_columns, size_t ld,
                                    const void *u_in_dev, void *u_out_dev, double dz, double dt, int n_steps,
                                    void *stream);
