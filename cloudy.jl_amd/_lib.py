@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CLOUDY_HIP_LIB selects another build of the SAME C ABI (kernel A/B experiments); never a CPU library.
 LIB_PATH = os.environ.get("CLOUDY_HIP_LIB") or os.path.join(_HERE, "libcloudy_hip.so")
 
-MAX_MODES, MAX_P, MAX_VEL = 4, 5, 4
+MAX_MODES, MAX_P, MAX_VEL = 8, 8, 4
 OK, EINVAL, ENOTSYMMETRIC, EHIP, ENOMEM, EUNSUPPORTED, ENODEVICE, ECOMM = 0, -1, -2, -3, -4, -5, -6, -7
 COMM_ID_BYTES = 128
 

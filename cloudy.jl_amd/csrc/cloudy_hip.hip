@@ -65,16 +65,18 @@ int fail_hip(hipError_t e, const char *what) {
 
 constexpr int kSumBlocks = 1024;
 
+inline bool plan_beyond_aot(const HostPlan &h) { return h.N > CLOUDY_AOT_MAX_MODES || h.P > CLOUDY_AOT_MAX_P; }
+
 hipError_t dispatch(const HostPlan &h, const LaunchReq &r) {
     using Fn = hipError_t (*)(const HostPlan &, const LaunchReq &);
-    static const Fn table[CLOUDY_MAX_MODES][CLOUDY_MAX_P] = {
+    static const Fn table[CLOUDY_AOT_MAX_MODES][CLOUDY_AOT_MAX_P] = {
         {launch_n1_p1, launch_n1_p2, launch_n1_p3, launch_n1_p4, launch_n1_p5},
         {launch_n2_p1, launch_n2_p2, launch_n2_p3, launch_n2_p4, launch_n2_p5},
         {launch_n3_p1, launch_n3_p2, launch_n3_p3, launch_n3_p4, launch_n3_p5},
         {launch_n4_p1, launch_n4_p2, launch_n4_p3, launch_n4_p4, launch_n4_p5}};
-    if (h.N < 1 || h.N > CLOUDY_MAX_MODES || h.P < 1 || h.P > CLOUDY_MAX_P) return hipErrorInvalidValue;
+    if (h.N < 1 || h.N > CLOUDY_AOT_MAX_MODES || h.P < 1 || h.P > CLOUDY_AOT_MAX_P) return hipErrorInvalidValue;
     if (h.coal_style == CLOUDY_NUMERICAL_COAL && (r.op == OP_COAL || r.op == OP_SSPRK33)) {
-        static const Fn quad[CLOUDY_MAX_MODES] = {launch_quad_n1, launch_quad_n2, launch_quad_n3, launch_quad_n4};
+        static const Fn quad[CLOUDY_AOT_MAX_MODES] = {launch_quad_n1, launch_quad_n2, launch_quad_n3, launch_quad_n4};
         return quad[h.N - 1](h, r);
     }
     return table[h.N - 1][h.P - 1](h, r);
@@ -238,6 +240,11 @@ int run(const cloudy_plan *plan, const LaunchReq &r) {
         if (e != hipSuccess) return fail_hip(e, "specialised kernel launch");
         return CLOUDY_OK;
     }
+    if (plan_beyond_aot(plan->h))
+        return fail(CLOUDY_EUNSUPPORTED, "plans of more than %d modes or order > %d are served by the kernels compiled for the plan: "
+                                         "cloudy_coal_rhs, the rainshaft sources and the fused integrators on moment planes "
+                                         "(this call is outside that set, or its compilation failed: %s)",
+                    CLOUDY_AOT_MAX_MODES, CLOUDY_AOT_MAX_P - 1, plan->int_log.c_str());
     hipError_t e = dispatch(plan->h, r);
     if (e != hipSuccess) return fail_hip(e, "kernel launch");
     return CLOUDY_OK;
@@ -287,6 +294,8 @@ int build_host_plan(const cloudy_plan_desc *d, cloudy_plan **out, std::vector<do
     const int N = d->n_modes, P = numerical ? 1 : d->tensor_p;
     if (N < 1 || N > CLOUDY_MAX_MODES) return fail(CLOUDY_EUNSUPPORTED, "n_modes %d outside 1..%d", N, CLOUDY_MAX_MODES);
     if (P < 1 || P > CLOUDY_MAX_P) return fail(CLOUDY_EUNSUPPORTED, "tensor_p %d outside 1..%d", P, CLOUDY_MAX_P);
+    if (numerical && N > CLOUDY_AOT_MAX_MODES)
+        return fail(CLOUDY_EUNSUPPORTED, "NumericalCoalStyle plans have up to %d modes (n_modes = %d)", CLOUDY_AOT_MAX_MODES, N);
     if (!numerical && !d->kernel_c) return fail(CLOUDY_EINVAL, "kernel_c is NULL");
     if (numerical) {
         if (d->kernel_func < CLOUDY_KFUNC_CONSTANT || d->kernel_func > CLOUDY_KFUNC_LONG)
@@ -577,7 +586,7 @@ int cloudy_plan_create(const cloudy_plan_desc *d, cloudy_plan **out) {
         cloudy_plan_destroy(p);
         return fail_hip(e, "workspace allocation");
     }
-    {
+    if (!plan_beyond_aot(h)) {  // (the kernels compiled for the plan carry its constants as literals)
         LaunchReq prep{OP_PREPARE, IN_MOMENTS, 1, 0, 0, 0, nullptr, &h.kargs_dev, nullptr, nullptr};
         e = dispatch(h, prep);
         if (e != hipSuccess) {
@@ -591,13 +600,19 @@ int cloudy_plan_create(const cloudy_plan_desc *d, cloudy_plan **out) {
     // every (threshold mode, plane type) combination of cloudy_coal_rhs has a specialised kernel
     if (d->specialize >= 0 && !(env_off && d->specialize == 0)) {
         p->jit_on = jit_get(h, p->jit, p->jit_log);
-        if (!p->jit_on && d->specialize > 0) {
+        if (!p->jit_on && (d->specialize > 0 || plan_beyond_aot(h))) {
             int rc = fail(CLOUDY_EUNSUPPORTED, "plan-time specialisation failed: %.400s", p->jit_log.c_str());
             cloudy_plan_destroy(p);
             return rc;
         }
     } else {
         p->jit_log = "switched off (desc.specialize < 0 or CLOUDY_HIP_JIT=0)";
+        if (plan_beyond_aot(h)) {
+            int rc = fail(CLOUDY_EUNSUPPORTED, "plans of more than %d modes or order > %d need plan-time compilation, which is %s",
+                          CLOUDY_AOT_MAX_MODES, CLOUDY_AOT_MAX_P - 1, p->jit_log.c_str());
+            cloudy_plan_destroy(p);
+            return rc;
+        }
     }
     *out = p;
     return CLOUDY_OK;

@@ -19,7 +19,7 @@ using Cloudy, Cloudy.Coalescence, Cloudy.ParticleDistributions, Cloudy.EquationT
 
 const lib = get(ENV, "CLOUDY_HIP_LIB", joinpath(@__DIR__, "..", "cloudy.jl_amd", "libcloudy_hip.so"))
 
-const MAX_MODES, MAX_P, MAX_VEL = 4, 5, 4
+const MAX_MODES, MAX_P, MAX_VEL = 8, 8, 4
 const COMM_ID_BYTES = 128
 
 # mirrors `struct cloudy_plan_desc` of include/cloudy_hip.h field by field

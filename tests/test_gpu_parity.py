@@ -288,6 +288,93 @@ def test_mode_and_order_families_vs_oracle(gpu_cloudy, oracle, dist_types, P, th
     print(f"N={N} P={P} thr={thr}: max |hip-oracle|/scale = {worst:.2e}")
 
 
+def many_mode_moments(dist_types, n, seed):
+    """physical moments of N size classes between 1e-12 and 1e-4 kg (one decade each for N = 8), number densities falling
+    with size as in bench.synth_moments, 1 % degenerate parcels per mode; -> (moments, mask of the parcels without a degenerate mode)"""
+    N = len(dist_types)
+    regular = np.ones(n, dtype=bool)
+    rng = np.random.Generator(np.random.Philox(key=seed))
+    edges = np.logspace(-12, -4, N + 1)
+    rows = []
+    for i, t in enumerate(dist_types):
+        hi = 1e9 * 10.0 ** (-1.5 * i * 8 / N)
+        m = bench._gamma_mode(rng, n, hi * 1e-3, hi, 0.5 if i == 0 else 1.0, 7.0, edges[i], edges[i + 1])
+        z = rng.choice(n, max(n // 100, 1), replace=False)
+        m[:, z[: len(z) // 2]] = 0.0
+        m[2, z[len(z) // 2:]] = m[1, z[len(z) // 2:]] ** 2 / m[0, z[len(z) // 2:]]
+        regular[z] = False
+        rows += [m[0], m[1]] + ([m[2]] if t in (1, 3) else [])
+    return np.ascontiguousarray(np.stack(rows)), regular
+
+
+@pytest.mark.parametrize("dist_types,P,thr,moving", [
+    ([1, 0, 1, 1, 1, 1], 2, (INF,) * 6, False),                                   # six modes, no thresholds
+    ([1, 1, 1, 0, 1], 3, (1e-10, 1e-9, 1e-8, 1e-7, INF), False),                  # five modes, all thresholded
+    ([1] * 8, 2, (1e-11, 1e-10, INF, 1e-8, 1e-7, 1e-6, 1e-5, INF), False),        # eight modes
+    ([1, 1], 7, (INF, INF), False), ([1, 1], 8, (5e-10, INF), False),             # order 6 / 7 tensors
+    ([1, 1, 1], 6, (1e-9, 1e-7, INF), False),
+    ([1] * 6, 2, (0.9, 0.95, 0.99, 0.9, 0.99, 1.0), True),                        # six modes, MovingThreshold
+])
+def test_plans_beyond_the_ahead_of_time_families(gpu_cloudy, oracle, dist_types, P, thr, moving):
+    """The reference bounds neither the number of modes nor the tensor order (CoalescenceData{N, P}, Coalescence.jl:55-104).
+    Plans of more than 4 modes or order > 4 run the kernels compiled for the plan at plan creation (include/cloudy_hip.h,
+    CLOUDY_AOT_MAX_MODES): RHS against the oracle to the same tolerances as the smaller families, the fused integrators
+    against stepping with that RHS, and a loud CLOUDY_EUNSUPPORTED from the entry points that have no such kernel."""
+    cloudy = gpu_cloudy
+    N = len(dist_types)
+    rng = np.random.default_rng(1000 * N + P)
+    kc = np.zeros((N, N, P, P))
+    for j in range(N):
+        for k in range(j, N):
+            a = rng.uniform(0, 1, (P, P)) * (rng.uniform(0, 1, (P, P)) < 0.6)
+            a = (a + a.T) * np.array([[10.0 ** (3 * (x + y)) for y in range(P)] for x in range(P)])
+            kc[j, k] = kc[k, j] = a
+    par, op, ts = make_case(cloudy, oracle, dist_types, kc, thr, bench.NORMS, moving=moving)
+    thresholded = moving or any(np.isfinite(thr))
+    n = 512 if thresholded else 20_000
+    mom, regular = many_mode_moments(dist_types, n, seed=11 + N + P)
+    d = run_rhs(cloudy, par, mom, ts)
+    plan = par.coal_data.plan(dist_types)
+    assert plan.specialized                                                # the plan-time compiled kernel ran
+    want, scale = oracle.rhs_coal_batch(op, mom, with_scale=True)
+    worst = assert_close_scaled(d, want, scale, TOL_QUAD if thresholded else TOL_POLY, f"N={N} P={P}")
+    rows = np.cumsum([0] + [2 if t in (0, 2) else 3 for t in dist_types])[:-1] + 1
+    ok = np.isfinite(d).all(axis=0)
+    assert ok.mean() > 0.9
+    mass = np.abs(d[rows][:, ok].sum(axis=0)) / scale[rows][:, ok].sum(axis=0)
+    print(f"N={N} P={P} thr={thr}: max |hip-oracle|/scale = {worst:.2e}, mass-rate residual {mass.max():.1e}")
+    assert mass.max() < 1e-12
+    # fused integrators of the same plan against host stepping with the device RHS (SSPRK33: three evaluations per step)
+    u0 = dev(cloudy, mom)
+    with np.errstate(all="ignore"):   # a step that changes no moment of any parcel by more than ~1e-3 of itself
+        dt = 1e-3 * float(np.min(np.where((np.abs(d) > 0) & (mom > 0) & (ok & regular), mom / np.abs(d), np.inf)))
+    assert 0 < dt < np.inf
+    out = cloudy.DeviceArray.zeros(*mom.shape)
+    cloudy.solve_ssprk33(par, u0, dt, 1, out=out)
+    f = lambda u: run_rhs(cloudy, par, np.ascontiguousarray(u), ts)
+    u1 = mom + dt * f(mom)
+    u2 = 0.75 * mom + 0.25 * (u1 + dt * f(u1))
+    u3 = mom / 3.0 + (2.0 / 3.0) * (u2 + dt * f(u2))
+    got = out.to_numpy()
+    fin = np.isfinite(u3).all(axis=0) & np.isfinite(got).all(axis=0) & regular
+    assert fin.mean() > 0.85 and (np.abs(got - mom) / np.maximum(np.abs(mom), 1e-300))[:, fin].max() > 1e-4   # a real step
+    bound = np.maximum(np.maximum(np.abs(mom), dt * scale), 1e-300)
+    r3 = (np.abs(got - u3) / bound)[:, fin].max()
+    out5 = cloudy.DeviceArray.zeros(*mom.shape)
+    cloudy.solve_tsit5(par, u0, dt, 1, out=out5)
+    g5 = out5.to_numpy()
+    # one Tsit5 step and one SSPRK33 step of the same dt differ by O(dt^4) of the state -- where the RHS is smooth over the
+    # step: a parcel sitting exactly on a clamp of the closure inversion (zero variance, an empty mode) is not, and dt
+    # is sized for the regular parcels
+    fin &= np.isfinite(g5).all(axis=0)
+    r5 = (np.abs(g5 - got) / bound)[:, fin].max()
+    print(f"dt = {dt:.2e}: fused SSPRK33 vs three RHS calls {r3:.1e}, Tsit5 vs SSPRK33 {r5:.1e} (of max(|u|, dt scale))")
+    assert r3 <= 1e-12 and r5 <= 1e-6
+    with pytest.raises(cloudy.CloudyError) as e:      # per-mode diagnostics: ahead-of-time kernels only
+        cloudy.update_dist_from_moments(plan, u0)
+    assert e.value.code == cloudy._lib.EUNSUPPORTED and "compiled for the plan" in str(e.value)
+
+
 def test_moving_threshold_vs_oracle_and_threshold_kats(gpu_cloudy, oracle, kats):
     """MovingThreshold (Coalescence.jl:152-185; box_gamma_mix_moving.jl:31: percentiles (0.99, 0.99, 0.99, 1.0))."""
     cloudy = gpu_cloudy

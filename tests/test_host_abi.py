@@ -259,7 +259,7 @@ def test_plan_validation_errors_precede_device_lookup(cloudy):
     assert rc == E.EINVAL and "norms must be positive" in msg         # helper_functions.jl:44-46
     rc, _ = create(lambda d, c: setattr(d, "n_modes", 9))
     assert rc == E.EUNSUPPORTED
-    rc, _ = create(lambda d, c: setattr(d, "tensor_p", 6))
+    rc, _ = create(lambda d, c: setattr(d, "tensor_p", 9))
     assert rc == E.EUNSUPPORTED
     rc, _ = create(lambda d, c: d.dist_type.__setitem__(0, 9))
     assert rc == E.EINVAL
@@ -418,7 +418,8 @@ def test_polyfit_reference_kats(cloudy):
 
 
 @pytest.mark.parametrize("case", ["cfg2", "cfg3a", "cfg3a_f32", "cfg3b", "cfg3b_f32fast", "cfg3_moving", "cfg4",
-                                  "n4p5_mixed"])
+                                  "n4p5_mixed", "n6p2_beyond_aot", "n5p3_fixed_beyond_aot", "n2p8_fixed_beyond_aot",
+                                  "n6p2_moving_beyond_aot"])
 def test_plan_time_translation_units_compile_without_a_gpu(cloudy, case):
     """cloudy_jit_selfcheck: the kernel sources embedded in libcloudy_hip.so plus the generated constexpr plan compile
     with hiprtc for gfx950 here, on the CPU -- the build check of the plan-time specialisation (jit.hpp).  Thresholded
@@ -436,6 +437,16 @@ def test_plan_time_translation_units_compile_without_a_gpu(cloudy, case):
                 c = rng.uniform(0.1, 1.0, (P, P)) * (rng.random((P, P)) < 0.5)
                 kc[j, k] = kc[k, j] = np.triu(c) + np.triu(c, 1).T
         dist_types, thr, dtype = [0, 1, 2, 1], (1e-9, 1e-8, 1e-7, INF), 1
+    elif case.endswith("beyond_aot"):   # more than CLOUDY_AOT_MAX_MODES modes / order > 4: plan-time compiled kernels only
+        N, P, thr = {"n6p2_beyond_aot": (6, 2, (INF,) * 6), "n5p3_fixed_beyond_aot": (5, 3, (1e-10, 1e-9, 1e-8, 1e-7, INF)),
+                     "n2p8_fixed_beyond_aot": (2, 8, (5e-10, INF)), "n6p2_moving_beyond_aot": (6, 2, (0.9,) * 5 + (1.0,))}[case]
+        rng = np.random.default_rng(N * 10 + P)
+        kc = np.zeros((N, N, P, P))
+        for j in range(N):
+            for k in range(j, N):
+                c = rng.uniform(0.1, 1.0, (P, P)) * (rng.random((P, P)) < 0.6)
+                kc[j, k] = kc[k, j] = np.triu(c) + np.triu(c, 1).T
+        dist_types, moving = [1] * N, int("moving" in case)
     else:
         name = {"cfg3a_f32": "cfg3a", "cfg3b_f32fast": "cfg3b", "cfg3_moving": "cfg3b"}.get(case, case)
         spec = bench.workload_spec(name)
