@@ -36,6 +36,9 @@ struct cloudy_plan {
     mutable hipFunction_t int_ssprk33 = nullptr, rs_coal = nullptr, rs_int = nullptr, int_tsit5 = nullptr;
     mutable hipFunction_t rs_int512 = nullptr, rs_int1024 = nullptr;  // the column integrator for 256 < nz <= 512 / 1024
     mutable std::string int_log;
+    // plans beyond the ahead-of-time families: diagnostics and parameter-plane entry points compiled on first use (jit.hpp part 7)
+    mutable std::once_flag diag_once;
+    mutable JitDiag diag;
 };
 
 namespace {
@@ -194,6 +197,52 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
     return hipModuleLaunchKernel(plan->jit.ppl1, g1, 1, 1, kBlock, 1, 1, 0, r.stream, args, nullptr);
 }
 
+// the diagnostics of a plan beyond the ahead-of-time families: argument lists as the kernels of launch_impl.hpp take them,
+// minus the constant block (a compile-time object of the module)
+hipError_t launch_diag(const cloudy_plan *plan, const LaunchReq &r) {
+    const HostPlan &h = plan->h;
+    size_t n = r.n, ld = r.ld;
+    const void *in = r.in;
+    void *out = r.out, *out2 = r.out2;
+    const double *nodes = h.nodes_dev;
+    const unsigned g = (unsigned)((n + kBlock - 1) / kBlock);
+    hipFunction_t fn = nullptr;
+    void *args[8];
+    int na = 0;
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+    const double *s_dev = r.s_dev;
+    switch (r.op) {
+    case OP_UPDATE_DIST:
+        fn = plan->diag.update_dist;
+        args[na++] = &n, args[na++] = &ld, args[na++] = &in, args[na++] = &out;
+        break;
+    case OP_FINITE_2D:
+        fn = plan->diag.finite_2d;
+        args[na++] = &nodes, args[na++] = &n, args[na++] = &ld, args[na++] = &in, args[na++] = &out, args[na++] = &out2;
+        break;
+    case OP_SEDI:
+        fn = plan->diag.sedi_flux;
+        args[na++] = &n, args[na++] = &ld, args[na++] = &in, args[na++] = &out;
+        break;
+    case OP_COND:
+        fn = plan->diag.cond_evap;
+        d0 = r.coef, d1 = r.s_scalar;
+        args[na++] = &d0, args[na++] = &d1, args[na++] = &s_dev, args[na++] = &n, args[na++] = &ld, args[na++] = &in, args[na++] = &out;
+        break;
+    case OP_NQ:
+        fn = plan->diag.standard_nq;
+        d0 = r.s_scalar / h.norms[1], d1 = h.norms[0], d2 = h.norms[1];
+        args[na++] = &d0, args[na++] = &d1, args[na++] = &d2, args[na++] = &n, args[na++] = &ld, args[na++] = &in, args[na++] = &out;
+        break;
+    case OP_COAL:
+        fn = plan->diag.coal_ints;
+        args[na++] = &nodes, args[na++] = &n, args[na++] = &ld, args[na++] = &in, args[na++] = &out;
+        break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipModuleLaunchKernel(fn, g, 1, 1, kBlock, 1, 1, 0, r.stream, args, nullptr);
+}
+
 int run(const cloudy_plan *plan, const LaunchReq &r) {
     if (plan->h.coal_style == CLOUDY_NUMERICAL_COAL &&
         (r.op == OP_FINITE_2D || r.op == OP_RAINSHAFT_SSPRK33 || r.rainshaft))
@@ -240,11 +289,23 @@ int run(const cloudy_plan *plan, const LaunchReq &r) {
         if (e != hipSuccess) return fail_hip(e, "specialised kernel launch");
         return CLOUDY_OK;
     }
-    if (plan_beyond_aot(plan->h))
-        return fail(CLOUDY_EUNSUPPORTED, "plans of more than %d modes or order > %d are served by the kernels compiled for the plan: "
-                                         "cloudy_coal_rhs, the rainshaft sources and the fused integrators on moment planes "
-                                         "(this call is outside that set, or its compilation failed: %s)",
+    if (plan_beyond_aot(plan->h)) {
+        // no ahead-of-time kernel exists for this (N, P): the diagnostics and the parameter-plane entry points run the
+        // bodies of their ahead-of-time kernels compiled for the plan (jit.hpp part 7, on first use)
+        const bool diag_op = !r.rainshaft && (r.op == OP_UPDATE_DIST || r.op == OP_FINITE_2D || r.op == OP_SEDI || r.op == OP_COND ||
+                                              r.op == OP_NQ || (r.op == OP_COAL && r.input_kind == IN_PARAMS));
+        if (diag_op && plan->jit_on) {
+            std::call_once(plan->diag_once, [&] { (void)jit_get_diag(plan->h, plan->diag, plan->int_log); });
+            if (plan->diag.ok) {
+                hipError_t e = launch_diag(plan, r);
+                if (e != hipSuccess) return fail_hip(e, "diagnostic kernel launch");
+                return CLOUDY_OK;
+            }
+        }
+        return fail(CLOUDY_EUNSUPPORTED, "plans of more than %d modes or order > %d are served by the kernels compiled for the plan "
+                                         "(this call has none, or its compilation failed: %s)",
                     CLOUDY_AOT_MAX_MODES, CLOUDY_AOT_MAX_P - 1, plan->int_log.c_str());
+    }
     hipError_t e = dispatch(plan->h, r);
     if (e != hipSuccess) return fail_hip(e, "kernel launch");
     return CLOUDY_OK;
@@ -641,6 +702,7 @@ int cloudy_jit_selfcheck(const cloudy_plan_desc *d, const char *arch) {
     if (ok && !numerical && p->h.n_vel > 0 && p->h.mode != MODE_MOVING)
         ok = jit_compile(jit_source(p->h, 3), a, true, code, log);                     // fused column integrator
     if (ok && p->h.dtype != CLOUDY_F32_FAST) ok = jit_compile(jit_source(p->h, 4), a, true, code, log);  // cloudy_tsit5_steps
+    if (ok && !numerical && plan_beyond_aot(p->h)) ok = jit_compile(jit_source(p->h, 7), a, false, code, log);  // diagnostics
     delete p;
     if (!ok) return fail(CLOUDY_EUNSUPPORTED, "plan-time compilation failed: %.440s", log.c_str());
     return CLOUDY_OK;

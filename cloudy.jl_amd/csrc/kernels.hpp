@@ -1442,8 +1442,7 @@ __global__ void __launch_bounds__(BS)
 // ---- diagnostics / the callers either side of the operator ---------------------------------------
 
 template <int N, int P>
-__global__ void __launch_bounds__(kBlock)
-    update_dist_kernel(const KArgs<N, P> A, size_t n, size_t ld, const double *__restrict__ in,
+__device__ __forceinline__ void update_dist_body(const KArgs<N, P> &A, size_t n, size_t ld, const double *__restrict__ in,
                        double *__restrict__ params) {
     // one parcel per lane, no grid-stride loop: a parcel loop would let LICM hoist every libm polynomial
     // constant of the body into registers for the whole kernel (measured: 256 VGPRs + spills vs ~100).
@@ -1459,11 +1458,16 @@ __global__ void __launch_bounds__(kBlock)
         }
     }
 }
+template <int N, int P>
+__global__ void __launch_bounds__(kBlock)
+    update_dist_kernel(const KArgs<N, P> A, size_t n, size_t ld, const double *__restrict__ in,
+                       double *__restrict__ params) {
+    update_dist_body<N, P>(A, n, ld, in, params);
+}
 
 // get_finite_2d_integrals (Coalescence.jl:200-244) and the thresholds it used; F planes (i, p1, p2)
 template <int N, int P, int MODE>
-__global__ void __launch_bounds__(kBlock)
-    finite_2d_kernel(const KArgs<N, P> A, const double *__restrict__ nodes, size_t n, size_t ld,
+__device__ __forceinline__ void finite_2d_body(const KArgs<N, P> &A, const double *__restrict__ nodes, size_t n, size_t ld,
                      const double *__restrict__ in, double *__restrict__ F, double *__restrict__ thr_out) {
     constexpr int M = P + 2;
     constexpr int T = M * (M + 1) / 2;
@@ -1530,6 +1534,12 @@ __global__ void __launch_bounds__(kBlock)
         }
     }
 }
+template <int N, int P, int MODE>
+__global__ void __launch_bounds__(kBlock)
+    finite_2d_kernel(const KArgs<N, P> A, const double *__restrict__ nodes, size_t n, size_t ld,
+                     const double *__restrict__ in, double *__restrict__ F, double *__restrict__ thr_out) {
+    finite_2d_body<N, P, MODE>(A, nodes, n, ld, in, F, thr_out);
+}
 
 #ifdef CLOUDY_ABLATE_BARRIER
 #define CLOUDY_STAGE_BARRIER() ((void)0)
@@ -1543,8 +1553,7 @@ __global__ void __launch_bounds__(kBlock)
 constexpr int kRainshaftBlock = CLOUDY_RS_BLOCK;  // workgroup size of the fused column integrator
 
 template <int N, int P, typename TIO>
-__global__ void __launch_bounds__(kBlock)
-    sedi_flux_kernel(const KArgs<N, P> A, const SediArgs S, size_t n, size_t ld, const TIO *__restrict__ in,
+__device__ __forceinline__ void sedi_flux_body(const KArgs<N, P> &A, const SediArgs &S, size_t n, size_t ld, const TIO *__restrict__ in,
                      TIO *__restrict__ out) {
     // one parcel per lane, no grid-stride loop: a parcel loop would let LICM hoist every libm polynomial
     // constant of the body into registers for the whole kernel (measured: 256 VGPRs + spills vs ~100).
@@ -1559,6 +1568,12 @@ __global__ void __launch_bounds__(kBlock)
             for (int j = 0; j < 3; ++j)
                 if (j < A.np[m]) out[(size_t)(A.off[m] + j) * ld + i] = (TIO)(fl[m][j] * A.out_scale[3 * m + j]);
     }
+}
+template <int N, int P, typename TIO>
+__global__ void __launch_bounds__(kBlock)
+    sedi_flux_kernel(const KArgs<N, P> A, const SediArgs S, size_t n, size_t ld, const TIO *__restrict__ in,
+                     TIO *__restrict__ out) {
+    sedi_flux_body<N, P, TIO>(A, S, n, ld, in, out);
 }
 
 // solve(ODEProblem(make_rainshaft_rhs(...), m, tspan, p), SSPRK33(), dt) of the rainshaft drivers
@@ -1715,8 +1730,7 @@ __global__ void __launch_bounds__(kRainshaftBlock)
 //   d(mom_j)/dt = 3 xi s j M_{j - 2/3} (4 pi/3)^(2/3) / rho_l^(1/3)   (0-based order j; zero for j = 0)
 // `coef` = 3 xi_normalised (4 pi/3)^(2/3) / rho_l^(1/3) is folded on the host; s is a scalar or one value per parcel.
 template <int N, int P, typename TIO>
-__global__ void __launch_bounds__(kBlock)
-    cond_evap_kernel(const KArgs<N, P> A, double coef, double s_scalar, const double *__restrict__ s_dev, size_t n,
+__device__ __forceinline__ void cond_evap_body(const KArgs<N, P> &A, double coef, double s_scalar, const double *__restrict__ s_dev, size_t n,
                      size_t ld, const TIO *__restrict__ in, TIO *__restrict__ out) {
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) {
@@ -1744,14 +1758,19 @@ __global__ void __launch_bounds__(kBlock)
         }
     }
 }
+template <int N, int P, typename TIO>
+__global__ void __launch_bounds__(kBlock)
+    cond_evap_kernel(const KArgs<N, P> A, double coef, double s_scalar, const double *__restrict__ s_dev, size_t n,
+                     size_t ld, const TIO *__restrict__ in, TIO *__restrict__ out) {
+    cond_evap_body<N, P, TIO>(A, coef, s_scalar, s_dev, n, ld, in, out);
+}
 
 // get_standard_N_q, ParticleDistributions.jl:634-687 (cloud / rain diagnostics by a size cutoff): 4 planes
 // (N_liq, N_rai, M_liq, M_rai) in physical units from partial_moment (:226-285):
 //   Gamma / Exponential: n theta^q Gamma(q+k)/Gamma(k) P(q+k, x_c/theta) = M_q P(q+k, x_c/theta)
 //   Monodisperse:        M_q if x_c >= theta else 0
 template <int N, int P, typename TIO>
-__global__ void __launch_bounds__(kBlock)
-    standard_nq_kernel(const KArgs<N, P> A, double cutoff_n, double n0, double m0, size_t n, size_t ld,
+__device__ __forceinline__ void standard_nq_body(const KArgs<N, P> &A, double cutoff_n, double n0, double m0, size_t n, size_t ld,
                        const TIO *__restrict__ in, TIO *__restrict__ out) {
     const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) {
@@ -1794,6 +1813,12 @@ __global__ void __launch_bounds__(kBlock)
         out[(size_t)2 * ld + i] = (TIO)(Ml * n0 * m0);
         out[(size_t)3 * ld + i] = (TIO)(Mr * n0 * m0);
     }
+}
+template <int N, int P, typename TIO>
+__global__ void __launch_bounds__(kBlock)
+    standard_nq_kernel(const KArgs<N, P> A, double cutoff_n, double n0, double m0, size_t n, size_t ld,
+                       const TIO *__restrict__ in, TIO *__restrict__ out) {
+    standard_nq_body<N, P, TIO>(A, cutoff_n, n0, m0, n, ld, in, out);
 }
 
 }  // namespace cloudy

@@ -76,13 +76,14 @@ extern "C" {
 
 #define CLOUDY_MAX_MODES 8  /* N: number of sub-distributions */
 #define CLOUDY_MAX_P 8      /* P = tensor order + 1 */
-/* Plans of up to CLOUDY_AOT_MAX_MODES modes and order <= 4 (P <= CLOUDY_AOT_MAX_P; the reference's examples stop at 3
- * modes and order 4, box_gamma_mixture_hydro.jl:23) have ahead-of-time compiled kernels behind every entry point.  Larger
- * AnalyticalCoalStyle plans (the reference's types bound neither N nor the order, Coalescence.jl:55-104) are served by the
- * kernels compiled for the plan at cloudy_plan_create (hiprtc must be loadable; otherwise CLOUDY_EUNSUPPORTED there):
- * cloudy_coal_rhs, cloudy_rainshaft_sources / _rhs, the fused integrators (cloudy_ssprk33_steps, cloudy_tsit5_steps,
- * cloudy_rainshaft_ssprk33_steps) and the plane reductions.  The per-mode diagnostics and the parameter-plane inputs of
- * such a plan return CLOUDY_EUNSUPPORTED, and so does a NumericalCoalStyle plan of more than CLOUDY_AOT_MAX_MODES modes. */
+/* Plans of up to CLOUDY_AOT_MAX_MODES modes and order <= 4 (P <= CLOUDY_AOT_MAX_P; the reference's examples stop at 4
+ * modes and order 4, box_gamma_mixture_4modes.jl:23, box_gamma_mixture_hydro.jl:23) have ahead-of-time compiled kernels
+ * behind every entry point.  Larger AnalyticalCoalStyle plans (the reference's types bound neither N nor the order,
+ * Coalescence.jl:55-104) run kernels compiled for the plan with hiprtc: the RHS / rainshaft / integrator kernels at
+ * cloudy_plan_create (CLOUDY_EUNSUPPORTED there when plan-time compilation is off or fails -- there is no other path), the
+ * per-mode diagnostics and the parameter-plane entry points (cloudy_update_dist_from_moments, cloudy_get_coal_ints,
+ * cloudy_get_finite_2d_integrals, cloudy_compute_thresholds, cloudy_sedimentation_flux, cloudy_cond_evap_rhs,
+ * cloudy_standard_N_q) on their first call.  A NumericalCoalStyle plan has at most CLOUDY_AOT_MAX_MODES modes. */
 #define CLOUDY_AOT_MAX_MODES 4
 #define CLOUDY_AOT_MAX_P 5
 #define CLOUDY_MAX_VEL 4    /* terms of the terminal-velocity power series */

@@ -319,7 +319,8 @@ def test_plans_beyond_the_ahead_of_time_families(gpu_cloudy, oracle, dist_types,
     """The reference bounds neither the number of modes nor the tensor order (CoalescenceData{N, P}, Coalescence.jl:55-104).
     Plans of more than 4 modes or order > 4 run the kernels compiled for the plan at plan creation (include/cloudy_hip.h,
     CLOUDY_AOT_MAX_MODES): RHS against the oracle to the same tolerances as the smaller families, the fused integrators
-    against stepping with that RHS, and a loud CLOUDY_EUNSUPPORTED from the entry points that have no such kernel."""
+    against stepping with that RHS, every diagnostic entry point against the oracle, and a loud CLOUDY_EUNSUPPORTED when
+    plan-time compilation is switched off."""
     cloudy = gpu_cloudy
     N = len(dist_types)
     rng = np.random.default_rng(1000 * N + P)
@@ -370,9 +371,56 @@ def test_plans_beyond_the_ahead_of_time_families(gpu_cloudy, oracle, dist_types,
     r5 = (np.abs(g5 - got) / bound)[:, fin].max()
     print(f"dt = {dt:.2e}: fused SSPRK33 vs three RHS calls {r3:.1e}, Tsit5 vs SSPRK33 {r5:.1e} (of max(|u|, dt scale))")
     assert r3 <= 1e-12 and r5 <= 1e-6
-    with pytest.raises(cloudy.CloudyError) as e:      # per-mode diagnostics: ahead-of-time kernels only
-        cloudy.update_dist_from_moments(plan, u0)
-    assert e.value.code == cloudy._lib.EUNSUPPORTED and "compiled for the plan" in str(e.value)
+    # ---- the diagnostics and the parameter-plane entry points of such a plan: the bodies of the ahead-of-time kernels compiled
+    # for the plan on first use (jit.hpp part 7)
+    prm_d = cloudy.update_dist_from_moments(plan, u0)
+    prm, prm_o = prm_d.to_numpy(), oracle.update_dist_batch(op, mom)
+    assert np.allclose(prm[:, regular], prm_o[:, regular], rtol=1e-14, atol=0)
+    nmm, n2d, thr_n, _, mom_norms = plan.get()
+    ci = cloudy.get_coal_ints(cloudy.AnalyticalCoalStyle(), (dist_types, prm_d), par.coal_data, ts).to_numpy()
+    assert_close_scaled(ci * mom_norms[:, None], want, scale, TOL_QUAD if thresholded else TOL_POLY, "get_coal_ints on (n, theta, k) planes")
+    thr_dev = cloudy.compute_thresholds(plan, prm_d).to_numpy()
+    M = P + 2
+    if not moving:
+        assert np.all(thr_dev == np.asarray(thr_n)[:, None])
+        F = cloudy.get_finite_2d_integrals(plan, prm_d).to_numpy().reshape(N, M, M, n)
+        worstF = 0.0
+        for i in np.flatnonzero(regular)[:: max(n // 12, 1)][:12]:
+            pd = [oracle.make_dist(dist_types[m], prm_o[3 * m, i], prm_o[3 * m + 1, i], prm_o[3 * m + 2, i]) for m in range(N)]
+            mo = oracle.get_moments_matrix(pd, M, nmm)
+            Fo = oracle.get_finite_2d_integrals(pd, [float(t) for t in thr_n], mo, [int(q) for q in n2d])
+            mm = np.maximum(mo[:, :, None] * mo[:, None, :], 1e-300)
+            worstF = max(worstF, float((np.abs(F[..., i] - Fo) / mm).max()))
+        print(f"get_finite_2d_integrals vs oracle: {worstF:.1e} of M_p M_q")
+        assert worstF <= TOL_QUAD
+    else:
+        for i in np.flatnonzero(regular)[:5]:
+            for m in range(N - 1):
+                od = oracle.make_dist(dist_types[m], prm_o[3 * m, i], prm_o[3 * m + 1, i], prm_o[3 * m + 2, i])
+                assert thr_dev[m, i] == pytest.approx(oracle.compute_threshold(od, thr[m]), rel=1e-11)
+    xi, sv = 1e-8, 0.03
+    dmc = cloudy.DeviceArray.zeros(*mom.shape)
+    cloudy.rhs_condensation(plan, dmc, u0, xi, sv)
+    assert np.allclose(dmc.to_numpy()[:, regular], oracle.rhs_condensation_batch(op, xi, sv, mom)[:, regular], rtol=1e-11, atol=0)
+    q = cloudy.get_standard_N_q(plan, u0, 1e-9).to_numpy()
+    for i in np.flatnonzero(regular)[:8]:
+        pd = [oracle.make_dist(dist_types[m], prm_o[3 * m, i], prm_o[3 * m + 1, i], prm_o[3 * m + 2, i]) for m in range(N)]
+        w = oracle.get_standard_N_q(pd, 1e-9 / bench.NORMS[1]) * np.array([1e6, 1e6, 1e6 * 1e-9, 1e6 * 1e-9])
+        assert np.allclose(q[:, i], w, rtol=1e-10, atol=1e-14 * np.abs(w).max())
+    if not moving:   # make_rainshaft_rhs uses FixedThreshold (rainshaft_helpers.jl:70)
+        vel = ((50.0, 1.0 / 6),)
+        par_v, op_v, _ = make_case(cloudy, oracle, dist_types, kc, thr, bench.NORMS, vel=vel)
+        plan_v = par_v.coal_data.plan(dist_types, vel=vel)
+        fl = cloudy.get_sedimentation_flux(plan_v, u0).to_numpy()
+        cs, sf = cloudy.rainshaft_sources(plan_v, u0)
+        wcs, wsf = oracle.rainshaft_cell_batch(op_v, mom)
+        assert np.allclose(fl[:, regular], wsf[:, regular], rtol=1e-11, atol=0)
+        assert np.allclose(sf.to_numpy()[:, regular], wsf[:, regular], rtol=1e-11, atol=0)
+        assert np.all(np.abs(cs.to_numpy() - wcs)[:, regular] <= TOL_QUAD * np.maximum(scale, 1e-300)[:, regular])
+    # without plan-time compilation such a plan cannot exist: a loud error, no fallback
+    with pytest.raises(cloudy.CloudyError) as e:
+        par.coal_data.plan(dist_types, specialize=-1)
+    assert e.value.code == cloudy._lib.EUNSUPPORTED and "plan-time compilation" in str(e.value)
 
 
 def test_moving_threshold_vs_oracle_and_threshold_kats(gpu_cloudy, oracle, kats):

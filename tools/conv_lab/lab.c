@@ -107,6 +107,8 @@ typedef struct {
     int imax;
     int desc;        /* 1: walk the initial panels from thi down to tlo */
     double tol_skip; /* > 0: skip an initial panel whose rigorous bound is below tol_skip * max(|acc|, floor * scale) */
+    int est;         /* 0: |K15 - G7|; 1: QUADPACK qk15's estimate |K - G| min(1, (200 |K - G| / resasc)^1.5) */
+    double est_pow, est_fac;
 } lab_params;
 
 int lab_T_rule(int N, int j, const int *type, const double *th, const double *k, double gam, const lab_params *P, double *T,
@@ -234,19 +236,27 @@ int lab_T_rule(int N, int j, const int *type, const double *th, const double *k,
         unsigned i = 0;
         for (;;) {
             const double w = ldexp(h, -L), hw = 0.5 * w, c = (a0 + w * i) + hw;
-            double K[3] = {0, 0, 0}, G[3] = {0, 0, 0}, vals[3];
+            double K[3] = {0, 0, 0}, G[3] = {0, 0, 0}, vals[3], fv[15][3];
             for (int g = 0; g < 15; ++g) {
                 node(&r, c + hw * GKX[g], vals);
                 st->nodes++;
                 for (int o = 0; o < 3; ++o) {
+                    fv[g][o] = vals[o];
                     K[o] += GKWK[g] * vals[o];
                     if (g & 1) G[o] += GKWG[g] * vals[o];
                 }
             }
             st->evals++;
             int ok = 1;
-            for (int o = 0; o < 3; ++o)
-                if (fabs(K[o] - G[o]) * hw > P->tol * fmax(fabs(out[o] + K[o] * hw), P->floor_ * scaleS[o])) ok = 0;
+            for (int o = 0; o < 3; ++o) {
+                double e = fabs(K[o] - G[o]);
+                if (P->est) {
+                    double ra = 0.0;
+                    for (int g = 0; g < 15; ++g) ra += GKWK[g] * fabs(fv[g][o] - 0.5 * K[o]);
+                    if (ra > 0.0 && e > 0.0) e *= fmin(1.0, pow(P->est_fac * e / ra, P->est_pow));
+                }
+                if (e * hw > P->tol * fmax(fabs(out[o] + K[o] * hw), P->floor_ * scaleS[o])) ok = 0;
+            }
             if (ok || L == P->lmax) {
                 for (int o = 0; o < 3; ++o) out[o] += K[o] * hw;
                 ++i;
