@@ -219,7 +219,31 @@ def _comm_setup(pkg, world, local_rank, dist, torch):
         if dist is None:
             _COMM["comm"] = pkg.Communicator(1, 0, pkg.Communicator.unique_id(), local_rank)
         elif dist.get_backend() == "nccl":
-            _COMM["comm"] = pkg.Communicator.from_torch_distributed(local_rank)
+            # ncclCommInitRank with more than one rank has never run on hardware from inside this library (no multi-GPU
+            # box was available to any round): it runs under a watchdog, so that a rendezvous that never completes costs
+            # the C-ABI collective (fallback below, said so in the JSON line) and not the whole bench line
+            import threading
+
+            box = {}
+            c_rank, c_world, uid = pkg.Communicator.exchange_unique_id()   # (torch collectives stay on this thread)
+
+            def make():
+                try:
+                    box["comm"] = pkg.Communicator(c_world, c_rank, uid, local_rank)
+                except Exception as e:   # noqa: BLE001
+                    box["err"] = f"{type(e).__name__}: {e}"
+
+            limit = float(os.environ.get("CLOUDY_BENCH_COMM_TIMEOUT", "180"))
+            th = threading.Thread(target=make, daemon=True)
+            th.start()
+            th.join(limit)
+            if th.is_alive():
+                ok, why = 0, f"cloudy_comm_create did not return within {limit:.0f} s"
+                _COMM["hung"] = True
+            elif "err" in box:
+                ok, why = 0, box["err"]
+            else:
+                _COMM["comm"] = box["comm"]
         else:
             ok, why = 0, "ranks share a GPU (non-nccl control backend)"
     except Exception as e:   # noqa: BLE001 -- any failure means the fallback, reported in the JSON line
@@ -1142,6 +1166,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         dist = None
+    if _COMM.get("hung") and rank != 0:
+        os._exit(0)   # a thread of this rank is still inside ncclCommInitRank: no interpreter shutdown to wait on it
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         cpu = _cpu_baseline(args.workload)
@@ -1185,6 +1211,8 @@ def main():
         }
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
+        if _COMM.get("hung"):
+            os._exit(0)   # (as the other ranks above: a thread is still inside ncclCommInitRank)
 
 
 if __name__ == "__main__":

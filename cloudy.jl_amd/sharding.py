@@ -48,6 +48,13 @@ class Communicator:
 
     @classmethod
     def from_torch_distributed(cls, device=-1, group=None):
+        rank, world, uid = cls.exchange_unique_id(group)
+        return cls(world, rank, uid, device)
+
+    @classmethod
+    def exchange_unique_id(cls, group=None):
+        """-> (rank, world, the 128 bytes of rank 0's unique id) over an initialised torch.distributed group: the
+        rendezvous half of from_torch_distributed (the caller may then build the communicator under its own watchdog)."""
         import torch.distributed as dist
 
         rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -64,7 +71,7 @@ class Communicator:
         kind, payload = box[0]
         if kind != "id":
             raise _lib.CloudyError(_lib.ECOMM, "rank 0 could not create the RCCL unique id: " + payload)
-        return cls(world, rank, payload, device)
+        return rank, world, payload
 
     def allreduce_moment_sums(self, plan, arr, stream=None):
         """cloudy_moment_sums_allreduce: plane sums of this rank's (planes, n) device array summed over all ranks."""
