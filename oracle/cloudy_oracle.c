@@ -463,7 +463,7 @@ static double co_msh_y(int j, void *vctx) {
  * tests/golden/lognormal_adaptive.json); the reference's own KATs (test_ParticleDistributions_correctness.jl:215-218)
  * are reproduced to their 4 digits. */
 #define CO_LN_NODES 48
-#define CO_LN_SIGMA_FLOOR 1e-8
+#define CO_LN_SIGMA_FLOOR 1e-6
 #define CO_LN_MAXORDER 7 /* M = P + 2 <= 7 orders share one range, as the kernel's single pass over the nodes does */
 static double co_softplus(double x) { return x > 0.0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
 /* The window of v in which the integrand lives, through the EXACT map v(ln y) = d - ln(1 - e^d), d = ln y - ln xt < 0
