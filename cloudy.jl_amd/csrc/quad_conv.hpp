@@ -622,11 +622,13 @@ __device__ __forceinline__ double conv_long_G_mid(const QArgs &Q, double k, doub
 // t = 0.  Outer: the adaptive rule over ln s in [mu - 8.5 sigma, mu + 8.5 sigma + (gamma + 2) sigma^2 + ln 2] (budget
 // kConvBudgetLn), marks at the other modes' cores (and ln x_t, ln 2 x_t for Long); inner: kLnPanels2 panels of nq
 // Gauss-Legendre points over t in [0, max(ln s - mu, 0) + 12 sigma], split at the Long kernel's jump.  totals[m]: T_m with 1 - w = 1 (closed form), the estimate's scale.
-// SIGMA FLOOR: the inner panels are equal pieces of that range, ~0.06 + sigma wide, while the integrand at t = 0 is
-// a half-Gaussian sqrt(2) sigma wide -- measured against the rule with 8 x the inner panels at s ~ 2 e^mu: 2e-10 at sigma =
-// 0.02, 7e-7 at 0.01.  The 1e-9-of-scale statement of this mode holds for Lognormal modes with sigma >= 0.03 (every
-// reference example: sigma = ln 2, 0.833, 2); narrower modes that are NOT the last one degrade as stated, without a guard.
-constexpr int kLnPanels2 = 12;
+// INNER PANELS (round 4): the integrand in t is a Gaussian sqrt(2) sigma ... 2 sigma wide around its peak (at t = 0 for
+// s ~ 2 e^mu), so the inner range is cut into as many equal panels as make a panel no wider than kLnPanelSigmas sigma: 12 (the
+// minimum) for sigma >= 0.03, up to kLnPanels2Max = 256 below 0.001.  Rounds 2-3 used 12 panels whatever sigma: measured against
+// the rule with panels of sigma / 2 at s ~ 2 e^mu: 2e-10 of scale at sigma = 0.02, 6e-7 at 0.01, 1e-4 ... 1e-1 below 0.005; now
+// <= 1.5e-12 down to sigma = 0.003, 6.5e-11 at 0.002, 1e-9 ... 2e-6 at 0.001 (the cap), tests/test_numerical_oracle.py.
+constexpr int kLnPanels2 = 12, kLnPanels2Max = 256;
+constexpr double kLnPanelSigmas = 3.0;
 template <int N, int KIND>
 __device__ __forceinline__ void conv_T_lognormal(const QArgs &Q, const double *__restrict__ tab, double n, double mu, double sg,
                                                  const double (&cm)[N], const double (&wm)[N], const ConvLogDensity (&lg)[N],
@@ -658,20 +660,23 @@ __device__ __forceinline__ void conv_T_lognormal(const QArgs &Q, const double *_
         // x_t < s < 2 x_t (below, both stay under x_t; above, x >= s / 2 >= x_t) -- the inner panels are split there
         double tb = 0.0;
         int n1 = 0;
+        double npd = ceil(Tm / (kLnPanelSigmas * sg));
+        npd = !(npd >= double(kLnPanels2)) ? double(kLnPanels2) : npd > double(kLnPanels2Max) ? double(kLnPanels2Max) : npd;
+        const int np2 = (int)npd;
         if (KIND == KF_LONG && s > Q.kf[0] && s < 2.0 * Q.kf[0]) {
             tb = log_pos(Q.kf[0] / (s - Q.kf[0]));
             if (tb > 0.0 && tb < Tm) {
-                n1 = (int)(double(kLnPanels2) * (tb / Tm) + 0.5);
-                n1 = n1 < 1 ? 1 : n1 > kLnPanels2 - 1 ? kLnPanels2 - 1 : n1;
+                n1 = (int)(double(np2) * (tb / Tm) + 0.5);
+                n1 = n1 < 1 ? 1 : n1 > np2 - 1 ? np2 - 1 : n1;
             }
         }
         double G2 = 0.0;
 #pragma unroll 1
-        for (int i2 = 0; i2 < kLnPanels2; ++i2) {
+        for (int i2 = 0; i2 < np2; ++i2) {
             // panel i2 of the first piece [0, t_b] (n1 panels) or of the second [t_b, Tm] (the rest); n1 = 0: one piece
             const bool first = i2 < n1;
             const double a = first ? 0.0 : (n1 ? tb : 0.0), b = first ? tb : Tm;
-            const double h2 = (b - a) / double(first ? n1 : kLnPanels2 - n1);
+            const double h2 = (b - a) / double(first ? n1 : np2 - n1);
             const double tc = fma(h2, double(first ? i2 : i2 - n1) + 0.5, a);
 #pragma unroll 1
             for (int g2 = 0; g2 < nq; ++g2) {

@@ -166,9 +166,9 @@ typedef struct cloudy_plan_desc {
      * Long kernel, whose G(s) is only finitely smooth at x_t and 2 x_t -- and ended by a rigorous bound of what is left:
      * <= 1.1e-10 of scale against the rule at 1e-13 over a thousand random multi-scale mixtures; quad_order is then only
      * the points per panel of the inner rule a Lognormal mode's self-collision integral needs, default 8) -- within 1e-9
-     * of scale of the adaptive result.  Lognormal modes: validated for sigma >= 0.03; a narrower
-     * Lognormal mode that is not the last one loses accuracy in that inner rule (7e-7 at sigma = 0.01,
-     * csrc/quad_conv.hpp).  quad_mode = CLOUDY_QUAD_FIXED (explicit opt-in; BASELINE configs[3] "via 10-pt Gauss
+     * of scale of the adaptive result.  Lognormal modes: that inner rule takes panels of at most 3 sigma
+     * (up to 256 of them): <= 1.5e-12 of scale down to sigma = 0.003, 1e-9 ... 2e-6 at sigma = 0.001, growing below
+     * (csrc/quad_conv.hpp).  quad_mode = CLOUDY_QUAD_FIXED (explicit opt-in; BASELINE configs[3] "via 10-pt Gauss
      * quadrature"): each integral by one fixed quad_order-point Gauss rule per distribution (generalised Gauss-Laguerre
      * for Gamma / Exponential modes, Gauss-Hermite in ln x for Lognormal modes; tensor product over a pair of modes after
      * the substitution x' = x - y; default 10 points) -- exact for the constant and linear kernels up to the weighting_fn

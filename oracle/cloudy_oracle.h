@@ -162,6 +162,7 @@ double co_inc_beta(double a, double b, double x);
 int co_gauss_legendre_rule(int q, double *x, double *w);
 void co_conv_range(double A, double *zlo, double *zhi);
 long co_conv_node_count(int reset); /* integrand evaluations of the adaptive rules on this thread since the last reset */
+void co_conv_set_ln_inner(double sigmas, int max_panels); /* inner rule of a Lognormal mode's T_m: panel width in sigma, cap */
 void co_conv_rule_node_counts(long *out); /* ... of the T_m rule of each mode (CO_MAX_MODES entries) in the last call */
 int co_get_coal_ints_numerical_converged(const co_dist *pdists, int N, const co_kernel_func *kf, int q, double tol,
                                          double *out, double *scale);

@@ -505,6 +505,14 @@ def get_coal_ints_numerical_converged(pdists, kf, q=8, tol=CONV_TOL, with_scale=
     return (out, sc) if with_scale else out
 
 
+def conv_set_ln_inner(sigmas=3.0, max_panels=256):
+    """inner rule of a Lognormal mode's T_m in converged mode: panel width in sigma and the cap on the panel count (tests use a
+    finer rule as the reference of the default one; call without arguments to restore the default)"""
+    f = lib().co_conv_set_ln_inner
+    f.argtypes, f.restype = [C.c_double, C.c_int], None
+    f(float(sigmas), int(max_panels))
+
+
 def get_coal_ints_numerical_adaptive(pdists, kf, eps_outer=1e-10, eps_inner=1e-12):
     """get_coal_ints(::NumericalCoalStyle, ...) by nested adaptive Gauss-Kronrod quadrature (cloudy_oracle_adaptive.c):
     (coal_ints, Q[orders, N, N], R[orders, N, N], S[orders, 2, N])."""

@@ -903,6 +903,23 @@ static void co_T_bound(double b, double *B, void *v) {
  * (budget CO_CONV_BUDGET_LN), marks at the other modes' cores (and ln x_t, ln 2 x_t for Long); inner: CO_LN_PAN2
  * panels of q Gauss-Legendre points over t in [0, max(ln s - mu, 0) + 12 sigma], split at the Long kernel's jump (co_TL_node). */
 #define CO_LN_PAN2 12
+/* ... at least; as many as make a panel no wider than CO_LN_PAN2_SIGMAS sigma (the integrand in t is a Gaussian sqrt(2) sigma
+ * to 2 sigma wide around its peak), up to CO_LN_PAN2_MAX: 12 for sigma >= 0.03, 256 below 0.001 (round 4; the fixed 12 were
+ * off by 2e-10 at sigma = 0.02, 6e-7 at 0.01 and 1e-4 ... 1e-1 below 0.005) */
+#define CO_LN_PAN2_SIGMAS 3.0
+#define CO_LN_PAN2_MAX 256
+static double co_ln_pan2_sigmas_ = CO_LN_PAN2_SIGMAS;
+static int co_ln_pan2_max_ = CO_LN_PAN2_MAX;
+void co_conv_set_ln_inner(double sigmas, int max_panels) { /* tests: a finer inner rule as the reference of the default one */
+    co_ln_pan2_sigmas_ = sigmas;
+    co_ln_pan2_max_ = max_panels;
+}
+static int co_ln_pan2(double Tm, double sg) {
+    double np = ceil(Tm / (co_ln_pan2_sigmas_ * sg));
+    if (!(np >= (double)CO_LN_PAN2)) np = (double)CO_LN_PAN2;
+    if (np > (double)co_ln_pan2_max_) np = (double)co_ln_pan2_max_;
+    return (int)np;
+}
 typedef struct {
     const co_dist *pdists;
     int N, j, q;
@@ -917,16 +934,17 @@ static void co_TL_node(double ls, double *vals, void *v) {
      * x_t < s < 2 x_t (below, both stay under x_t; above, x >= s / 2 >= x_t) -- the inner panels are split there */
     double tb = 0.0;
     int n1 = 0;
+    const int np2 = co_ln_pan2(Tm, sg);
     if (c->kf->kind == CO_KF_LONG && s > c->kf->p[0] && s < 2.0 * c->kf->p[0]) {
         tb = log(c->kf->p[0] / (s - c->kf->p[0]));
         if (tb > 0.0 && tb < Tm) {
-            n1 = (int)(CO_LN_PAN2 * (tb / Tm) + 0.5);
-            n1 = n1 < 1 ? 1 : n1 > CO_LN_PAN2 - 1 ? CO_LN_PAN2 - 1 : n1;
+            n1 = (int)(np2 * (tb / Tm) + 0.5);
+            n1 = n1 < 1 ? 1 : n1 > np2 - 1 ? np2 - 1 : n1;
         }
     }
     double G2 = 0.0;
     for (int seg = 0; seg < 2; ++seg) {
-        const int np = seg == 0 ? n1 : CO_LN_PAN2 - n1;
+        const int np = seg == 0 ? n1 : np2 - n1;
         const double a = seg == 0 ? 0.0 : (n1 ? tb : 0.0), b = seg == 0 ? tb : Tm;
         if (np == 0) continue;
         const double h2 = (b - a) / np;

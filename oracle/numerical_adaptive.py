@@ -73,6 +73,11 @@ CASES = [
     # a Lognormal mode that is NOT the last one under the Long kernel: its T_m is the 2-D rule with the kernel's jump inside
     dict(name="lognormal_gamma_long", kf=(3, LONG), pdists=[(3, 80.0, -1.5, 0.7), (1, 2.0, 2.0, 3.0)], mp=True),
     dict(name="gamma_narrow_lognormal_constant", kf=(0, [0.7]), pdists=[(1, 2.02, 0.17, 1.5), (3, 79.6, -1.888, 0.15)]),
+    # a NARROW Lognormal mode below a Gamma mode that sits at ~2 e^mu: the inner integrand of its T_m (over ln(x / y)) is a
+    # Gaussian ~sqrt(2) sigma wide on the boundary t = 0 (round 4, ADVICE r3: 12 equal inner panels were off by 6e-7 at sigma = 0.01)
+    dict(name="narrow_lognormal_gamma_constant", kf=(0, [0.7]), pdists=[(3, 2.0, -1.0, 0.01), (1, 1.0, 0.9, 2.0)]),
+    dict(name="narrow_lognormal_gamma_hydro", kf=(2, [3.14]), pdists=[(3, 2.0, -1.0, 0.005), (1, 1.0, 0.9, 2.0)]),
+    dict(name="narrow_lognormal_gamma_long", kf=(3, [0.5, 2.0, 1.0]), pdists=[(3, 2.0, -1.0, 0.02), (1, 1.0, 0.9, 2.0)]),
 ]
 
 

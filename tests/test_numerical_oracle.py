@@ -9,7 +9,7 @@ What pins the oracle here:
   * exactness for polynomial kernels: for one mode the Numerical and Analytical closures coincide, so the fixed rule
     must reproduce co_get_coal_ints (all thresholds Inf) to rounding; for several modes the sums over modes must;
   * the adaptive-quadrature restatement of the reference integrals (oracle/cloudy_oracle_adaptive.c, driven by
-    oracle/numerical_adaptive.py -> tests/golden/numerical_adaptive.json, 35 cases at 1e-10, two of them cross-checked with
+    oracle/numerical_adaptive.py -> tests/golden/numerical_adaptive.json, 38 cases at 1e-10, twelve of them cross-checked with
     mpmath): the discretisation error of the FIXED rule is reported and bounded per kernel family, and the CONVERGED mode
     (csrc/quad_conv.hpp, restated in cloudy_oracle_quad.c) must reach the adaptive values to <= 1e-8 of scale.
 """
@@ -230,6 +230,30 @@ def test_converged_mode_on_random_multi_scale_mixtures(oracle):
     print(f"{errs.size} mixtures: worst {errs.max():.1e} of scale, {100 * (errs > 1e-9).mean():.1f} % beyond 1e-9; "
           f"integrand evaluations per mode: mean {evals.mean():.0f}, 90th percentile {np.percentile(evals, 90):.0f}")
     assert errs.max() <= 1e-8 and (errs > 1e-9).mean() <= 0.01
+
+
+def test_converged_mode_narrow_lognormal_modes(oracle):
+    """the inner rule of a Lognormal mode's T_m (over t = ln(x / y)) used 12 equal panels whatever sigma, while the
+    integrand is a Gaussian ~sqrt(2) sigma wide: 6e-7 of scale at sigma = 0.01, 1e-4 ... 1e-1 below 0.005.  Its panels are now
+    at most 3 sigma wide (up to 256 of them).  Checked against the same rule with panels of sigma / 2: a narrow Lognormal mode
+    below a Gamma mode sitting at ~2 e^mu (where the peak of the inner integrand is on the boundary t = 0), every kernel family."""
+    O = oracle
+    worst = {}
+    try:
+        for kind, prm in ((0, (1.0,)), (1, (0.7,)), (2, (3.14,)), (3, (0.5, 2.0, 1.0))):
+            kf = O.kernel_func(kind, *prm)
+            for sg, bound in ((0.05, 2e-12), (0.02, 2e-12), (0.01, 2e-12), (0.005, 2e-12), (0.003, 2e-12), (0.002, 1e-10)):
+                pd = [O.make_dist(O.LOGNORMAL, 2.0, -1.0, sg), O.make_dist(O.GAMMA, 1.0, 0.9, 2.0)]
+                O.conv_set_ln_inner(0.5, 8192)
+                ref, sc = O.get_coal_ints_numerical_converged(pd, kf, q=8, tol=1e-12, with_scale=True)
+                O.conv_set_ln_inner()
+                got, _ = O.get_coal_ints_numerical_converged(pd, kf, q=8, tol=1e-12, with_scale=True)
+                err = float(np.max(np.abs(got - ref) / sc))
+                worst[(kind, sg)] = err
+                assert err <= bound, (kind, sg, err)
+    finally:
+        O.conv_set_ln_inner()
+    print("narrow Lognormal modes, default inner rule against panels of sigma / 2:", {k: f"{v:.1e}" for k, v in worst.items()})
 
 
 def test_converged_mode_building_blocks(oracle):
