@@ -36,15 +36,19 @@ __device__ __forceinline__ double recip_fast(double x) {
 // Wallis forward recurrence (no division per term).  *q_out gets Q on the same branch's accuracy.
 // Stopping tolerances (relative size of the last term / of the last change of the continued fraction), tested every four
 // terms.  Rounds 1-3 used 1e-17 / 1e-16 -- BELOW the rounding unit, so both loops ran one or two groups of four past the
-// point where double precision stops changing: measured in round 4 (tools/time_kernels.py --error, gpurun_out/r04l), 1e-15
-// gives the same error against the oracle to both printed digits (1.8e-14 / 1.9e-14 / 7.5e-15 of scale on cfg3b / cfg4 /
-// moving4) at 2.05 -> 1.86 ms, 6.56 -> 6.06 ms, 1.375 -> 1.298 ms.  (1e-14: 1.84 / 6.02 / 1.284, the same errors; 1e-13: the
-// moving4 error doubles.  CLOUDY_F64_RELAXED plans define both as 1e-11.)
+// point where double precision stops changing.  Measured in round 4 (tools/time_kernels.py --error; cfg3b / cfg4 / moving4,
+// error against the oracle in units of the term scale):
+//   1e-17 / 1e-16   2.05 / 6.56 / 1.375 ms   1.8e-14 / 1.9e-14 / 7.5e-15
+//   1e-15           1.85 / 6.05 / 1.291 ms   the same errors to both printed digits
+//   1e-14           1.83 / 5.98 / 1.281 ms   1.8e-14 / 1.9e-14 / 7.6e-15      <- the default
+//   1e-13                                    the moving4 error doubles
+// (the tail left behind a last term of 1e-14 is of that size: by then the term ratio is well below 1.)  CLOUDY_F64_RELAXED
+// plans define both as 1e-11.
 #ifndef CLOUDY_SERIES_TOL
-#define CLOUDY_SERIES_TOL 1e-15
+#define CLOUDY_SERIES_TOL 1e-14
 #endif
 #ifndef CLOUDY_CF_TOL
-#define CLOUDY_CF_TOL 1e-15
+#define CLOUDY_CF_TOL 1e-14
 #endif
 __device__ __forceinline__ double inc_gamma_p_from_E(double a, double z, double E, double *q_out) {
 #ifdef CLOUDY_ABLATE_PTOP  // timing experiment only: skips the series / continued fraction
