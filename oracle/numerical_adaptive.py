@@ -78,6 +78,12 @@ CASES = [
     dict(name="narrow_lognormal_gamma_constant", kf=(0, [0.7]), pdists=[(3, 2.0, -1.0, 0.01), (1, 1.0, 0.9, 2.0)]),
     dict(name="narrow_lognormal_gamma_hydro", kf=(2, [3.14]), pdists=[(3, 2.0, -1.0, 0.005), (1, 1.0, 0.9, 2.0)]),
     dict(name="narrow_lognormal_gamma_long", kf=(3, [0.5, 2.0, 1.0]), pdists=[(3, 2.0, -1.0, 0.02), (1, 1.0, 0.9, 2.0)]),
+    # four modes (box_gamma_mixture_4modes.jl has four; NumericalCoalStyle plans take up to four), and two identical modes
+    dict(name="4gamma_hydrodynamic", kf=(2, [3.14e-3]), pdists=[(1, 100.0, 0.02, 2.0), (1, 10.0, 0.5, 3.0), (1, 1.0, 8.0, 2.5), (1, 0.05, 100.0, 4.0)]),
+    dict(name="exp_gamma_lognormal_gamma_linear", kf=(1, [5e-3]),
+         pdists=[(0, 100.0, 0.02, 1.0), (1, 10.0, 0.5, 3.0), (3, 1.0, 2.0, 0.4), (1, 0.05, 100.0, 4.0)]),
+    dict(name="4gamma_long", kf=(3, [0.5, 2.0, 1.0]), pdists=[(1, 100.0, 0.02, 2.0), (1, 10.0, 0.3, 3.0), (1, 1.0, 2.0, 2.5), (1, 0.05, 30.0, 4.0)]),
+    dict(name="2gamma_identical_hydrodynamic", kf=(2, [3.14e-3]), pdists=[(1, 10.0, 1.0, 2.0), (1, 10.0, 1.0, 2.0)]),
 ]
 
 

@@ -9,7 +9,7 @@ What pins the oracle here:
   * exactness for polynomial kernels: for one mode the Numerical and Analytical closures coincide, so the fixed rule
     must reproduce co_get_coal_ints (all thresholds Inf) to rounding; for several modes the sums over modes must;
   * the adaptive-quadrature restatement of the reference integrals (oracle/cloudy_oracle_adaptive.c, driven by
-    oracle/numerical_adaptive.py -> tests/golden/numerical_adaptive.json, 38 cases at 1e-10, twelve of them cross-checked with
+    oracle/numerical_adaptive.py -> tests/golden/numerical_adaptive.json, 42 cases at 1e-10, twelve of them cross-checked with
     mpmath): the discretisation error of the FIXED rule is reported and bounded per kernel family, and the CONVERGED mode
     (csrc/quad_conv.hpp, restated in cloudy_oracle_quad.c) must reach the adaptive values to <= 1e-8 of scale.
 """
@@ -123,12 +123,12 @@ def _golden_scale(c):
 
 
 def test_golden_set_is_what_the_verdict_asked_for():
-    """>= 24 cases, N = 1..3, Gamma / Exponential / Lognormal, hydrodynamic + Long + linear (+ constant), generated at
+    """>= 42 cases, N = 1..4, Gamma / Exponential / Lognormal, hydrodynamic + Long + linear (+ constant), generated at
     1e-10 by oracle/numerical_adaptive.py; twelve of them carry an mpmath cross-check of every Q / R / S entry"""
     g = _golden()
     cases = g["cases"]
-    assert len(cases) >= 32 and g["eps_outer"] <= 1e-10
-    assert {len(c["pdists"]) for c in cases} == {1, 2, 3}
+    assert len(cases) >= 42 and g["eps_outer"] <= 1e-10
+    assert {len(c["pdists"]) for c in cases} == {1, 2, 3, 4}
     assert {int(d[0]) for c in cases for d in c["pdists"]} == {0, 1, 3}
     assert {c["kf"][0] for c in cases} == {0, 1, 2, 3}
     # VERDICT r3 item 5: the golden set is pinned independently of the builder's own integrator -- mpmath (20 digits,
