@@ -373,6 +373,45 @@ def test_converged_mode_vs_same_rule_oracle(gpu_cloudy, oracle, dist_types, knam
     assert np.all(np.abs(mass[ok]) <= 1e-11 * mag[ok] + 1e-300)            # mass is conserved by the closed forms
 
 
+@pytest.mark.parametrize("kname", ["hydro", "long", "linear", "constant"])
+def test_converged_mode_extreme_parcels(gpu_cloudy, oracle, kname):
+    """Hand-made parcels at the edges of the rule (a CPU sweep of round 4 against nested adaptive quadrature): modes
+    4 ... 10 decades apart (where the reference's own Q - R + S loses the tendency to cancellation), identical and nearly
+    identical modes, shapes at both clamps, a narrow Lognormal mode below a Gamma mode at ~2 e^mu -- against the same-rule
+    oracle, with exact mass conservation."""
+    cloudy = gpu_cloudy
+    n0, m0 = NORMS
+    rows = []
+    def gamma_pair(n1, th1, k1, n2, th2, k2):
+        return [n1, n1 * k1 * th1, n1 * k1 * (k1 + 1) * th1 ** 2, n2, n2 * k2 * th2, n2 * k2 * (k2 + 1) * th2 ** 2]
+    for dec in (4, 6, 8, 10):
+        rows.append(gamma_pair(10.0 ** (dec / 2), 10.0 ** (-dec / 2), 3.0, 10.0 ** (-dec / 2), 10.0 ** (dec / 2), 3.0))
+    rows.append(gamma_pair(10.0, 1.0, 2.0, 10.0, 1.0, 2.0))              # identical modes
+    rows.append(gamma_pair(10.0, 1.0, 2.0, 5.0, 1.0001, 2.0001))        # nearly identical
+    rows.append(gamma_pair(50.0, 0.05, 9.99, 2.0, 3.0, 0.05))           # shapes next to the upper clamp / small
+    rows.append(gamma_pair(50.0, 0.05, 1e-3, 2.0, 3.0, 9.0))            # a shape of 1e-3
+    rows.append(gamma_pair(1.0, 1e-6, 2.0, 1.0, 1e6, 2.0))              # 12 decades, equal numbers
+    mom = np.ascontiguousarray(np.array(rows).T * np.array([n0, n0 * m0, n0 * m0 ** 2] * 2)[:, None])
+    par, op, okf = converged_case(cloudy, oracle, [1, 1], kname, 8)
+    got = run_numerical(cloudy, par, mom)
+    want, scale = oracle.rhs_coal_numerical_converged_batch(op, okf, 8, mom, with_scale=True)
+    worst = assert_same_rule(got, want, scale, np.zeros_like(scale), f"extreme parcels {kname}", tol=TOL_CONVERGED)
+    mass = np.abs(got[1] + got[4]) / (scale[1] + scale[4])
+    print(f"extreme Gamma pairs, {kname}: max |hip - oracle| / scale = {worst:.2e}, mass residual {mass.max():.1e}")
+    assert np.all(np.isfinite(got)) and mass.max() <= 1e-13
+    # a narrow Lognormal mode below a Gamma mode sitting at ~2 e^mu (the inner rule of its T_m: panels of <= 3 sigma)
+    lrows = []
+    for sg in (0.05, 0.01, 0.004):
+        mu = -1.0
+        lrows.append([2.0, 2.0 * np.exp(mu + 0.5 * sg * sg), 2.0 * np.exp(2 * mu + 2 * sg * sg), 1.0, 1.0 * 2.0 * 0.9, 1.0 * 2.0 * 3.0 * 0.81])
+    lmom = np.ascontiguousarray(np.array(lrows).T * np.array([n0, n0 * m0, n0 * m0 ** 2] * 2)[:, None])
+    par, op, okf = converged_case(cloudy, oracle, [3, 1], kname, 8)
+    got = run_numerical(cloudy, par, lmom)
+    want, scale = oracle.rhs_coal_numerical_converged_batch(op, okf, 8, lmom, with_scale=True)
+    worst = assert_same_rule(got, want, scale, np.zeros_like(scale), f"narrow Lognormal {kname}", tol=TOL_CONVERGED)
+    print(f"narrow Lognormal below a Gamma mode, {kname}: max |hip - oracle| / scale = {worst:.2e}")
+
+
 def test_converged_mode_jit_aot_params_and_float_planes(gpu_cloudy, oracle):
     cloudy = gpu_cloudy
     L = cloudy.lib()
