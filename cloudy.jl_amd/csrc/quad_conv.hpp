@@ -755,6 +755,12 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
     double tmode = 0.0, lwmode = 0.0, lnup = 0.0, ltlo[NM];
     bool convex = false;
     ConvLogDensity own, oth[NM];
+    // ln rho of a Gamma-family mode against the rule's own (Gamma-family) mode is linear in (ln s, s): its three coefficients,
+    // differences formed once per rule -- two FMAs per node and slot instead of two log densities and their difference (and
+    // without the cancellation of that difference); Lognormal modes keep the general form.  (Round 4: -7 of ~118 instructions
+    // per node for an all-Gamma plan, where `own` and `oth` then drop out of the loop.)
+    double da[NM], nb[NM], nc[NM];
+    bool anyln = false;
     ConvMarks<NM> mk;
     double h0 = 0.0, gap = 0.0, cur = 0.0, a0 = 0.0, h = 0.0;
     int io = 1, L = 0, budget = kConvBudget;
@@ -763,11 +769,14 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
     own = lg[0];
 #pragma unroll
     for (int sl = 0; sl < NM; ++sl) oth[sl] = lg[0];
+#pragma unroll
+    for (int m = 0; m < N; ++m) anyln = anyln || lg[m].lognormal;
     mk.shift = 0.0;
     mk.extra[0] = mk.extra[1] = mk.extra[2] = INFINITY;
 #pragma unroll
     for (int sl = 0; sl < NM; ++sl) {
         ltlo[sl] = 0.0;
+        da[sl] = nb[sl] = nc[sl] = 0.0;
         mk.c[sl] = 0.0;
         mk.w[sl] = 1.0;
         mk.I[sl] = 0;
@@ -829,6 +838,9 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
                             oth[s2].b = sel ? lg[m].b : oth[s2].b;
                             oth[s2].c = sel ? lg[m].c : oth[s2].c;
                             oth[s2].lognormal = sel ? lg[m].lognormal : oth[s2].lognormal;
+                            da[s2] = sel ? lg[m].a - lg[r].a : da[s2];
+                            nb[s2] = sel ? lg[r].b - lg[m].b : nb[s2];
+                            nc[s2] = sel ? lg[r].c - lg[m].c : nc[s2];
                         }
                 }
         }
@@ -867,11 +879,12 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
     const auto next_panel = [&](bool need) -> bool {
         const double ub = exp_fin(cur), sb = ub * thj, lsb = cur + lnthj;
         const double lw = cur > tmode ? lwmode : fma(A, cur, -ub) - lgA;
-        const double ow = own(sb, lsb);
+        const double ow = anyln ? own(sb, lsb) : 0.0;
         double lmax = -INFINITY;
 #pragma unroll
         for (int sl = 0; sl < NM; ++sl) {
-            const double l = fmax(oth[sl](sb, lsb) - ow, ltlo[sl]);
+            const double lr = oth[sl].lognormal ? oth[sl](sb, lsb) - ow : fma(da[sl], lsb, fma(nb[sl], sb, nc[sl]));
+            const double l = fmax(lr, ltlo[sl]);
             lmax = sl >= j ? fmax(lmax, l) : lmax;
         }
         const double lsig = convex ? fmin(0.0, lmax + lnup) : 0.0;
@@ -909,19 +922,20 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
         const double w = ldexp(h, -L), hw = 0.5 * w, c = fma(w, double(i), a0) + hw;
         double K[3] = {0.0, 0.0, 0.0}, G[3] = {0.0, 0.0, 0.0};
         --budget;
-#pragma unroll
-        for (int g = 0; g < 15; ++g) {
-            const ConvNode nd = conv_node(fma(hw, kGKX[g], c), A, lgA);
-            const double s = nd.u * thj, ls = nd.lu + lnthj;
-            const double ow = own(s, ls);
+        // one node: t, u = e^t, its Kronrod weight and (Gauss nodes) its Gauss weight
+        const auto eval_node = [&](double t, double u, double wk, double wg, bool gauss) {
+            const double wt = exp_fin(fma(A, t, -u) - lgA);
+            const double s = u * thj, ls = t + lnthj;
+            const double ow = anyln ? own(s, ls) : 0.0;
             double up = 0.0, den = 1.0;
 #pragma unroll
             for (int sl = 0; sl < NM; ++sl) {
-                const double rho = exp_fin(fmin(oth[sl](s, ls) - ow, 700.0));
+                const double lr = oth[sl].lognormal ? oth[sl](s, ls) - ow : fma(da[sl], ls, fma(nb[sl], s, nc[sl]));
+                const double rho = exp_fin(fmin(lr, 700.0));
                 den += rho;
                 up += sl >= j ? rho : 0.0;
             }
-            double hh = nd.wt * (up * recip_fast(den));
+            double hh = wt * (up * recip_fast(den));
             if (KIND == KF_LONG) {
                 const double xt = Q.kf[0];
                 double Gs;
@@ -934,16 +948,27 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
                 hh *= Gs;
             }
             const double v0 = hh, v1 = hh * s, v2 = (hh * s) * s;
-            const double wk = kGKWK[g], wg = kGKWG[g];
             K[0] = fma(wk, v0, K[0]);
             K[1] = fma(wk, v1, K[1]);
             K[2] = fma(wk, v2, K[2]);
-            if (g & 1) {  // the Gauss nodes
+            if (gauss) {
                 G[0] = fma(wg, v0, G[0]);
                 G[1] = fma(wg, v1, G[1]);
                 G[2] = fma(wg, v2, G[2]);
             }
+        };
+        // The Kronrod nodes are symmetric about the centre: e^(c +- d) = e^c e^(+-d), so a pair of nodes shares ONE exponential
+        // and its reciprocal (8 exponentials + 7 reciprocals per panel for the 15 values of u instead of 15 exponentials; round
+        // 4).  The pairs are taken from the outside in (g = 0 with 14, ...), the centre last.
+        const double uc = exp_fin(c);
+#pragma unroll
+        for (int g = 0; g < 7; ++g) {
+            const double d = hw * kGKX[14 - g];   // > 0
+            const double e = exp_fin(d), re = recip_fast(e);
+            eval_node(c - d, uc * re, kGKWK[g], kGKWG[g], (g & 1) != 0);
+            eval_node(c + d, uc * e, kGKWK[14 - g], kGKWG[14 - g], (g & 1) != 0);
         }
+        eval_node(c, uc, kGKWK[7], kGKWG[7], true);
         bool ok = true;
 #pragma unroll
         for (int e = 0; e < 3; ++e)
@@ -958,16 +983,21 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
         i = ni >> upl;
         L = accept ? L - upl : L + 1;
         const bool done = next_panel(accept && L == 0);
-        // the rule of this lane is finished: park its sums and take the next one (selects; lanes with done = false pass through)
+        // the rule of this lane is finished: park its sums and take the next one (selects; lanes with done = false pass through).
+        // The block is a no-op for a wave none of whose lanes has finished a rule in this trip -- about half of the trips (the
+        // lanes of a wave finish their rules within a few trips of each other) -- so it sits behind a wave-level vote: which
+        // path a wave takes depends on its other lanes, no lane's values do.
+        if (__builtin_amdgcn_ballot_w64(done) != 0ull) {
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const bool st = done && j == r;
-            Traw[r][0] = st ? out[0] : Traw[r][0];
-            Traw[r][1] = st ? out[1] : Traw[r][1];
-            Traw[r][2] = st ? out[2] : Traw[r][2];
+            for (int r = 0; r < NR; ++r) {
+                const bool st = done && j == r;
+                Traw[r][0] = st ? out[0] : Traw[r][0];
+                Traw[r][1] = st ? out[1] : Traw[r][1];
+                Traw[r][2] = st ? out[2] : Traw[r][2];
+            }
+            next_rule(done);
+            (void)next_panel(done && busy);
         }
-        next_rule(done);
-        (void)next_panel(done && busy);
     }
 }
 
