@@ -729,6 +729,7 @@ template <int NM>
 struct ConvRule {
     bool valid;
     double A, lgA, th, lnth, tlo, thi;
+    double gl;                     // Long: (k + 1) / (2k + 1), the factor of G below x_t
     double kj, lgB, rB, ex1, ex2;  // Long: the shape, -ln B(k, k), B(k+1, k+1) / B(k, k), the kinks of G in the rule's variable
     double sc[3];                  // Long: the scale of each output (T_m with 1 - w = 1, over the prefactor)
     // the bound of what is left of the integral below an edge (the walk goes DOWN and stops early, see conv_T_merged):
@@ -750,7 +751,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
     constexpr double kTolT = KIND == KF_LONG ? 0.01 * kConvTol : kConvTol;
     // ---- the state of the rule in hand
     int j = -1;
-    double A = 1.0, lgA = 0.0, thj = 1.0, lnthj = 0.0, tlo = 0.0, thi = 0.0, kj = 1.0, lgB = 0.0, rB = 0.0;
+    double A = 1.0, lgA = 0.0, thj = 1.0, lnthj = 0.0, tlo = 0.0, thi = 0.0, kj = 1.0, lgB = 0.0, rB = 0.0, gl = 0.0;
     double scaleS[3] = {1.0, 1.0, 1.0}, out[3] = {0.0, 0.0, 0.0};
     double tmode = 0.0, lwmode = 0.0, lnup = 0.0, ltlo[NM];
     bool convex = false;
@@ -760,6 +761,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
     // without the cancellation of that difference); Lognormal modes keep the general form.  (Round 4: -7 of ~118 instructions
     // per node for an all-Gamma plan, where `own` and `oth` then drop out of the loop.)
     double da[NM], nb[NM], nc[NM];
+    double upw[NM];   // 1 for the slots of the modes above the rule's own (they make up 1 - w), 0 below: one FMA instead of a select
     bool anyln = false;
     ConvMarks<NM> mk;
     double h0 = 0.0, gap = 0.0, cur = 0.0, a0 = 0.0, h = 0.0;
@@ -777,6 +779,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
     for (int sl = 0; sl < NM; ++sl) {
         ltlo[sl] = 0.0;
         da[sl] = nb[sl] = nc[sl] = 0.0;
+        upw[sl] = 0.0;
         mk.c[sl] = 0.0;
         mk.w[sl] = 1.0;
         mk.I[sl] = 0;
@@ -807,6 +810,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
             for (int sl = 0; sl < NM; ++sl) ltlo[sl] = sel ? rb[r].ltlo[sl] : ltlo[sl];
             if (KIND == KF_LONG) {
                 kj = sel ? rb[r].kj : kj;
+                gl = sel ? rb[r].gl : gl;
                 lgB = sel ? rb[r].lgB : lgB;
                 rB = sel ? rb[r].rB : rB;
                 mk.extra[1] = sel ? rb[r].ex1 : mk.extra[1];
@@ -844,6 +848,8 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
                         }
                 }
         }
+#pragma unroll
+        for (int sl = 0; sl < NM; ++sl) upw[sl] = go ? (sl >= jn ? 1.0 : 0.0) : upw[sl];
         if (go) {
             j = jn;
             mk.shift = lnthj;
@@ -931,16 +937,16 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
 #pragma unroll
             for (int sl = 0; sl < NM; ++sl) {
                 const double lr = oth[sl].lognormal ? oth[sl](s, ls) - ow : fma(da[sl], ls, fma(nb[sl], s, nc[sl]));
-                const double rho = exp_fin(fmin(lr, 700.0));
+                const double rho = exp_fin(fmin(lr, 700.0));   // (finite: 0 x rho below is 0)
                 den += rho;
-                up += sl >= j ? rho : 0.0;
+                up = fma(upw[sl], rho, up);
             }
             double hh = wt * (up * recip_fast(den));
             if (KIND == KF_LONG) {
                 const double xt = Q.kf[0];
                 double Gs;
                 if (s <= xt)
-                    Gs = Q.kf[1] * (s * s) * ((kj + 1.0) / fma(2.0, kj, 1.0));
+                    Gs = Q.kf[1] * (s * s) * gl;
                 else if (s >= 2.0 * xt)
                     Gs = Q.kf[2] * s;
                 else
@@ -1061,7 +1067,7 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
             Traw[j][0] = Traw[j][1] = Traw[j][2] = 0.0;
             r.valid = !lnj_[j] && nj_[j] > 0.0;
             r.A = r.lgA = r.th = 1.0;
-            r.lnth = r.tlo = r.thi = r.kj = r.lgB = r.rB = 0.0;
+            r.lnth = r.tlo = r.thi = r.kj = r.lgB = r.rB = r.gl = 0.0;
             r.ex1 = r.ex2 = INFINITY;
             r.sc[0] = r.sc[1] = r.sc[2] = 1.0;
             r.tmode = r.lwmode = 0.0;
@@ -1126,6 +1132,7 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
                 r.convex = cvx;
             }
             r.kj = kj;
+            r.gl = (kj + 1.0) / fma(2.0, kj, 1.0);
             if (KIND == KF_LONG) {
                 r.lgB = lgamma_pos(2.0 * kj) - 2.0 * lgkj_[j];  // -ln B(k, k)
                 r.rB = kj / (2.0 * fma(2.0, kj, 1.0));           // B(k+1, k+1) / B(k, k)
