@@ -313,6 +313,8 @@ def many_mode_moments(dist_types, n, seed):
     ([1] * 8, 2, (1e-11, 1e-10, INF, 1e-8, 1e-7, 1e-6, 1e-5, INF), False),        # eight modes
     ([1, 1], 7, (INF, INF), False), ([1, 1], 8, (5e-10, INF), False),             # order 6 / 7 tensors
     ([1, 1, 1], 6, (1e-9, 1e-7, INF), False),
+    ([1] * 8, 8, (INF,) * 8, False),                                              # the largest plan the ABI takes
+    ([1, 0, 1, 1, 1, 1], 6, (1e-10, 1e-9, 1e-8, INF, 1e-6, INF), False),
     ([1] * 6, 2, (0.9, 0.95, 0.99, 0.9, 0.99, 1.0), True),                        # six modes, MovingThreshold
 ])
 def test_plans_beyond_the_ahead_of_time_families(gpu_cloudy, oracle, dist_types, P, thr, moving):
