@@ -34,35 +34,38 @@
 
 namespace cloudy {
 
-// continued fraction of the incomplete beta function (DLMF 8.17.22, modified Lentz), converging for x < (a+1)/(a+b+2)
+// continued fraction of the incomplete beta function (DLMF 8.17.22), converging for x < (a+1)/(a+b+2):
+//   h = 1 / (1 + e_1 / (1 + e_2 / (1 + ...))),   e_1 = -(a+b) x / (a+1),
+//   e_2m = m (b-m) x / ((a+2m-1)(a+2m)),   e_2m+1 = -(a+m)(a+b+m) x / ((a+2m)(a+2m+1))
+// by the forward (Wallis) recurrence of its numerators and denominators, A_n = A_n-1 + e_n A_n-2 (B likewise): one
+// reciprocal per coefficient instead of the three of a modified-Lentz step (rounds 2-3; ~55 -> ~36 instructions per
+// double step).  In the range it is called for |e_n| < 1, so A and B grow at most like Fibonacci numbers (1e125 over the
+// 600 coefficients of the iteration cap) and no rescaling is needed; the relative change of A_n / B_n is tested through
+// the cross product, without a division.  Against 30-digit mpmath over a, b in [1e-3, 50]: 7e-15 (Lentz: 6e-15), the
+// same number of steps (7 on average).
 __device__ __forceinline__ double inc_beta_cf(double a, double b, double x) {
-    // (quotients through recip_fast: ~1 ulp, 5 instructions instead of the 30 of an IEEE division -- four per step)
-    const double tiny = 1e-300;
-    double c = 1.0, d = 1.0 - (a + b) * x * recip_fast(a + 1.0);
-    d = fabs(d) < tiny ? tiny : d;
-    d = recip_fast(d);
-    double h = d;
+    double Ap = 1.0, Bp = 1.0, Ac = 1.0, Bc = 1.0 - (a + b) * x * recip_fast(a + 1.0);
 #pragma unroll 1
     for (int m = 1; m <= 300; ++m) {
-        const double md = double(m), m2 = 2.0 * md;
-        double aa = md * (b - md) * x * recip_fast((a + m2 - 1.0) * (a + m2));
-        d = fma(aa, d, 1.0);
-        d = fabs(d) < tiny ? tiny : d;
-        c = fma(aa, recip_fast(c), 1.0);
-        c = fabs(c) < tiny ? tiny : c;
-        d = recip_fast(d);
-        h *= d * c;
-        aa = -(a + md) * (a + b + md) * x * recip_fast((a + m2) * (a + m2 + 1.0));
-        d = fma(aa, d, 1.0);
-        d = fabs(d) < tiny ? tiny : d;
-        c = fma(aa, recip_fast(c), 1.0);
-        c = fabs(c) < tiny ? tiny : c;
-        d = recip_fast(d);
-        const double del = d * c;
-        h *= del;
-        if (fabs(del - 1.0) < 4e-16) break;
+        const double md = double(m), am2 = a + 2.0 * md;
+        double e = md * (b - md) * x * recip_fast((am2 - 1.0) * am2);
+        double An = fma(e, Ap, Ac), Bn = fma(e, Bp, Bc);
+        Ap = Ac;
+        Bp = Bc;
+        Ac = An;
+        Bc = Bn;
+        e = -(a + md) * (a + b + md) * x * recip_fast(am2 * (am2 + 1.0));
+        An = fma(e, Ap, Ac);
+        Bn = fma(e, Bp, Bc);
+        Ap = Ac;
+        Bp = Bc;
+        Ac = An;
+        Bc = Bn;
+        // (A_n / B_n - A_n-1 / B_n-1) / (A_n / B_n) = (A_n B_n-1 - A_n-1 B_n) / (A_n B_n-1)
+        const double cross = Ac * Bp;
+        if (!(fabs(fma(-Ap, Bc, cross)) > 1e-15 * fabs(cross))) break;
     }
-    return h;
+    return Ac * recip_fast(Bc);
 }
 
 // I_x(a, b) given D = x^a (1-x)^b / B(a, b); omx = 1 - x (passed in: the callers know it without cancellation)
