@@ -70,8 +70,9 @@ __device__ __forceinline__ double inc_beta_cf(double a, double b, double x) {
 
 // I_x(a, b) given D = x^a (1-x)^b / B(a, b); omx = 1 - x (passed in: the callers know it without cancellation)
 __device__ __forceinline__ double inc_beta_from_D(double a, double b, double x, double omx, double D) {
-    if (x < (a + 1.0) / (a + b + 2.0)) return D * inc_beta_cf(a, b, x) / a;
-    return 1.0 - D * inc_beta_cf(b, a, omx) / b;
+    // (x < (a + 1) / (a + b + 2) without the division; at the boundary either branch converges)
+    if (x * (a + b + 2.0) < a + 1.0) return D * inc_beta_cf(a, b, x) * recip_fast(a);
+    return fma(-D * recip_fast(b), inc_beta_cf(b, a, omx), 1.0);
 }
 
 // per-mode quantities of the closed forms.  Lognormal modes keep (mu, sigma) in (th, k), as everywhere (kernels.hpp).
@@ -615,7 +616,7 @@ __device__ __forceinline__ void conv_pair(const QArgs &Q, const double *__restri
 // E_tau[K(s (1 - tau), s tau)], tau ~ Beta(k, k), Long kernel, for x_t < s < 2 x_t
 __device__ __forceinline__ double conv_long_G_mid(const QArgs &Q, double k, double lgB, double rB, double s) {
     const double xt = Q.kf[0], cb = Q.kf[1], ca = Q.kf[2];
-    const double x = xt / s, omx = 1.0 - x;  // x in (1/2, 1)
+    const double x = xt * recip_fast(s), omx = 1.0 - x;  // x in (1/2, 1)
     // I_x(k, k) = 1 - I_{1-x}(k, k); I_x(k+1, k+1) by two steps of the recurrences
     const double D = exp_fin(fma(k, log_pos(x) + log_pos(omx), lgB));  // x^k (1-x)^k / B(k, k)
     const double Dk = D * recip_fast(k);                 // (one reciprocal for the three quotients by k)
