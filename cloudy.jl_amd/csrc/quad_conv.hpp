@@ -618,7 +618,7 @@ __device__ __forceinline__ double conv_long_G_mid(const QArgs &Q, double k, doub
     const double xt = Q.kf[0], cb = Q.kf[1], ca = Q.kf[2];
     const double x = xt * recip_fast(s), omx = 1.0 - x;  // x in (1/2, 1)
     // I_x(k, k) = 1 - I_{1-x}(k, k); I_x(k+1, k+1) by two steps of the recurrences
-    const double D = exp_fin(fma(k, log_pos(x) + log_pos(omx), lgB));  // x^k (1-x)^k / B(k, k)
+    const double D = exp_fin(fma(k, log_pos(x * omx), lgB));  // x^k (1-x)^k / B(k, k)  (x (1 - x) in [0, 1/4]: one logarithm)
     const double Dk = D * recip_fast(k);                 // (one reciprocal for the three quotients by k)
     const double Ikk = fma(-Dk, inc_beta_cf(k, k, omx), 1.0);
     const double Ik1k = Ikk - Dk;                        // I_x(k+1, k)
