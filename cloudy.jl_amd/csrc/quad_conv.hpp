@@ -536,8 +536,12 @@ __device__ __forceinline__ void conv_pair(const QArgs &Q, const double *__restri
             const double lz = log_pos(z), lomz = log_pos(omz);
             double G[2][3][4];
             const double lgab = lgamma_pos(K.k + J.k + 1.0 / 3.0);  // ln Gamma(a0 + b0), the same for both grids
+            // A self pair (z = 1/2, both modes the same): the second grid is the mirror image of the first,
+            //   I_1/2(k + 1/3 + i, k + i') = 1 - I_1/2(k + i', k + 1/3 + i),
+            // so ONE continued fraction serves it (the first grid then runs one row further in a).
+            double G0x[4];  // G1 row a = k + 3 of the first grid (self pairs only)
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+            for (int g = 0; g < (self ? 1 : 2); ++g) {
                 const double a0 = K.k + (g ? 1.0 / 3.0 : 0.0), b0 = J.k + (g ? 0.0 : 1.0 / 3.0);
                 const double lgb = g ? J.lgk : J.lgk3, lga = g ? K.lgk3 : K.lgk;
                 double D0 = exp_fin(fma(a0, lz, b0 * lomz) + (lgab - lga - lgb));
@@ -558,9 +562,16 @@ __device__ __forceinline__ void conv_pair(const QArgs &Q, const double *__restri
                         D *= (z * (a + b)) * ra[ia];
                         a += 1.0;
                     }
+                    if (self) G0x[ib] = I;   // I_z(a0 + 3, b0 + ib)
                     I0 = fma(D0, rb, I0);
                     D0 *= (omz * (a0 + b)) * rb;
                 }
+            }
+            if (self) {
+#pragma unroll
+                for (int ia = 0; ia < 3; ++ia)
+#pragma unroll
+                    for (int ib = 0; ib < 4; ++ib) G[1][ia][ib] = 1.0 - (ib < 3 ? G[0][ib][ia] : G0x[ia]);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
