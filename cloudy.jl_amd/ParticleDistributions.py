@@ -9,7 +9,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib
-from .device import DeviceArray, as_device
+from .device import DeviceArray, as_device, plane_dtype
 
 EXPONENTIAL, GAMMA, MONODISPERSE, LOGNORMAL = 0, 1, 2, 3
 NPARAMS = {EXPONENTIAL: 2, GAMMA: 3, MONODISPERSE: 2, LOGNORMAL: 3}
@@ -124,7 +124,7 @@ def get_standard_N_q(plan, mom, size_cutoff=1e-6, out=None, stream=None):
     """get_standard_N_q(pdists, size_cutoff) (ParticleDistributions.jl:634-687), batched: mom (nmom, n) device,
     physical units -> (4, n) device array of (N_liq, N_rai, M_liq, M_rai)."""
     ptr, planes, n, ld = as_device(mom)
-    o = out if out is not None else DeviceArray(4, n, np.float32 if plan.dtype >= 1 else np.float64)
+    o = out if out is not None else DeviceArray(4, n, plane_dtype(plan))
     if as_device(o)[3] != ld:
         raise ValueError("out must have the same leading dimension as mom")
     _lib.check(_lib.lib().cloudy_standard_N_q(plan.handle, n, ld, ptr, float(size_cutoff), as_device(o)[0], stream))

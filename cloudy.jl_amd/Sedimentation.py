@@ -3,20 +3,20 @@
 import numpy as np
 
 from . import _lib
-from .device import DeviceArray, as_device
+from .device import DeviceArray, as_device, plane_dtype
 
 
 def get_sedimentation_flux(plan, mom, out=None, stream=None):
     """mom (nmom, n) device, physical units -> flux (nmom, n) device, physical units."""
     ptr, planes, n, ld = as_device(mom)
-    o = out if out is not None else DeviceArray(plan.nmom, n, np.float32 if plan.dtype >= 1 else np.float64)
+    o = out if out is not None else DeviceArray(plan.nmom, n, plane_dtype(plan))
     _lib.check(_lib.lib().cloudy_sedimentation_flux(plan.handle, n, ld, ptr, as_device(o)[0], stream))
     return o
 
 
 def rainshaft_sources(plan, mom, coal_source=None, sedi_flux=None, stream=None):
     ptr, planes, n, ld = as_device(mom)
-    dt = np.float32 if plan.dtype >= 1 else np.float64
+    dt = plane_dtype(plan)
     cs = coal_source if coal_source is not None else DeviceArray(plan.nmom, n, dt)
     sf = sedi_flux if sedi_flux is not None else DeviceArray(plan.nmom, n, dt)
     _lib.check(_lib.lib().cloudy_rainshaft_sources(plan.handle, n, ld, ptr, as_device(cs)[0], as_device(sf)[0], stream))
@@ -50,7 +50,7 @@ def make_rainshaft_rhs(coal_type=None):
         nz = int(getattr(p, "nz", n))
         if n % nz:
             raise ValueError("number of cells must be a multiple of p.nz")
-        dt = np.float32 if plan.dtype >= 1 else np.float64
+        dt = plane_dtype(plan)
         o = out if out is not None else DeviceArray(plan.nmom, n, dt)
         w = work if work is not None else DeviceArray(plan.nmom, n, dt)
         _lib.check(_lib.lib().cloudy_rainshaft_rhs(plan.handle, nz, n // nz, ld, ptr, float(p.dz), as_device(w)[0],

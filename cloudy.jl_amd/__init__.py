@@ -8,7 +8,7 @@ RHS factory of test/examples/utils/box_model_helpers.jl.  There is no CPU comput
 """
 from . import _lib
 from ._lib import CloudyError, device_count, lib
-from .device import DeviceArray
+from .device import DeviceArray, plane_dtype
 from .EquationTypes import (AbstractStyle, AnalyticalCoalStyle, CoalescenceStyle, FixedThreshold, MovingThreshold,
                             NumericalCoalStyle, ThresholdStyle)
 from .helper_functions import (get_dist_moment_ind, get_dist_moments_ind_range, get_moments_normalizing_factors,

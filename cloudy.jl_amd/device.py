@@ -94,6 +94,13 @@ class DeviceArray:
             pass
 
 
+def plane_dtype(plan):
+    """numpy element type of the moment planes a plan reads and writes: float32 for CLOUDY_F32 / CLOUDY_F32_FAST, float64
+    for CLOUDY_F64 and CLOUDY_F64_RELAXED (dtype code 3: fp64 planes, relaxed series tolerance -- include/cloudy_hip.h).
+    The one place the Python mirror derives it (`plan.dtype >= 1` sized float32 buffers for the relaxed dtype)."""
+    return np.dtype(np.float32) if int(plan.dtype) in (1, 2) else np.dtype(np.float64)
+
+
 def dtype_code(x):
     """CLOUDY_F64 (0) / CLOUDY_F32 (1) of a device array."""
     if isinstance(x, DeviceArray):

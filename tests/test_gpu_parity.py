@@ -926,6 +926,35 @@ def test_f64_relaxed_dtype_error_report(gpu_cloudy, oracle):
     assert np.array_equal(outs[0], outs[1], equal_nan=True)
 
 
+def test_python_helpers_allocate_fp64_planes_for_the_relaxed_dtype(gpu_cloudy):
+    """CLOUDY_F64_RELAXED (dtype code 3) has fp64 planes; the Python helpers that allocate their output
+    (get_sedimentation_flux, rainshaft_sources, get_standard_N_q with out=None) used `plan.dtype >= 1 -> float32` and handed
+    the kernels buffers of half the size they write.  They derive the plane type through device.plane_dtype now: the
+    outputs are float64 and equal to the CLOUDY_F64 plan's wherever the relaxed series tolerance plays no part."""
+    cloudy = gpu_cloudy
+    n = 5000
+    wl = bench.make_workload("cfg3b", n, seed=5)
+    vel = ((50.0, 1.0 / 6),)
+    p64 = wl["coal_data"].plan(wl["dist_types"], vel=vel, dtype=cloudy.F64)
+    prx = wl["coal_data"].plan(wl["dist_types"], vel=vel, dtype=cloudy.F64_RELAXED)
+    assert cloudy.plane_dtype(prx) == np.float64 and cloudy.plane_dtype(p64) == np.float64
+    assert cloudy.plane_dtype(wl["coal_data"].plan(wl["dist_types"], dtype=cloudy.F32)) == np.float32
+    assert cloudy.plane_dtype(wl["coal_data"].plan(wl["dist_types"], dtype=cloudy.F32_FAST)) == np.float32
+    m = dev(cloudy, wl["mom"])
+    f_rx, f_64 = cloudy.get_sedimentation_flux(prx, m), cloudy.get_sedimentation_flux(p64, m)
+    assert f_rx.dtype == np.float64 and f_rx.shape == (6, n)
+    assert np.array_equal(f_rx.to_numpy(), f_64.to_numpy(), equal_nan=True)
+    cs_rx, sf_rx = cloudy.rainshaft_sources(prx, m)
+    cs_64, sf_64 = cloudy.rainshaft_sources(p64, m)
+    assert cs_rx.dtype == np.float64 and sf_rx.dtype == np.float64
+    assert np.array_equal(sf_rx.to_numpy(), sf_64.to_numpy(), equal_nan=True)
+    a, b = cs_rx.to_numpy(), cs_64.to_numpy()
+    ok = np.isfinite(b)
+    assert np.array_equal(np.isfinite(a), ok) and np.max(np.abs(a - b)[ok] / np.maximum(np.abs(b[ok]), 1e-300)) < 1e-6
+    nq_rx, nq_64 = cloudy.get_standard_N_q(prx, m), cloudy.get_standard_N_q(p64, m)
+    assert nq_rx.dtype == np.float64 and np.array_equal(nq_rx.to_numpy(), nq_64.to_numpy(), equal_nan=True)
+
+
 @pytest.mark.parametrize("name,tol", [("cfg3a", TOL_POLY), ("cfg3b", TOL_QUAD)])
 def test_fused_ssprk33_batch_vs_oracle_stepping(gpu_cloudy, oracle, name, tol):
     """box_gamma_mixture_long.jl:37-46 pattern on a batch of different boxes, 4 steps.  The synthetic parcels span

@@ -465,3 +465,67 @@ def test_jit_selfcheck_reports_descriptor_errors(cloudy):
     d, keep = cloudy.Plan.make_desc([1], [[1.0, 2.0], [3.0, 4.0]], (INF,), (1.0, 1.0), 0)
     assert L.cloudy_jit_selfcheck(C.byref(d), None) == cloudy._lib.ENOTSYMMETRIC
     assert b"not symmetric" in L.cloudy_last_error()
+
+
+def _strict_loads(text):
+    """json.loads that rejects NaN / Infinity (what a strict parser on the driver's side does)"""
+    import json
+
+    def bad(name):
+        raise ValueError("non-standard JSON constant " + name)
+
+    return json.loads(text, parse_constant=bad)
+
+
+def test_bench_contract_line_is_compact_strict_json():
+    """BENCH_r04.parsed was null because bench.py printed one 20 KB line.  The LAST stdout line is now
+    assembled by bench.compact_line from the full result object: < 4 KB, strict JSON, headline + roofline + cpu_baseline +
+    per variant {value, kernel_ms, frac}.  Canned input: round 4's full 20 KB object (profiles/r04_bench.json), then the
+    same with 8 ranks, NaN / Inf values and three dozen variants."""
+    import copy
+    import json
+
+    import bench
+
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
+    assert len(json.dumps(full)) > 15000
+    line = bench.compact_line(full)
+    assert len(line) < 4096 and "\n" not in line
+    out = _strict_loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "collective", "variants", "variants_file"):
+        assert key in out, key
+    assert out["value"] == pytest.approx(full["value"], rel=1e-6) and out["ms_per_step"] == pytest.approx(full["ms_per_step"], rel=1e-6)
+    assert out["config"]["workload"].startswith("cfg3a: 10000000 parcels/GPU")
+    rl = out["roofline"]
+    assert rl["bound"] == "hbm" and rl["unit"] == "GB/s" and rl["peak"] == 8000.0 and rl["kernel"] == "cloudy_jit_allinf2_n2p3_f64"
+    assert rl["frac"] == pytest.approx(rl["achieved"] / rl["peak"], rel=1e-5) and rl["traffic"] > 9e8 and rl["kernel_ms"] > 0
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 16 and cb["value"] > 0 and cb["unit"] == "parcel-RHS/s" and cb["sample"]
+    assert set(out["variants"]) == set(full["variants"])
+    for name, v in out["variants"].items():
+        assert set(v) <= {"value", "kernel_ms", "frac", "unit"} and v["value"] > 0, name
+    assert out["variants"]["cfg4q_converged"]["frac"] == pytest.approx(full["variants"]["cfg4q_converged"]["roofline"]["frac"], rel=1e-3)
+    # a multi-rank line: one kernel_ms per rank; non-finite numbers become null; a flood of variants is dropped, not printed
+    big = copy.deepcopy(full)
+    big["n_gpus"] = 8
+    big["roofline"]["per_rank"] = [{"rank": r, "kernel_ms": 0.15 + 0.001 * r, "achieved": 6000.0, "frac": 0.75} for r in range(8)]
+    big["mass_rate_residual"] = float("nan")
+    big["variants"]["cfg2"]["value"] = float("inf")
+    big["collective_fallback"] = True
+    line8 = bench.compact_line(big)
+    out8 = _strict_loads(line8)
+    assert len(line8) < 4096 and out8["roofline"]["per_rank_kernel_ms"] == [pytest.approx(0.15 + 0.001 * r) for r in range(8)]
+    assert out8["mass_rate_residual"] is None and out8["variants"]["cfg2"]["value"] is None and out8["collective_fallback"] is True
+    for i in range(40):
+        big["variants"][f"extra_variant_with_a_long_name_{i:02d}"] = {"value": 1.0 * i, "kernel_ms": 2.0, "roofline": {"frac": 0.5}}
+    line_big = bench.compact_line(big)
+    out_big = _strict_loads(line_big)
+    assert len(line_big) < 4096 and "variants" not in out_big and out_big["roofline"]["frac"] > 0 and out_big["cpu_baseline"]
+    # the one-process form (no roofline block in its object) goes through the same assembly
+    one = {"metric": full["metric"], "value": 1e10, "unit": "parcel-RHS/s", "n_gpus": 2, "steps": 5, "warmup": 2, "ms_per_step": 0.3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "cfg3a: 300000 parcels/GPU", "global_parcels": 600000, "launch": "ONE process driving all GPUs"},
+           "collective": "ncclAllReduce", "mass_rate_residual": 1e-17}
+    o1 = _strict_loads(bench.compact_line(one))
+    assert o1["config"]["launch"].startswith("ONE process") and o1["cpu_baseline"] is None and o1["variants"] == {}

@@ -138,9 +138,11 @@ def test_bench_gpus_2_spawns_two_ranks(gpu_cloudy):
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["global_parcels"] == 800000 and out["scaling"] == "weak"
-    assert [r["rank"] for r in out["roofline"]["per_rank"]] == [0, 1]
-    assert all(r["kernel_ms"] > 0 for r in out["roofline"]["per_rank"])
+    assert len(line) < 4096 and len(out["roofline"]["per_rank_kernel_ms"]) == 2
+    assert all(ms > 0 for ms in out["roofline"]["per_rank_kernel_ms"])
     assert out["mass_rate_residual"] is not None and out["value"] > 0
+    # both ranks share the one GPU of the test box: no RCCL communicator can be formed, and the line says so
+    assert out["collective_fallback"] is True and "share one GPU" in out["collective"]
 
 
 @pytest.mark.gpu
@@ -157,10 +159,11 @@ def test_bench_gpus_8_on_one_gpu_with_an_empty_jit_cache(gpu_cloudy, tmp_path):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--parcels", "200000", "--steps", "3",
                         "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
-    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    line = p.stdout.splitlines()[-1]
+    assert len(line) < 4096, len(line)
+    out = json.loads(line)
     assert out["n_gpus"] == 8 and out["config"]["global_parcels"] == 1_600_000 and out["scaling"] == "weak"
-    assert [r["rank"] for r in out["roofline"]["per_rank"]] == list(range(8))
-    assert all(r["kernel_ms"] > 0 for r in out["roofline"]["per_rank"])
+    assert len(out["roofline"]["per_rank_kernel_ms"]) == 8 and all(ms > 0 for ms in out["roofline"]["per_rank_kernel_ms"])
     assert out["mass_rate_residual"] is not None and out["value"] > 0
     files = [f for f in os.listdir(cache) if not f.endswith(".tmp")]
     assert files and not [f for f in os.listdir(cache) if f.endswith(".tmp")], os.listdir(cache)
@@ -176,7 +179,9 @@ def test_bench_one_process_mode(gpu_cloudy):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--one-process", "--gpus", "1", "--parcels", "300000",
                         "--steps", "5", "--warmup", "2"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
-    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    line = p.stdout.splitlines()[-1]
+    assert len(line) < 4096
+    out = json.loads(line)
     assert out["n_gpus"] == 1 and out["config"]["global_parcels"] == 300000 and "ONE process" in out["config"]["launch"]
     assert out["value"] > 0 and out["mass_rate_residual"] < 1e-9 and "ncclAllReduce" in out["collective"]
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--one-process", "--gpus", "64", "--parcels", "1000",
@@ -256,6 +261,6 @@ def test_bench_single_rank_line_uses_the_c_abi_collective(gpu_cloudy):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--parcels", "400000", "--steps", "5", "--warmup", "2",
                         "--no-variants", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
-    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    out = json.loads(p.stdout.splitlines()[-1])
     assert "ncclAllReduce" in out["collective"] and "libcloudy_hip.so" in out["collective"], out["collective"]
-    assert out["mass_rate_residual"] is not None
+    assert out["mass_rate_residual"] is not None and out["collective_fallback"] is False

@@ -8,6 +8,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out
 mkdir -p $OUT
 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+cp bench_variants.json $OUT/${TAG}_bench_variants.json
 # (the profiled passes leave out the 1e8-parcel launch of configs[3]: every kernel name keeps ONE launch size in the stats)
 export CLOUDY_BENCH_SKIP_FULL=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 bench.py --steps 200 --warmup 50 --no-cpu-baseline > $OUT/${TAG}_stats_bench.json 2> $OUT/${TAG}_stats.err

@@ -15,7 +15,7 @@ def newest(pattern):
 
 for f in newest(os.path.join(src, f"{tag}_stats", "*", "*kernel_stats.csv")):
     shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats.csv"))
-for name in ("bench.json", "hbm_ceiling.txt"):
+for name in ("bench.json", "bench_variants.json", "hbm_ceiling.txt"):
     f = os.path.join(src, f"{tag}_{name}")
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, f"{tag}_{name}"))
