@@ -639,6 +639,81 @@ __device__ __forceinline__ double conv_long_G_mid(const QArgs &Q, double k, doub
     return fma(ca, s, fma(fma(cb, s2, -(ca * s)), P0, -2.0 * cb * s2 * P1));
 }
 
+// ---- Long kernel, x_t < s < 2 x_t: I_y(k, k), y = 1 - x_t / s in (0, 1/2), from a per-rule table (round 5) ----
+// Rounds 3-4 ran one incomplete-beta continued fraction per node there (inc_beta_cf: ~7 double steps on average, each lane
+// as many as ITS (k, y) needs, the wave as many as its slowest lane): a Long-kernel rule cost 3.7 x a hydrodynamic one per
+// evaluation (7.4e7 against 4.6e8 parcel-RHS/s).  For fixed k the function is smooth in y once its
+// end-point behaviour is factored out:
+//     I_y(k, k) = y^k / (k B(k, k)) g(y),   g(y) = (1 - y)^k 2F1(2k, 1; k+1; y) = 2F1(1-k, k; k+1; y)   (Euler)
+// -- g is a polynomial for integer k, bounded by 1, with its only singularity at y = 1 -- so a rule tabulates g ONCE, before
+// the walk, at kLongNT Chebyshev points of [0, 1/2] (one continued fraction each: every lane the same dozen), turns the values
+// into Chebyshev coefficients (the cosine transform below: perfectly conditioned) and a node between x_t and 2 x_t costs one
+// logarithm, two exponentials and a kLongNT-term Clenshaw sum, the same for every lane.  Truncation + rounding against
+// 30-digit mpmath over k in [1e-8, 10]: <= 7e-13 absolute in I_y (kLongNT = 12); shapes beyond kLongTabKmax (a plan whose
+// k_range allows them) keep the continued fraction per node, as do N = 4 plans (the tables of three rules would not leave
+// two workgroups per CU their LDS).
+constexpr int kLongNT = 12;
+constexpr double kLongTabKmax = 10.0;
+// y_i = (1 + cos(pi (i + 1/2) / 12)) / 4 and ln(1 - y_i)
+__device__ static const double kLongY[kLongNT] = {0.4978612153434526028, 0.480969883127821689, 0.4483383350728087911, 0.4021903572521801599, 0.3456708580912724429, 0.2826315480550128979, 0.2173684519449871021, 0.1543291419087275571, 0.09780964274781984015, 0.05166166492719120886, 0.01903011687217831097, 0.002138784656547397214};
+__device__ static const double kLongL1mY[kLongNT] = {-0.6888787340401301498, -0.65579336884439617, -0.5948203464774217886, -0.5144828988712590366, -0.4241447790355740864, -0.3321656903945551713, -0.2450932581667887604, -0.1676250517077815243, -0.1029297421028883111, -0.05304394686174657753, -0.01921352006354706144, -0.002141075122909895517};
+// kLongDct[i][r] = (r == 0 ? 1 : 2) / 12 cos(r pi (i + 1/2) / 12): coefficient r of the Chebyshev series from the node values
+__device__ static const double kLongDct[kLongNT][kLongNT] = {
+    {0.08333333333333333333, 0.1652408102289684019, 0.1609876377148447145, 0.1539799220852144594, 0.1443375672974064411, 0.1322255567152058608, 0.1178511301977579207, 0.1014602381681201066, 0.08333333333333333333, 0.06378057206084829529, 0.04313650751708679372, 0.02175436537000859859},
+    {0.08333333333333333333, 0.1539799220852144594, 0.1178511301977579207, 0.06378057206084829529, 0.0, -0.06378057206084829529, -0.1178511301977579207, -0.1539799220852144594, -0.1666666666666666667, -0.1539799220852144594, -0.1178511301977579207, -0.06378057206084829529},
+    {0.08333333333333333333, 0.1322255567152058608, 0.04313650751708679372, -0.06378057206084829529, -0.1443375672974064411, -0.1652408102289684019, -0.1178511301977579207, -0.02175436537000859859, 0.08333333333333333333, 0.1539799220852144594, 0.1609876377148447145, 0.1014602381681201066},
+    {0.08333333333333333333, 0.1014602381681201066, -0.04313650751708679372, -0.1539799220852144594, -0.1443375672974064411, -0.02175436537000859859, 0.1178511301977579207, 0.1652408102289684019, 0.08333333333333333333, -0.06378057206084829529, -0.1609876377148447145, -0.1322255567152058608},
+    {0.08333333333333333333, 0.06378057206084829529, -0.1178511301977579207, -0.1539799220852144594, 3.723127401091647207e-42, 0.1539799220852144594, 0.1178511301977579207, -0.06378057206084829529, -0.1666666666666666667, -0.06378057206084829529, 0.1178511301977579207, 0.1539799220852144594},
+    {0.08333333333333333333, 0.02175436537000859859, -0.1609876377148447145, -0.06378057206084829529, 0.1443375672974064411, 0.1014602381681201066, -0.1178511301977579207, -0.1322255567152058608, 0.08333333333333333333, 0.1539799220852144594, -0.04313650751708679372, -0.1652408102289684019},
+    {0.08333333333333333333, -0.02175436537000859859, -0.1609876377148447145, 0.06378057206084829529, 0.1443375672974064411, -0.1014602381681201066, -0.1178511301977579207, 0.1322255567152058608, 0.08333333333333333333, -0.1539799220852144594, -0.04313650751708679372, 0.1652408102289684019},
+    {0.08333333333333333333, -0.06378057206084829529, -0.1178511301977579207, 0.1539799220852144594, 3.998731682401833717e-42, -0.1539799220852144594, 0.1178511301977579207, 0.06378057206084829529, -0.1666666666666666667, 0.06378057206084829529, 0.1178511301977579207, -0.1539799220852144594},
+    {0.08333333333333333333, -0.1014602381681201066, -0.04313650751708679372, 0.1539799220852144594, -0.1443375672974064411, 0.02175436537000859859, 0.1178511301977579207, -0.1652408102289684019, 0.08333333333333333333, 0.06378057206084829529, -0.1609876377148447145, 0.1322255567152058608},
+    {0.08333333333333333333, -0.1322255567152058608, 0.04313650751708679372, 0.06378057206084829529, -0.1443375672974064411, 0.1652408102289684019, -0.1178511301977579207, 0.02175436537000859859, 0.08333333333333333333, -0.1539799220852144594, 0.1609876377148447145, -0.1014602381681201066},
+    {0.08333333333333333333, -0.1539799220852144594, 0.1178511301977579207, -0.06378057206084829529, 3.585325260436553952e-42, 0.06378057206084829529, -0.1178511301977579207, 0.1539799220852144594, -0.1666666666666666667, 0.1539799220852144594, -0.1178511301977579207, 0.06378057206084829529},
+    {0.08333333333333333333, -0.1652408102289684019, 0.1609876377148447145, -0.1539799220852144594, 0.1443375672974064411, -0.1322255567152058608, 0.1178511301977579207, -0.1014602381681201066, 0.08333333333333333333, -0.06378057206084829529, 0.04313650751708679372, -0.02175436537000859859}};
+
+// the Chebyshev coefficients of g for shape k, left in the lane's own LDS slots sh[row0 + r][lane] (conflict-free, no barrier:
+// a lane reads what it wrote)
+template <int NROW>
+__device__ __forceinline__ void conv_long_tab_build(double k, double (&sh)[NROW][kBlock], int row0) {
+    double c[kLongNT];
+#pragma unroll
+    for (int r = 0; r < kLongNT; ++r) c[r] = 0.0;
+#pragma unroll 1
+    for (int i = 0; i < kLongNT; ++i) {
+        // (1 - y)^k 2F1(2k, 1; k+1; y): inc_beta_cf(k, k, y) is the hypergeometric factor (y < 1/2: its range of convergence)
+        const double g = exp_fin(k * kLongL1mY[i]) * inc_beta_cf(k, k, kLongY[i]);
+#pragma unroll
+        for (int r = 0; r < kLongNT; ++r) c[r] = fma(kLongDct[i][r], g, c[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < kLongNT; ++r) sh[row0 + r][threadIdx.x] = c[r];
+}
+// E_tau[K(s (1 - tau), s tau)] for x_t < s < 2 x_t from the table: lx = ln(x_t / s) (the rule has it for free),
+// c0 = 1 / (k B(k, k)), rB = B(k+1, k+1) / B(k, k)
+template <int NROW>
+__device__ __forceinline__ double conv_long_G_mid_tab(const QArgs &Q, double k, double c0, double rB, double s, double lx,
+                                                      const double (&sh)[NROW][kBlock], int row0) {
+    const double xt = Q.kf[0], cb = Q.kf[1], ca = Q.kf[2];
+    const double x = xt * recip_fast(s), y = 1.0 - x;   // y in (0, 1/2)
+    const double z2 = fma(8.0, y, -2.0);                // 2 z, z = 4 y - 1 in [-1, 1]
+    double b1 = 0.0, b2 = 0.0;                           // Clenshaw: b_r = c_r + 2 z b_{r+1} - b_{r+2}
+#pragma unroll
+    for (int r = kLongNT - 1; r >= 1; --r) {
+        const double b0 = fma(z2, b1, sh[row0 + r][threadIdx.x]) - b2;
+        b2 = b1;
+        b1 = b0;
+    }
+    const double g = fma(0.5 * z2, b1, sh[row0][threadIdx.x]) - b2;
+    const double yk = exp_fin(k * log_pos(y)) * c0;      // y^k / (k B(k, k))
+    const double Dk = yk * exp_fin(k * lx);              // x^k y^k / (k B(k, k)) = D(k, k) / k
+    const double Ikk = fma(-yk, g, 1.0);                 // I_x(k, k) = 1 - I_y(k, k)
+    const double Ik1k1 = fma(Dk, fma(2.0, x, -1.0), Ikk);  // I_x(k+1, k+1) = I_x(k, k) - D/k + 2 x D/k
+    const double P0 = fma(2.0, Ikk, -1.0), P1 = rB * fma(2.0, Ik1k1, -1.0);
+    const double s2 = s * s;
+    return fma(ca, s, fma(fma(cb, s2, -(ca * s)), P0, -2.0 * cb * s2 * P1));
+}
+
 // T_m of a LOGNORMAL mode j: the sum of two Lognormal variates has no closed law, so two variables remain,
 //   s = x + y,  t = ln(x / y):   f(x) f(y) dx dy = n^2 g(ln x) g(ln y) d(ln s) dt   (g: the normal density of ln x),
 //   T_m = 1/2 n^2 int d(ln s) s^m (1 - w(s)) G2(ln s),   G2 = 2 int_0^inf dt K(x, y) g(ln x) g(ln y),
@@ -756,6 +831,7 @@ struct ConvRule {
     double A, lgA, th, lnth, tlo, thi;
     double gl;                     // Long: (k + 1) / (2k + 1), the factor of G below x_t
     double kj, lgB, rB, ex1, ex2;  // Long: the shape, -ln B(k, k), B(k+1, k+1) / B(k, k), the kinks of G in the rule's variable
+    double c0;                     // Long: 1 / (k B(k, k))  (conv_long_G_mid_tab)
     double sc[3];                  // Long: the scale of each output (T_m with 1 - w = 1, over the prefactor)
     // the bound of what is left of the integral below an edge (the walk goes DOWN and stops early, see conv_T_merged):
     double tmode, lwmode;          // ln A, ln of the weight's maximum
@@ -765,18 +841,24 @@ struct ConvRule {
     int mI[NM];
 };
 
-template <int N, int KIND>
+template <int N, int KIND, bool LTAB, int NROW>
 __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensity (&lg)[N],
                                               const ConvRule<(N > 1 ? N - 1 : 1)> (&rb)[(N > 1 ? N - 1 : 1)],
-                                              double (&Traw)[(N > 1 ? N - 1 : 1)][3]) {
+                                              double (&Traw)[(N > 1 ? N - 1 : 1)][3], const double (&gtab)[NROW][kBlock]) {
     constexpr int NM = N > 1 ? N - 1 : 1, NR = NM;
-    // (the Long kernel's G(s) is only finitely smooth at s = x_t and 2 x_t -- the Beta(k, k) law of tau ends like tau^(k-1)
-    // there -- and K15 converges slowly in the panels next to them: 1e-9 of scale at 1e-8 on random mixtures, against
-    // 1e-10 ... 1e-13 for the homogeneous kernels; its rules run at a tenth of the tolerance)
-    constexpr double kTolT = KIND == KF_LONG ? 0.01 * kConvTol : kConvTol;
+    // The Long kernel's G(s) behaves like (s - x_t)^k just above x_t (the Beta(k, k) law of tau ends like tau^(k-1)), so K15
+    // converges only algebraically in the panel whose lower edge is x_t; rounds 3-4 ran the Long rules at a hundredth of the
+    // tolerance for it (43 against 30 panel evaluations per parcel, 1e-9 of scale on random mixtures, shapes below 0.1 not
+    // converged at the depth limit).  Round 5: THAT initial panel [a0, a0 + h] is integrated in xi, t = a0 + h xi^4,
+    // dt = 4 h xi^3 d xi -- integrand x Jacobian ~ xi^(4k + 3) -- and the bisection works on xi in [0, 1]; every other panel has
+    // t = a0 + h xi.  Same tolerance as the other kernels now: 33 evaluations per parcel, <= 5e-12 of scale on 600 random
+    // mixtures with shapes down to 1e-3 (against the rule at 1e-13).
+    constexpr double kTolT = kConvTol;
+    constexpr bool kLong = KIND == KF_LONG;
+    bool sing = false;   // Long: the initial panel in hand has x_t as its lower edge
     // ---- the state of the rule in hand
     int j = -1;
-    double A = 1.0, lgA = 0.0, thj = 1.0, lnthj = 0.0, tlo = 0.0, thi = 0.0, kj = 1.0, lgB = 0.0, rB = 0.0, gl = 0.0;
+    double A = 1.0, lgA = 0.0, thj = 1.0, lnthj = 0.0, tlo = 0.0, thi = 0.0, kj = 1.0, lgB = 0.0, rB = 0.0, gl = 0.0, c0 = 0.0;
     double scaleS[3] = {1.0, 1.0, 1.0}, out[3] = {0.0, 0.0, 0.0};
     double tmode = 0.0, lwmode = 0.0, lnup = 0.0, ltlo[NM];
     bool convex = false;
@@ -838,6 +920,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
                 gl = sel ? rb[r].gl : gl;
                 lgB = sel ? rb[r].lgB : lgB;
                 rB = sel ? rb[r].rB : rB;
+                c0 = sel ? rb[r].c0 : c0;
                 mk.extra[1] = sel ? rb[r].ex1 : mk.extra[1];
                 mk.extra[2] = sel ? rb[r].ex2 : mk.extra[2];
                 scaleS[0] = sel ? rb[r].sc[0] : scaleS[0];
@@ -944,15 +1027,22 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
         cur = go ? nxt : cur;
         L = go ? 0 : L;
         i = go ? 0u : i;
+        if (kLong) sing = go ? nxt == mk.extra[1] : sing;
         return need && !go;
     };
     next_rule(true);
     (void)next_panel(busy);
 #pragma unroll 1
     while (busy) {
-        const double w = ldexp(h, -L), hw = 0.5 * w, c = fma(w, double(i), a0) + hw;
+        // the panel in xi (its position inside the initial panel [a0, a0 + h]): centre (i + 1/2) 2^-L, half width 2^-(L+1)
+        const double hx = ldexp(0.5, -L), cx = fma(2.0 * hx, double(i), hx);
+        const double hw = h * hx, c = fma(h, cx, a0);   // half width and centre in t of a plain panel
         double K[3] = {0.0, 0.0, 0.0}, G[3] = {0.0, 0.0, 0.0};
         --budget;
+        // (Long, table: does any lane's panel reach into x_t < s < 2 x_t?  Those two sizes are panel edges -- marks of the
+        // rule -- so a panel lies on one side of each up to the 1e-7 `gap` rule; the test is on the panel, the selection per node)
+        const bool wave_mid = kLong && LTAB &&
+                              __builtin_amdgcn_ballot_w64(sing || (c + hw > mk.extra[1] && c - hw < mk.extra[2])) != 0ull;
         // one node: t, u = e^t, its Kronrod weight and (Gauss nodes) its Gauss weight
         const auto eval_node = [&](double t, double u, double wk, double wg, bool gauss) {
             const double wt = exp_fin(fma(A, t, -u) - lgA);
@@ -967,15 +1057,22 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
                 up = fma(upw[sl], rho, up);
             }
             double hh = wt * (up * recip_fast(den));
-            if (KIND == KF_LONG) {
+            if (kLong) {
                 const double xt = Q.kf[0];
-                double Gs;
-                if (s <= xt)
-                    Gs = Q.kf[1] * (s * s) * gl;
-                else if (s >= 2.0 * xt)
-                    Gs = Q.kf[2] * s;
-                else
+                const bool below = s <= xt, mid = !below && s < 2.0 * xt;
+                double Gs = below ? (Q.kf[1] * gl) * (s * s) : Q.kf[2] * s;   // both particles below x_t / the larger one above
+                if (LTAB) {
+                    // Between x_t and 2 x_t: the table, as straight-line code every lane of the wave runs through (a lane
+                    // outside the range computes on y <= 0 or y > 1/2 and drops the result) -- skipped, by a wave-level vote
+                    // taken once per trip, when no lane's panel reaches into that range.  (Round 4 branched per node and lane:
+                    // 0.46 active lanes, and the branches kept the 15 unrolled nodes from sharing registers.)
+                    if (wave_mid) {
+                        const double Gm = conv_long_G_mid_tab(Q, kj, c0, rB, s, mk.extra[1] - t, gtab, j * kLongNT);
+                        Gs = mid ? Gm : Gs;
+                    }
+                } else if (mid) {
                     Gs = conv_long_G_mid(Q, kj, lgB, rB, s);
+                }
                 hh *= Gs;
             }
             const double v0 = hh, v1 = hh * s, v2 = (hh * s) * s;
@@ -988,18 +1085,38 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
                 G[2] = fma(wg, v2, G[2]);
             }
         };
-        // The Kronrod nodes are symmetric about the centre: e^(c +- d) = e^c e^(+-d), so a pair of nodes shares ONE exponential
-        // and its reciprocal (8 exponentials + 7 reciprocals per panel for the 15 values of u instead of 15 exponentials; round
-        // 4).  The pairs are taken from the outside in (g = 0 with 14, ...), the centre last.
-        const double uc = exp_fin(c);
+        if (kLong) {
+            // The pairs of Kronrod nodes as a ROLLED loop (their constants come through scalar loads): unrolled, the 15 copies
+            // of the node -- each with the table branch -- left 220 registers in scratch, 221 scratch accesses per trip and
+            // 20 KB of HBM traffic per parcel (VALU busy 0.35; round 5 PMC); rolled: 30 accesses per trip, 66.7 -> 28.7 ms per
+            // 4e6 parcels.  Node positions go through xi; the panel with the singular edge maps t = a0 + h xi^4.
+            const auto node_at = [&](double xi, double wk, double wg) {
+                const double xi2 = xi * xi;
+                const double tt = sing ? xi2 * xi2 : xi, jac = sing ? 4.0 * (xi2 * xi) : 1.0;
+                const double t = fma(h, tt, a0);
+                eval_node(t, exp_fin(t), wk * jac, wg * jac, true);
+            };
+#pragma unroll 1
+            for (int g = 0; g < 7; ++g) {
+                const double dx = hx * kGKX[14 - g], wk = kGKWK[g], wg = kGKWG[g];
+                node_at(cx - dx, wk, wg);
+                node_at(cx + dx, wk, wg);
+            }
+            node_at(cx, kGKWK[7], kGKWG[7]);
+        } else {
+            // The Kronrod nodes are symmetric about the centre: e^(c +- d) = e^c e^(+-d), so a pair of nodes shares ONE exponential
+            // and its reciprocal (8 exponentials + 7 reciprocals per panel for the 15 values of u instead of 15 exponentials; round
+            // 4).  The pairs are taken from the outside in (g = 0 with 14, ...), the centre last.
+            const double uc = exp_fin(c);
 #pragma unroll
-        for (int g = 0; g < 7; ++g) {
-            const double d = hw * kGKX[14 - g];   // > 0
-            const double e = exp_fin(d), re = recip_fast(e);
-            eval_node(c - d, uc * re, kGKWK[g], kGKWG[g], (g & 1) != 0);
-            eval_node(c + d, uc * e, kGKWK[14 - g], kGKWG[14 - g], (g & 1) != 0);
+            for (int g = 0; g < 7; ++g) {
+                const double d = hw * kGKX[14 - g];   // > 0
+                const double e = exp_fin(d), re = recip_fast(e);
+                eval_node(c - d, uc * re, kGKWK[g], kGKWG[g], (g & 1) != 0);
+                eval_node(c + d, uc * e, kGKWK[14 - g], kGKWG[14 - g], (g & 1) != 0);
+            }
+            eval_node(c, uc, kGKWK[7], kGKWG[7], true);
         }
-        eval_node(c, uc, kGKWK[7], kGKWG[7], true);
         bool ok = true;
 #pragma unroll
         for (int e = 0; e < 3; ++e)
@@ -1094,6 +1211,7 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
             r.A = r.lgA = r.th = 1.0;
             r.lnth = r.tlo = r.thi = r.kj = r.lgB = r.rB = r.gl = 0.0;
             r.ex1 = r.ex2 = INFINITY;
+            r.c0 = 0.0;
             r.sc[0] = r.sc[1] = r.sc[2] = 1.0;
             r.tmode = r.lwmode = 0.0;
             r.convex = false;
@@ -1161,6 +1279,7 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
             if (KIND == KF_LONG) {
                 r.lgB = lgamma_pos(2.0 * kj) - 2.0 * lgkj_[j];  // -ln B(k, k)
                 r.rB = kj / (2.0 * fma(2.0, kj, 1.0));           // B(k+1, k+1) / B(k, k)
+                r.c0 = exp_fin(r.lgB) / kj;                      // 1 / (k B(k, k))
                 // (totals: T_m with 1 - w = 1 -- half the self-collision integrals of orders 0, 1, 2 -- the estimates' scale)
                 const double rp = 1.0 / prefj[j];
                 r.sc[0] = (0.5 * pr[0]) * rp;
@@ -1182,7 +1301,16 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
 #pragma unroll
             for (int j = 0; j < N - 1; ++j) sh_park[3 * N + j][t] = prefj[j];
 #endif
-            conv_T_merged<N, KIND>(Q, lg, rb, Traw);
+            constexpr bool kTabFits = KIND == KF_LONG && N <= 3;
+            __shared__ double sh_gtab[kTabFits ? (N > 1 ? N - 1 : 1) * kLongNT : 1][kBlock];
+            if (kTabFits && A.kmax <= kLongTabKmax) {   // (wave-uniform; a compile-time fact in a kernel compiled for the plan)
+#pragma unroll
+                for (int j = 0; j < N - 1; ++j)
+                    if (!lnj_[j] && kTabFits) conv_long_tab_build(kj_[j], sh_gtab, kTabFits ? j * kLongNT : 0);
+                conv_T_merged<N, KIND, kTabFits>(Q, lg, rb, Traw, sh_gtab);
+            } else {
+                conv_T_merged<N, KIND, false>(Q, lg, rb, Traw, sh_gtab);
+            }
 #ifndef CLOUDY_CONV_NO_PARK
 #pragma unroll
             for (int k = 0; k < N; ++k)

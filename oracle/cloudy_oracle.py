@@ -484,7 +484,7 @@ def get_coal_ints_numerical_fixed(pdists, kf, nq=10, with_scale=False):
     return (out, sc) if with_scale else out
 
 
-CONV_TOL = 1e-7   # acceptance tolerance of the converged mode's adaptive rules (kConvTol in csrc/quad_conv.hpp); the Long kernel's rules run at 1e-9
+CONV_TOL = 1e-7   # acceptance tolerance of the converged mode's adaptive rules (kConvTol in csrc/quad_conv.hpp), every kernel function
 
 
 def get_coal_ints_numerical_converged(pdists, kf, q=8, tol=CONV_TOL, with_scale=False, with_nodes=False):

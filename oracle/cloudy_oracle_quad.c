@@ -608,8 +608,19 @@ static void co_conv_adaptive(double tlo, double thi, const double *marks, int nm
  * bound(b, B[3], ctx) returns the three bounds. */
 #define CO_CONV_TERM_TOL 1e-10
 typedef void (*co_bound_fn)(double b, double *B, void *ctx);
+/* Round 5 -- an END-POINT SINGULARITY inside the range (the Long kernel: G(s) behaves like (s - x_t)^k just above x_t, k the
+ * shape of the mode, so K15 converges only algebraically in the panel whose lower edge is x_t and rounds 3-4 ran the Long
+ * rules at a hundredth of the tolerance, 43 against 30 panel evaluations per parcel): the initial panel [a0, a0 + h] whose
+ * LOWER edge is `sing_edge` is integrated in xi, t = a0 + h xi^P, P = CO_CONV_SING_P = 4, dt = h P xi^(P-1) d xi -- the integrand
+ * times the Jacobian behaves like xi^(P k + P - 1) there, and the bisection works on xi in [0, 1].  Every other panel has
+ * t = a0 + h xi.  sing_edge = NaN: none. */
+#define CO_CONV_SING_P 4
+static double co_conv_long_tol_factor_ = 1.0;   /* (experiments; rounds 3-4: 0.01) */
+void co_conv_set_long_tol_factor(double f) { co_conv_long_tol_factor_ = f; }
+static int co_conv_sing_p_ = CO_CONV_SING_P;   /* (experiments: 1 switches the substitution off) */
+void co_conv_set_sing_p(int p) { co_conv_sing_p_ = p; }
 static void co_conv_descending(double tlo, double thi, const double *marks, int nmarks, double tol, const double *scaleS,
-                               int budget, co_vec_fn f, co_bound_fn bound, void *ctx, double *out) {
+                               int budget, co_vec_fn f, co_bound_fn bound, void *ctx, double sing_edge, double *out) {
     double vals[3], K[3], G[3], B[3];
     const double h0 = (thi - tlo) / CO_CONV_NINIT, gap = 1e-7 * (thi - tlo);
     double cur = thi;
@@ -631,21 +642,32 @@ static void co_conv_descending(double tlo, double thi, const double *marks, int 
             if (marks[m] < lim && marks[m] > nxt) nxt = marks[m];
         if (nxt < tlo + gap) nxt = tlo;
         const double a0 = nxt, h = cur - nxt;
+        const int sing = co_conv_sing_p_ > 1 && a0 == sing_edge;
         cur = nxt;
         int L = 0;
         unsigned i = 0;
         for (;;) {
-            const double w = ldexp(h, -L), hw = 0.5 * w, c = (a0 + w * i) + hw;
+            /* the panel in xi: centre (i + 1/2) 2^-L, half width 2^-(L+1) */
+            const double wx = ldexp(1.0, -L), hx = 0.5 * wx, cx = wx * i + hx;
             for (int o = 0; o < 3; ++o) K[o] = G[o] = 0.0;
             --budget;
             for (int g = 0; g < 15; ++g) {
-                f(c + hw * CO_GK_X[g], vals, ctx);
+                const double xi = cx + hx * CO_GK_X[g];
+                double t = a0 + h * xi, jac = 1.0;
+                if (sing) {
+                    const double xp1 = co_ipow(xi, co_conv_sing_p_ - 1);
+                    t = a0 + h * (xp1 * xi);
+                    jac = co_conv_sing_p_ * xp1;
+                }
+                f(t, vals, ctx);
                 ++co_conv_nodes_;
                 for (int o = 0; o < 3; ++o) {
-                    K[o] += CO_GK_WK[g] * vals[o];
-                    if (g & 1) G[o] += CO_GK_WG[g] * vals[o];
+                    const double v = vals[o] * jac;
+                    K[o] += CO_GK_WK[g] * v;
+                    if (g & 1) G[o] += CO_GK_WG[g] * v;
                 }
             }
+            const double hw = h * hx;
             int ok = 1;
             for (int o = 0; o < 3; ++o)
                 if (fabs(K[o] - G[o]) * hw > tol * fmax(fabs(out[o] + K[o] * hw), CO_CONV_FLOOR * scaleS[o])) ok = 0;
@@ -1059,9 +1081,10 @@ int co_get_coal_ints_numerical_converged(const co_dist *pdists, int N, const co_
                 /* (the Long kernel's G(s) is only finitely smooth at s = x_t and 2 x_t -- the Beta(k, k) law of tau ends like
                  * tau^(k-1) there -- and K15 converges slowly in the panels next to them: measured 1e-9 of scale at tol =
                  * 1e-8 on random mixtures, against 1e-10 ... 1e-13 for the homogeneous kernels; its rules run at tol / 10) */
-                const double tol_T = lng ? 0.01 * tol : tol;
+                const double tol_T = lng ? co_conv_long_tol_factor_ * tol : tol;
                 if (co_conv_walk_down_)
-                    co_conv_descending(tlo, thi, marks, nm, tol_T, tolS, CO_CONV_BUDGET, co_T_node, co_T_bound, &c, T);
+                    co_conv_descending(tlo, thi, marks, nm, tol_T, tolS, CO_CONV_BUDGET, co_T_node, co_T_bound, &c,
+                                       lng ? marks[nm - 2] : NAN, T);
                 else
                     co_conv_adaptive(tlo, thi, marks, nm, 3, NULL, 0, tol_T, tolS, CO_CONV_BUDGET, co_T_node, &c, T);
                 if (!lng) { /* the mass below t_lo (1e-13 of the weight; a sizeable part of it for a shape clamped to eps) */

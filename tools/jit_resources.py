@@ -34,7 +34,18 @@ def main():
     L = pkg.lib()
     for name in a.workloads:
         before = set(glob.glob(os.path.join(dump, "*.co")))
-        if name in ("cfg4q", "cfg4q_converged"):
+        if name.startswith(("conv:", "quad:")):
+            # conv:<kernel>:<dist,dist,...>  e.g. conv:long:1,1,1  conv:linear:3,3  (1 Gamma, 0 Exponential, 3 Lognormal)
+            mode, kname, dists = name.split(":")
+            kf = {"constant": pkg.ConstantKernelFunction(1e-4), "linear": pkg.LinearKernelFunction(5.0),
+                  "hydrodynamic": pkg.HydrodynamicKernelFunction(1e2 * np.pi),
+                  "long": pkg.LongKernelFunction(5.236e-10, 9.44e9, 5.78)}[kname]
+            conv = mode == "conv"
+            d = pkg.NumericalPlan.make_desc([int(x) for x in dists.split(",")], kf, bench.NORMS, 8 if conv else 10,
+                                            kernel_func_is_normalized=False,
+                                            quad_mode=pkg.QUAD_CONVERGED if conv else pkg.QUAD_FIXED)
+            keep = None
+        elif name in ("cfg4q", "cfg4q_converged"):
             conv = name.endswith("converged")
             d = pkg.NumericalPlan.make_desc([1, 1, 1], pkg.HydrodynamicKernelFunction(1e2 * np.pi), bench.NORMS,
                                             8 if conv else 10, kernel_func_is_normalized=False,
