@@ -841,11 +841,23 @@ struct ConvRule {
     int mI[NM];
 };
 
-template <int N, int KIND, bool LTAB, int NROW>
+// PHASE (the Long kernel only; 0 for the others): the range x_t < s < 2 x_t of a Long rule -- where G(s) needs the incomplete
+// beta table, ~115 instructions per node on top of the ~130 of any node -- is a few panels of a rule, but the lanes of a wave
+// reach theirs in different trips, so a walk that takes the panels in order has some lane there in almost every trip and the
+// whole wave pays for the table code in all of them (round 5, first version: 22.2 ms per 4e6 parcels, 172 k VALU instructions
+// per parcel against 73 k for the hydrodynamic kernel).  The walk is therefore split: PHASE 1 walks every rule of the parcel
+// from t_hi down to t_lo and JUMPS over [x_t, 2 x_t] (the "hole": both ends are forced panel edges) -- G is c_a s above and
+// c_b s^2 (k+1)/(2k+1) below, the loop is the hydrodynamic kernel's; PHASE 2, a second loop every lane of the wave enters
+// together, walks the holes of the parcel's rules from 2 x_t down to x_t with the table code unconditional.  The accumulated
+// sums of a rule carry over (the acceptance test of a hole's panels compares with everything outside the hole); the bound
+// that ends a rule early covers the hole while the walk is above it (midneed[r] = false then: the hole is negligible too).
+template <int N, int KIND, bool LTAB, int PHASE, int NROW>
 __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensity (&lg)[N],
                                               const ConvRule<(N > 1 ? N - 1 : 1)> (&rb)[(N > 1 ? N - 1 : 1)],
-                                              double (&Traw)[(N > 1 ? N - 1 : 1)][3], const double (&gtab)[NROW][kBlock]) {
+                                              double (&Traw)[(N > 1 ? N - 1 : 1)][3], bool (&midneed)[(N > 1 ? N - 1 : 1)],
+                                              const double (&gtab)[NROW][kBlock]) {
     constexpr int NM = N > 1 ? N - 1 : 1, NR = NM;
+    static_assert((KIND == KF_LONG) == (PHASE != 0), "the Long kernel's rules are walked in two phases, the others in one");
     // The Long kernel's G(s) behaves like (s - x_t)^k just above x_t (the Beta(k, k) law of tau ends like tau^(k-1)), so K15
     // converges only algebraically in the panel whose lower edge is x_t; rounds 3-4 ran the Long rules at a hundredth of the
     // tolerance for it (43 against 30 panel evaluations per parcel, 1e-9 of scale on random mixtures, shapes below 0.1 not
@@ -855,7 +867,10 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
     // mixtures with shapes down to 1e-3 (against the rule at 1e-13).
     constexpr double kTolT = kConvTol;
     constexpr bool kLong = KIND == KF_LONG;
-    bool sing = false;   // Long: the initial panel in hand has x_t as its lower edge
+    bool sing = false;   // PHASE 2: the initial panel in hand has x_t as its lower edge
+    double stop = 0.0;   // the lower end of the walk: t_lo, or the lower end of the hole (PHASE 2)
+    double hlo = 0.0, hhi = 0.0;   // the hole [x_t, 2 x_t] in the rule's variable, clamped to [t_lo, t_hi]
+    bool mid_flag = false;         // PHASE 1, set by next_panel when a rule ends: its hole has to be walked
     // ---- the state of the rule in hand
     int j = -1;
     double A = 1.0, lgA = 0.0, thj = 1.0, lnthj = 0.0, tlo = 0.0, thi = 0.0, kj = 1.0, lgB = 0.0, rB = 0.0, gl = 0.0, c0 = 0.0;
@@ -898,7 +913,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
         int jn = NR;
 #pragma unroll
         for (int r = NR - 1; r >= 0; --r)
-            if (rb[r].valid && r > j) jn = r;
+            if (rb[r].valid && (PHASE != 2 || midneed[r]) && r > j) jn = r;
         const bool go = need && jn < NR;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
@@ -973,13 +988,25 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
                 scaleS[1] = A * thj;
                 scaleS[2] = A * (A + 1.0) * thj * thj;
             }
-            cur = thi;
-            a0 = thi;
+            stop = tlo;
+            if (PHASE != 0) {
+                hlo = fmin(fmax(mk.extra[1], tlo), thi);
+                hhi = fmin(fmax(mk.extra[2], tlo), thi);
+            }
+            cur = PHASE == 2 ? hhi : thi;
+            if (PHASE == 2) stop = hlo;
+            a0 = cur;
             io = kConvNInit - 1;
             L = 0;
             i = 0u;
             budget = kConvBudget;
             out[0] = out[1] = out[2] = 0.0;
+        }
+        if (PHASE == 2) {   // the sums of phase 1 carry over
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int e = 0; e < 3; ++e) out[e] = (go && jn == r) ? Traw[r][e] : out[e];
         }
         busy = need ? go : busy;
     };
@@ -1002,32 +1029,40 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
             lmax = sl >= j ? fmax(lmax, l) : lmax;
         }
         const double lsig = convex ? fmin(0.0, lmax + lnup) : 0.0;
-        double Bv = exp_fin(lw + lsig) * (cur - tlo);
+        double Bv = exp_fin(lw + lsig) * (cur - stop);
         if (KIND == KF_LONG) Bv *= fma(Q.kf[1] * sb, sb, Q.kf[2] * sb);  // G(s) <= c_a s + c_b s^2
-        bool stop = true;
+        bool stopb = true;
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
-            if (!(Bv <= kConvTermTol * fmax(fabs(out[e]), kConvFloor * scaleS[e]))) stop = false;
+            if (!(Bv <= kConvTermTol * fmax(fabs(out[e]), kConvFloor * scaleS[e]))) stopb = false;
             Bv *= sb;
         }
-        const bool go = need && cur > tlo && !stop;
-        const double lim = cur - gap;
+        // PHASE 1: an edge on the upper end of the hole jumps to its lower end
+        const double curj = (PHASE == 1 && cur <= hhi && cur > hlo) ? hlo : cur;
+        const bool go = need && curj > stop && !stopb;
+        if (PHASE == 1) mid_flag = hlo < hhi && !(stopb && cur >= hhi);
+        const double lim = curj - gap;
         int io2 = io;
         double ownp = io2 > 0 ? fma(h0, double(io2), tlo) : tlo;
         while (need && io2 > 0 && ownp >= lim) {
             --io2;
             ownp = io2 > 0 ? fma(h0, double(io2), tlo) : tlo;
         }
-        double nxt = fmax(tlo, ownp);
+        double nxt = fmax(stop, ownp);
         nxt = fmax(nxt, mk.prev(lim, need));
-        nxt = nxt < tlo + gap ? tlo : nxt;
+        if (PHASE == 1) nxt = hhi < curj ? fmax(nxt, hhi) : nxt;   // (a forced edge, whatever the gap rule says)
+        nxt = nxt < stop + gap ? stop : nxt;
         io = io2;
-        a0 = go ? nxt : a0;
-        h = go ? cur - nxt : h;
+        // (need && !go: the rule is over -- the caller sees it when it looks at the return value; the two call sites that take
+        // a rule's FIRST panel do not, and the lane then runs one trip on a panel of width zero, which adds nothing, and is
+        // told again.  Without the zero width that trip evaluated the previous rule's last panel with the new rule's
+        // parameters: harmless while a rule could not end before its first panel -- a hole of phase 2 can, on the bound.)
+        a0 = go ? nxt : need ? curj : a0;
+        h = go ? curj - nxt : need ? 0.0 : h;
         cur = go ? nxt : cur;
-        L = go ? 0 : L;
-        i = go ? 0u : i;
-        if (kLong) sing = go ? nxt == mk.extra[1] : sing;
+        L = need ? 0 : L;
+        i = need ? 0u : i;
+        if (PHASE == 2) sing = need ? (go && nxt == mk.extra[1]) : sing;
         return need && !go;
     };
     next_rule(true);
@@ -1039,10 +1074,6 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
         const double hw = h * hx, c = fma(h, cx, a0);   // half width and centre in t of a plain panel
         double K[3] = {0.0, 0.0, 0.0}, G[3] = {0.0, 0.0, 0.0};
         --budget;
-        // (Long, table: does any lane's panel reach into x_t < s < 2 x_t?  Those two sizes are panel edges -- marks of the
-        // rule -- so a panel lies on one side of each up to the 1e-7 `gap` rule; the test is on the panel, the selection per node)
-        const bool wave_mid = kLong && LTAB &&
-                              __builtin_amdgcn_ballot_w64(sing || (c + hw > mk.extra[1] && c - hw < mk.extra[2])) != 0ull;
         // one node: t, u = e^t, its Kronrod weight and (Gauss nodes) its Gauss weight
         const auto eval_node = [&](double t, double u, double wk, double wg, bool gauss) {
             const double wt = exp_fin(fma(A, t, -u) - lgA);
@@ -1057,24 +1088,11 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
                 up = fma(upw[sl], rho, up);
             }
             double hh = wt * (up * recip_fast(den));
-            if (kLong) {
-                const double xt = Q.kf[0];
-                const bool below = s <= xt, mid = !below && s < 2.0 * xt;
-                double Gs = below ? (Q.kf[1] * gl) * (s * s) : Q.kf[2] * s;   // both particles below x_t / the larger one above
-                if (LTAB) {
-                    // Between x_t and 2 x_t: the table, as straight-line code every lane of the wave runs through (a lane
-                    // outside the range computes on y <= 0 or y > 1/2 and drops the result) -- skipped, by a wave-level vote
-                    // taken once per trip, when no lane's panel reaches into that range.  (Round 4 branched per node and lane:
-                    // 0.46 active lanes, and the branches kept the 15 unrolled nodes from sharing registers.)
-                    if (wave_mid) {
-                        const double Gm = conv_long_G_mid_tab(Q, kj, c0, rB, s, mk.extra[1] - t, gtab, j * kLongNT);
-                        Gs = mid ? Gm : Gs;
-                    }
-                } else if (mid) {
-                    Gs = conv_long_G_mid(Q, kj, lgB, rB, s);
-                }
-                hh *= Gs;
-            }
+            if (PHASE == 1)   // outside [x_t, 2 x_t]: both particles below x_t, or the larger one above
+                hh *= s <= Q.kf[0] ? (Q.kf[1] * gl) * (s * s) : Q.kf[2] * s;
+            if (PHASE == 2)   // inside: this rule's table (rows j * kLongNT + r of the lane's LDS column); ln(x_t / s) = ex1 - t
+                hh *= LTAB ? conv_long_G_mid_tab(Q, kj, c0, rB, s, mk.extra[1] - t, gtab, j * kLongNT)
+                           : conv_long_G_mid(Q, kj, lgB, rB, s);
             const double v0 = hh, v1 = hh * s, v2 = (hh * s) * s;
             K[0] = fma(wk, v0, K[0]);
             K[1] = fma(wk, v1, K[1]);
@@ -1085,11 +1103,11 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
                 G[2] = fma(wg, v2, G[2]);
             }
         };
-        if (kLong) {
+        if (PHASE == 2) {
             // The pairs of Kronrod nodes as a ROLLED loop (their constants come through scalar loads): unrolled, the 15 copies
-            // of the node -- each with the table branch -- left 220 registers in scratch, 221 scratch accesses per trip and
-            // 20 KB of HBM traffic per parcel (VALU busy 0.35; round 5 PMC); rolled: 30 accesses per trip, 66.7 -> 28.7 ms per
-            // 4e6 parcels.  Node positions go through xi; the panel with the singular edge maps t = a0 + h xi^4.
+            // of the node with the table code left 220 registers in scratch, 221 scratch accesses per trip and 20 KB of HBM
+            // traffic per parcel (VALU busy 0.35; round 5 PMC); rolled: 30 accesses per trip.  Node positions go through xi;
+            // the panel with the singular edge maps t = a0 + h xi^4.
             const auto node_at = [&](double xi, double wk, double wg) {
                 const double xi2 = xi * xi;
                 const double tt = sing ? xi2 * xi2 : xi, jac = sing ? 4.0 * (xi2 * xi) : 1.0;
@@ -1122,7 +1140,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
         for (int e = 0; e < 3; ++e)
             if (fabs(K[e] - G[e]) * hw > kTolT * fmax(fabs(fma(K[e], hw, out[e])), kConvFloor * scaleS[e])) ok = false;
         const bool accept = ok || L == kConvLMax || budget <= 0;
-        if (accept) {
+        if (accept && hw > 0.0) {   // (hw = 0: the panel of width zero of a rule that ended before its first panel, see next_panel)
 #pragma unroll
             for (int e = 0; e < 3; ++e) out[e] = fma(K[e], hw, out[e]);
         }
@@ -1142,6 +1160,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
                 Traw[r][0] = st ? out[0] : Traw[r][0];
                 Traw[r][1] = st ? out[1] : Traw[r][1];
                 Traw[r][2] = st ? out[2] : Traw[r][2];
+                if (PHASE == 1) midneed[r] = st ? mid_flag : midneed[r];
             }
             next_rule(done);
             (void)next_panel(done && busy);
@@ -1303,13 +1322,23 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
 #endif
             constexpr bool kTabFits = KIND == KF_LONG && N <= 3;
             __shared__ double sh_gtab[kTabFits ? (N > 1 ? N - 1 : 1) * kLongNT : 1][kBlock];
-            if (kTabFits && A.kmax <= kLongTabKmax) {   // (wave-uniform; a compile-time fact in a kernel compiled for the plan)
+            bool midneed[NM];
 #pragma unroll
-                for (int j = 0; j < N - 1; ++j)
-                    if (!lnj_[j] && kTabFits) conv_long_tab_build(kj_[j], sh_gtab, kTabFits ? j * kLongNT : 0);
-                conv_T_merged<N, KIND, kTabFits>(Q, lg, rb, Traw, sh_gtab);
+            for (int j = 0; j < NM; ++j) midneed[j] = false;
+            if (KIND != KF_LONG) {
+                conv_T_merged<N, KIND, false, (KIND == KF_LONG ? 1 : 0)>(Q, lg, rb, Traw, midneed, sh_gtab);
             } else {
-                conv_T_merged<N, KIND, false>(Q, lg, rb, Traw, sh_gtab);
+                // (the choice is wave-uniform, and a compile-time fact in a kernel compiled for the plan)
+                const bool tab = kTabFits && A.kmax <= kLongTabKmax;
+                conv_T_merged<N, KIND, false, (KIND == KF_LONG ? 1 : 0)>(Q, lg, rb, Traw, midneed, sh_gtab);
+                if (tab) {
+#pragma unroll
+                    for (int j = 0; j < N - 1; ++j)
+                        if (!lnj_[j] && kTabFits) conv_long_tab_build(kj_[j], sh_gtab, kTabFits ? j * kLongNT : 0);
+                    conv_T_merged<N, KIND, kTabFits, (KIND == KF_LONG ? 2 : 0)>(Q, lg, rb, Traw, midneed, sh_gtab);
+                } else {
+                    conv_T_merged<N, KIND, false, (KIND == KF_LONG ? 2 : 0)>(Q, lg, rb, Traw, midneed, sh_gtab);
+                }
             }
 #ifndef CLOUDY_CONV_NO_PARK
 #pragma unroll

@@ -607,7 +607,7 @@ static void co_conv_adaptive(double tlo, double thi, const double *marks, int nm
  * supremum over [t_lo, b] is at an end point; any other mode above j (a Lognormal one, or a smaller scale): sup (1 - w) = 1.
  * bound(b, B[3], ctx) returns the three bounds. */
 #define CO_CONV_TERM_TOL 1e-10
-typedef void (*co_bound_fn)(double b, double *B, void *ctx);
+typedef void (*co_bound_fn)(double b, double stop, double *B, void *ctx);
 /* Round 5 -- an END-POINT SINGULARITY inside the range (the Long kernel: G(s) behaves like (s - x_t)^k just above x_t, k the
  * shape of the mode, so K15 converges only algebraically in the panel whose lower edge is x_t and rounds 3-4 ran the Long
  * rules at a hundredth of the tolerance, 43 against 30 panel evaluations per parcel): the initial panel [a0, a0 + h] whose
@@ -619,30 +619,41 @@ static double co_conv_long_tol_factor_ = 1.0;   /* (experiments; rounds 3-4: 0.0
 void co_conv_set_long_tol_factor(double f) { co_conv_long_tol_factor_ = f; }
 static int co_conv_sing_p_ = CO_CONV_SING_P;   /* (experiments: 1 switches the substitution off) */
 void co_conv_set_sing_p(int p) { co_conv_sing_p_ = p; }
-static void co_conv_descending(double tlo, double thi, const double *marks, int nmarks, double tol, const double *scaleS,
-                               int budget, co_vec_fn f, co_bound_fn bound, void *ctx, double sing_edge, double *out) {
+/* Round 5, the Long kernel's rules are walked in TWO PHASES (csrc/quad_conv.hpp, conv_T_merged): phase 1 goes from t_hi down
+ * to t_lo and jumps over the "hole" [hlo, hhi] = [x_t, 2 x_t] (clamped to the range; both ends are forced panel edges); phase
+ * 2 walks the hole from hhi down to hlo, the sums of phase 1 carried over (the acceptance test of the hole's panels compares
+ * with everything outside it).  The bound that ends a rule covers [stop, b] -- stop = t_lo in phases 0 / 1, hlo in phase 2 --
+ * so a phase-1 stop ABOVE the hole makes the hole negligible too: the return value says whether phase 2 is needed.
+ * phase 0: the plain walk of the other kernel functions (hlo, hhi unused). */
+static int co_conv_descending(double tlo, double thi, const double *marks, int nmarks, double tol, const double *scaleS,
+                              int budget, co_vec_fn f, co_bound_fn bound, void *ctx, double sing_edge, int phase, double hlo,
+                              double hhi, double *out) {
     double vals[3], K[3], G[3], B[3];
     const double h0 = (thi - tlo) / CO_CONV_NINIT, gap = 1e-7 * (thi - tlo);
-    double cur = thi;
-    int io = CO_CONV_NINIT - 1;
-    while (cur > tlo) {
-        bound(cur, B, ctx);
-        int stop = 1;
+    const double stop = phase == 2 ? hlo : tlo;
+    double cur = phase == 2 ? hhi : thi;
+    int io = CO_CONV_NINIT - 1, midneed = phase == 1 && hlo < hhi;
+    for (;;) {
+        bound(cur, stop, B, ctx);
+        int stopb = 1;
         for (int o = 0; o < 3; ++o)
-            if (!(B[o] <= CO_CONV_TERM_TOL * fmax(fabs(out[o]), CO_CONV_FLOOR * scaleS[o]))) stop = 0;
-        if (stop) break;
-        const double lim = cur - gap;
+            if (!(B[o] <= CO_CONV_TERM_TOL * fmax(fabs(out[o]), CO_CONV_FLOOR * scaleS[o]))) stopb = 0;
+        if (stopb && phase == 1 && cur >= hhi) midneed = 0;
+        const double curj = (phase == 1 && cur <= hhi && cur > hlo) ? hlo : cur; /* an edge on the hole's upper end jumps */
+        if (stopb || !(curj > stop)) break;
+        const double lim = curj - gap;
         double own = io > 0 ? tlo + h0 * io : tlo;
         while (io > 0 && own >= lim) {
             --io;
             own = io > 0 ? tlo + h0 * io : tlo;
         }
-        double nxt = fmax(tlo, own);
+        double nxt = fmax(stop, own);
         for (int m = 0; m < nmarks; ++m)
             if (marks[m] < lim && marks[m] > nxt) nxt = marks[m];
-        if (nxt < tlo + gap) nxt = tlo;
-        const double a0 = nxt, h = cur - nxt;
-        const int sing = co_conv_sing_p_ > 1 && a0 == sing_edge;
+        if (phase == 1 && hhi < curj) nxt = fmax(nxt, hhi); /* a forced edge, whatever the gap rule says */
+        if (nxt < stop + gap) nxt = stop;
+        const double a0 = nxt, h = curj - nxt;
+        const int sing = phase == 2 && co_conv_sing_p_ > 1 && a0 == sing_edge;
         cur = nxt;
         int L = 0;
         unsigned i = 0;
@@ -685,6 +696,7 @@ static void co_conv_descending(double tlo, double thi, const double *marks, int 
             }
         }
     }
+    return midneed;
 }
 /* t of a size s in the variable of a rule with scale theta */
 static double co_conv_t_of_s(double s, double theta) { return log(s / theta); }
@@ -890,7 +902,7 @@ static void co_T_node(double t, double *vals, void *v) {
     vals[2] = h * s * s;
 }
 /* the bound of what is left below b for the rule of co_T_ctx (see co_conv_descending) */
-static void co_T_bound(double b, double *B, void *v) {
+static void co_T_bound(double b, double stop, double *B, void *v) {
     const co_T_ctx *c = (const co_T_ctx *)v;
     const co_dist *dj = &c->pdists[c->j];
     const double ub = exp(b), sb = ub * c->theta, lsb = b + c->lth;
@@ -908,7 +920,7 @@ static void co_T_bound(double b, double *B, void *v) {
         lmax = fmax(lmax, fmax(co_ln_normed(dm, sb, lsb) - own_b, co_ln_normed(dm, slo, lslo) - own_lo));
     }
     if (convex && n_up > 0) lsig = fmin(0.0, lmax + log((double)n_up));
-    double Bv = exp(lw + lsig) * (b - c->tlo);
+    double Bv = exp(lw + lsig) * (b - stop);
     if (c->kf->kind == CO_KF_LONG) Bv *= c->kf->p[2] * sb + c->kf->p[1] * sb * sb; /* G(s) <= c_a s + c_b s^2 */
     B[0] = Bv;
     B[1] = Bv * sb;
@@ -1082,9 +1094,13 @@ int co_get_coal_ints_numerical_converged(const co_dist *pdists, int N, const co_
                  * tau^(k-1) there -- and K15 converges slowly in the panels next to them: measured 1e-9 of scale at tol =
                  * 1e-8 on random mixtures, against 1e-10 ... 1e-13 for the homogeneous kernels; its rules run at tol / 10) */
                 const double tol_T = lng ? co_conv_long_tol_factor_ * tol : tol;
-                if (co_conv_walk_down_)
-                    co_conv_descending(tlo, thi, marks, nm, tol_T, tolS, CO_CONV_BUDGET, co_T_node, co_T_bound, &c,
-                                       lng ? marks[nm - 2] : NAN, T);
+                if (co_conv_walk_down_ && lng) {
+                    const double ex1 = marks[nm - 2], ex2 = marks[nm - 1];
+                    const double hlo = fmin(fmax(ex1, tlo), thi), hhi = fmin(fmax(ex2, tlo), thi);
+                    if (co_conv_descending(tlo, thi, marks, nm, tol_T, tolS, CO_CONV_BUDGET, co_T_node, co_T_bound, &c, ex1, 1, hlo, hhi, T))
+                        co_conv_descending(tlo, thi, marks, nm, tol_T, tolS, CO_CONV_BUDGET, co_T_node, co_T_bound, &c, ex1, 2, hlo, hhi, T);
+                } else if (co_conv_walk_down_)
+                    co_conv_descending(tlo, thi, marks, nm, tol_T, tolS, CO_CONV_BUDGET, co_T_node, co_T_bound, &c, NAN, 0, 0.0, 0.0, T);
                 else
                     co_conv_adaptive(tlo, thi, marks, nm, 3, NULL, 0, tol_T, tolS, CO_CONV_BUDGET, co_T_node, &c, T);
                 if (!lng) { /* the mass below t_lo (1e-13 of the weight; a sizeable part of it for a shape clamped to eps) */
