@@ -815,6 +815,99 @@ __device__ __forceinline__ void conv_T_lognormal(const QArgs &Q, const double *_
     T2 = T[2] * pref;
 }
 
+// ---- T_m of a LOGNORMAL mode under a POLYNOMIAL kernel (constant, linear): the inner integral by a trapezoidal rule (round 5) ----
+// the reference's own n_particles_lognorm.jl (two Lognormal modes, sigma = ln 2, linear kernel) ran at
+// 2.3e5 ... 4e5 parcel-RHS/s -- 21 M VALU instructions per parcel at 0.28 active lanes (round 5 PMC): >= 96 Gauss-Legendre
+// points per outer node, each with a log1p, two exponentials and the generic kernel, and up to 2048 of them for a shape clamped
+// to sigma = eps, whose lane the other 63 of its wave waited for.  For K = c s^gamma (gamma = 0, 1) the kernel leaves the inner
+// integral, which is then the density of S = X + Y in ln s,
+//     G2(ln s) = 2 c s^gamma int_0^inf g(ln x) g(ln y) dt = c s^gamma / (pi sigma^2) int_0^inf exp(-[(m - q(t))^2 + t^2 / 4] / sigma^2) dt,
+//     m = ln s - mu,   q(t) = ln(2 cosh(t / 2))   (ln x - mu = m + t/2 - q, ln y - mu = m - t/2 - q),
+// an EVEN, analytic integrand (poles of q at t = +- i pi) that decays like a Gaussian: the trapezoidal rule converges
+// geometrically.  Step h = min(sigma, 1/2): <= 2e-13 of the density's peak against 30-digit mpmath for sigma from 0.002 to 2
+// (1.2 sigma: 3e-12; 1.4 sigma: 4e-9).  Range: the integrand is below e^-42 of its maximum beyond
+// T = min(max(m, 0) + 12 sigma, 2 sqrt((m - ln 2)^2 + 42 sigma^2)) (E(t) >= t^2 / (4 sigma^2), E_min <= E(0)); and the whole
+// density is below e^-42 of its peak where min(d^2, 2 d - 1) > 42 sigma^2, d = m - ln 2 (q <= ln 2 + t^2 / 8): zero there --
+// which also bounds the number of points by ~20 for every sigma <= 1/2, clamped shapes included.  q(i h) does not depend on s:
+// the first kLnQTab values wait in the lane's own LDS slots (conflict-free, no barrier), further ones (sigma > 1/2 only) are
+// computed.  Per inner point: one LDS read, one exponential, four FMAs.  The outer rule is the adaptive walk over ln s of
+// conv_T_lognormal (same range, marks and tolerance).
+constexpr int kLnQTab = 24;
+constexpr double kLnCut = 42.0;
+template <int N, int KIND>
+__device__ __forceinline__ void conv_T_lognormal_poly(const QArgs &Q, double n, double mu, double sg, const double (&cm)[N],
+                                                      const double (&wm)[N], const ConvLogDensity (&lg)[N], int j,
+                                                      const double (&totals)[3], double &T0, double &T1, double &T2) {
+    static_assert(KIND == KF_CONSTANT || KIND == KF_LINEAR, "polynomial kernels only");
+    constexpr double gtop = KIND == KF_LINEAR ? 1.0 : 0.0, ln2 = 0.6931471805599453;
+    __shared__ double sh_q[kLnQTab][kBlock];
+    const int lane = threadIdx.x;
+    const double L0 = fma(-8.5, sg, mu), L1 = mu + 8.5 * sg + (gtop + 2.0) * (sg * sg) + ln2;
+    const double c1 = 1.0 / (sg * sg), h = fmin(sg, 0.5), rh = 1.0 / h, pref = 0.5 * (n * n);
+    const double eh = exp_fin(-h);
+    {   // q(i h) - ln 2 = i h / 2 + log1p(e^(-i h)) - ln 2, i = 1 .. kLnQTab
+        double v = 1.0;
+#pragma unroll 1
+        for (int i = 1; i <= kLnQTab; ++i) {
+            v *= eh;
+            sh_q[i - 1][lane] = fma(0.5 * h, double(i), log1p(v) - ln2);
+        }
+    }
+    ConvMarks<(N > 1 ? N - 1 : 1)> mk;
+    mk.shift = 0.0;
+    mk.extra[0] = mk.extra[1] = mk.extra[2] = INFINITY;
+    {
+        int slot = 0;
+#pragma unroll
+        for (int m = 0; m < N; ++m)
+            if (m != j) {
+#pragma unroll
+                for (int sl = 0; sl < N - 1; ++sl)
+                    if (sl == slot) mk.core(sl, cm[m], wm[m], (L1 - L0) * (1.0 / double(kConvNInit)));
+                ++slot;
+            }
+    }
+    const double kc = Q.kf[0] * (0.3183098861837907 * c1);   // c / (pi sigma^2)
+    const auto node = [&](double ls, double (&vals)[3]) {
+        const double m = ls - mu, d = m - ln2;
+        const double lb = (d <= 1.0 ? d * d : fma(2.0, d, -1.0)) * c1;   // a lower bound of the exponent over t
+        double sum = 0.0;
+        if (lb <= kLnCut) {
+            const double Tm = fmin(fmax(m, 0.0) + 12.0 * sg, 2.0 * sqrt(fma(d, d, kLnCut * (sg * sg))));
+            const int npt = (int)ceil(Tm * rh);
+            sum = 0.5 * exp_fin(-(d * d) * c1);   // t = 0
+            const double hq = 0.25 * (h * h);
+            double vv = exp_fin(-h * double(kLnQTab));   // e^(-t) beyond the table
+#pragma unroll 1
+            for (int i = 1; i <= npt; ++i) {
+                double qd;   // q(i h) - ln 2
+                if (i <= kLnQTab) {
+                    qd = sh_q[i - 1][lane];
+                } else {
+                    vv *= eh;
+                    qd = fma(0.5 * h, double(i), log1p(vv) - ln2);
+                }
+                const double dq = d - qd, fi = double(i);
+                sum += exp_fin(-fma(dq, dq, hq * (fi * fi)) * c1);
+            }
+        }
+        const double s = exp_fin(ls);
+        double v = conv_one_minus_w<N>(lg, j, s, ls) * (kc * h * sum);   // (1 - w) x G2 / s^gamma
+        if (KIND == KF_LINEAR) v *= s;
+        vals[0] = v;
+        vals[1] = v * s;
+        vals[2] = (v * s) * s;
+    };
+    const int est_idx[3] = {0, 1, 2};
+    const double rp = 1.0 / pref;
+    const double scaleS[3] = {totals[0] * rp, totals[1] * rp, totals[2] * rp};
+    double T[3] = {0.0, 0.0, 0.0};
+    conv_adaptive<3, 3, false>(L0, L1, mk, est_idx, scaleS, kConvBudgetLn, node, node, T);
+    T0 = T[0] * pref;
+    T1 = T[1] * pref;
+    T2 = T[2] * pref;
+}
+
 // ---- ONE walk over all the Gamma-weight rules of a parcel (round 4) ----
 // A wave runs a rule for as long as its lane with the most panel evaluations; run rule by rule, a wave of the cfg4q batch
 // keeps 0.69 of its lanes busy (tools/conv_lab: 48 evaluations per parcel on average, 69 for the slowest lanes of a wave).
@@ -1356,7 +1449,11 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
             double T0 = 0.0, T1 = 0.0, T2 = 0.0;
             if (lnj_[j]) {  // wave-uniform
                 const double totals[3] = {0.5 * pr[0], pr[1], pr[2] + pr[3]};
-                conv_T_lognormal<N, KIND>(Q, tab, nj_[j], thj_[j], kj_[j], cm, wm, lg, j, totals, T0, T1, T2);
+                if (KIND == KF_CONSTANT || KIND == KF_LINEAR)
+                    conv_T_lognormal_poly<N, (KIND == KF_LINEAR ? KF_LINEAR : KF_CONSTANT)>(Q, nj_[j], thj_[j], kj_[j], cm, wm, lg, j,
+                                                                                          totals, T0, T1, T2);
+                else
+                    conv_T_lognormal<N, KIND>(Q, tab, nj_[j], thj_[j], kj_[j], cm, wm, lg, j, totals, T0, T1, T2);
             } else {
                 double T[3] = {Traw[j][0], Traw[j][1], Traw[j][2]};
                 if (KIND != KF_LONG) {
