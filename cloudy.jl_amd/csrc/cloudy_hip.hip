@@ -35,7 +35,10 @@ struct cloudy_plan {
     mutable std::once_flag int_once, rs_once, rsint_once, tsit5_once, rsint512_once, rsint1024_once;
     mutable hipFunction_t int_ssprk33 = nullptr, rs_coal = nullptr, rs_int = nullptr, int_tsit5 = nullptr;
     mutable hipFunction_t rs_int512 = nullptr, rs_int1024 = nullptr;  // the column integrator for 256 < nz <= 512 / 1024
-    mutable std::string int_log;
+    // one log per once-flag (a single string written from seven independent call_once lambdas raced when two host
+    // threads made first calls to different entry points of one plan, and a later successful compile overwrote the log an
+    // earlier failure's message refers to); each is written once, inside its call_once, and read only after it
+    mutable std::string int_log, rs_log, rsint_log, rsint512_log, rsint1024_log, tsit5_log, diag_log;
     // plans beyond the ahead-of-time families: diagnostics and parameter-plane entry points compiled on first use (jit.hpp part 7)
     mutable std::once_flag diag_once;
     mutable JitDiag diag;
@@ -255,28 +258,29 @@ int run(const cloudy_plan *plan, const LaunchReq &r) {
     bool use_jit = plan->jit_on && r.input_kind == IN_MOMENTS && r.physical_out &&
                    (r.op == OP_COAL || (r.op == OP_SSPRK33 && !r.rainshaft) || r.op == OP_RAINSHAFT_SSPRK33 || r.op == OP_TSIT5);
     if (use_jit && r.op == OP_TSIT5) {
-        std::call_once(plan->tsit5_once, [&] { (void)jit_get_tsit5(plan->h, plan->int_tsit5, plan->int_log); });
+        std::call_once(plan->tsit5_once, [&] { (void)jit_get_tsit5(plan->h, plan->int_tsit5, plan->tsit5_log); });
         use_jit = plan->int_tsit5 != nullptr;  // otherwise the ahead-of-time integrator (tensor plans)
     }
     if (!use_jit && r.op == OP_TSIT5 && plan->h.coal_style == CLOUDY_NUMERICAL_COAL)
         return fail(CLOUDY_EUNSUPPORTED, "cloudy_tsit5_steps of a NumericalCoalStyle plan runs the kernel compiled for the plan "
-                                         "(hiprtc); plan-time compilation is off or failed: %s", plan->int_log.c_str());
+                                         "(hiprtc); plan-time compilation is off or failed: %s", plan->tsit5_log.c_str());
     if (use_jit && r.op == OP_RAINSHAFT_SSPRK33) {
         const int part = jit_rainshaft_part(r.nz);
         if (part == 3)
-            std::call_once(plan->rsint_once, [&] { (void)jit_get_rainshaft_integrator(plan->h, plan->rs_int, plan->int_log); });
+            std::call_once(plan->rsint_once, [&] { (void)jit_get_rainshaft_integrator(plan->h, plan->rs_int, plan->rsint_log); });
         else if (part == 5)
-            std::call_once(plan->rsint512_once, [&] { (void)jit_get_rainshaft_integrator(plan->h, plan->rs_int512, plan->int_log, 5); });
+            std::call_once(plan->rsint512_once, [&] { (void)jit_get_rainshaft_integrator(plan->h, plan->rs_int512, plan->rsint512_log, 5); });
         else
-            std::call_once(plan->rsint1024_once, [&] { (void)jit_get_rainshaft_integrator(plan->h, plan->rs_int1024, plan->int_log, 6); });
+            std::call_once(plan->rsint1024_once, [&] { (void)jit_get_rainshaft_integrator(plan->h, plan->rs_int1024, plan->rsint1024_log, 6); });
         hipFunction_t fn = part == 3 ? plan->rs_int : part == 5 ? plan->rs_int512 : plan->rs_int1024;
         use_jit = fn != nullptr && plan->h.mode != MODE_MOVING;  // otherwise the ahead-of-time integrator (nz <= 256)
     }
     if (!use_jit && r.op == OP_RAINSHAFT_SSPRK33 && r.nz > (size_t)kRainshaftBlock)
         return fail(CLOUDY_EUNSUPPORTED, "columns of %zu cells run the column integrator compiled for the plan (hiprtc, up to 1024 "
-                                         "cells); plan-time compilation is off or failed: %s", r.nz, plan->int_log.c_str());
+                                         "cells); plan-time compilation is off or failed: %s", r.nz,
+                    (r.nz <= 512 ? plan->rsint512_log : plan->rsint1024_log).c_str());
     if (use_jit && r.op == OP_COAL && r.rainshaft) {
-        std::call_once(plan->rs_once, [&] { (void)jit_get_rainshaft(plan->h, plan->rs_coal, plan->int_log); });
+        std::call_once(plan->rs_once, [&] { (void)jit_get_rainshaft(plan->h, plan->rs_coal, plan->rs_log); });
         use_jit = plan->rs_coal != nullptr;
     }
     if (use_jit && r.op == OP_SSPRK33 && (plan->h.mode != MODE_ALLINF || plan->h.coal_style == CLOUDY_NUMERICAL_COAL)) {
@@ -295,7 +299,7 @@ int run(const cloudy_plan *plan, const LaunchReq &r) {
         const bool diag_op = !r.rainshaft && (r.op == OP_UPDATE_DIST || r.op == OP_FINITE_2D || r.op == OP_SEDI || r.op == OP_COND ||
                                               r.op == OP_NQ || (r.op == OP_COAL && r.input_kind == IN_PARAMS));
         if (diag_op && plan->jit_on) {
-            std::call_once(plan->diag_once, [&] { (void)jit_get_diag(plan->h, plan->diag, plan->int_log); });
+            std::call_once(plan->diag_once, [&] { (void)jit_get_diag(plan->h, plan->diag, plan->diag_log); });
             if (plan->diag.ok) {
                 hipError_t e = launch_diag(plan, r);
                 if (e != hipSuccess) return fail_hip(e, "diagnostic kernel launch");
@@ -304,7 +308,7 @@ int run(const cloudy_plan *plan, const LaunchReq &r) {
         }
         return fail(CLOUDY_EUNSUPPORTED, "plans of more than %d modes or order > %d are served by the kernels compiled for the plan "
                                          "(this call has none, or its compilation failed: %s)",
-                    CLOUDY_AOT_MAX_MODES, CLOUDY_AOT_MAX_P - 1, plan->int_log.c_str());
+                    CLOUDY_AOT_MAX_MODES, CLOUDY_AOT_MAX_P - 1, plan->diag_log.c_str());
     }
     hipError_t e = dispatch(plan->h, r);
     if (e != hipSuccess) return fail_hip(e, "kernel launch");
@@ -905,7 +909,7 @@ int cloudy_rainshaft_sources(const cloudy_plan *plan, size_t n, size_t ld, const
     // The cell-body kernel compiled for the plan writes the sedimentation flux as well (one launch, one read of the
     // moments, one closure inversion); the ahead-of-time path is two launches.
     if (plan->jit_on && n > 0) {
-        std::call_once(plan->rs_once, [&] { (void)jit_get_rainshaft(plan->h, plan->rs_coal, plan->int_log); });
+        std::call_once(plan->rs_once, [&] { (void)jit_get_rainshaft(plan->h, plan->rs_coal, plan->rs_log); });
         if (plan->rs_coal != nullptr) {
             r1.out2 = sedi_flux_dev;
             return run(plan, r1);

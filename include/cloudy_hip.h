@@ -17,7 +17,8 @@
  *    rhs_coal!(NumericalCoalStyle(), dm, m, par, ts) with par.kernel_func, box_model_helpers.jl:47-48, and
  *    get_coal_ints(::NumericalCoalStyle, pdists, kernel_func), src/Sources/Coalescence.jl:470-489 -- the reference's
  *    nested adaptive quadgk replaced by a fixed Gauss rule (cloudy_plan_desc.quad_order) or, with quad_mode =
- *    CLOUDY_QUAD_CONVERGED, by closed forms + one 1-D rule per mode that reach quadgk's answer to <= 1e-9 of scale)
+ *    CLOUDY_QUAD_CONVERGED, by closed forms + one 1-D rule per mode that reach quadgk's answer to <= 1e-8 of scale --
+ *    the GUARANTEED bound, asserted on the device against the golden values; measured <= 5.5e-10)
  *   cloudy_update_dist_from_moments <- update_dist_from_moments(pdist, moments)
  *                                    src/ParticleDistributions/ParticleDistributions.jl:456-476, 512-523
  *   cloudy_finite_2d_integrals    <- get_finite_2d_integrals / moment_source_helper
@@ -140,9 +141,18 @@ typedef struct cloudy_plan_desc {
     int32_t dtype;                           /* element type of the mom / dmom / flux planes: CLOUDY_F64, or CLOUDY_F32
                                                 (float planes in HBM = half the traffic; arithmetic stays fp64 in
                                                 registers; (n, theta, k) / F diagnostics planes are always fp64), or
-                                                CLOUDY_F32_FAST (float planes AND single-precision arithmetic in the
-                                                per-node Simpson / incomplete-gamma pass: ~1e-6 relative on the
-                                                thresholded integrals, several times faster on threshold plans), or
+                                                CLOUDY_F32_FAST (float planes AND single-precision arithmetic: in the
+                                                per-node Simpson / incomplete-gamma pass of threshold plans -- ~1e-6
+                                                relative on the thresholded integrals; and, for plans WITHOUT a
+                                                threshold compiled for the plan, in the whole cloudy_coal_rhs kernel
+                                                (packed v_pk_fma_f32, four parcels per lane): <= 1e-2 of scale,
+                                                99.9 % of parcels <= 1e-4, median 1e-8, and parcels whose closure is
+                                                clamped to k = eps may come out Inf / NaN where fp64 arithmetic stays
+                                                finite.  That packed kernel needs ld % 4 == 0 and 16-byte aligned
+                                                planes; any other layout of the same plan -- and cloudy_ssprk33_steps /
+                                                cloudy_tsit5_steps -- run fp64 arithmetic on the float planes (~2e-7):
+                                                the arithmetic of an all-Inf F32_FAST plan depends on the batch layout;
+                                                use CLOUDY_F32 where one answer per parcel matters), or
                                                 CLOUDY_F64_RELAXED (fp64 planes and arithmetic; the power series and the
                                                 continued fraction of the incomplete gamma function of the threshold
                                                 plans stop at 1e-11 instead of 1e-17 / 1e-16: <= 1e-9 of scale against
@@ -162,12 +172,17 @@ typedef struct cloudy_plan_desc {
      * the reference nests adaptive quadgk(rtol = 1e-8).  quad_mode = CLOUDY_QUAD_CONVERGED (THE DEFAULT: the drop-in
      * answers within north_star's 1e-8 of the reference): the integrals split along the kernel function's non-smooth
      * sets -- closed forms for Q and R, one ADAPTIVE Gauss-Kronrod (7, 15) rule per mode for the weighting_fn split
-     * (panels walked from large sizes down, bisected until |K15 - G7| <= 1e-7 of the accumulated value -- 1e-9 for the
-     * Long kernel, whose G(s) is only finitely smooth at x_t and 2 x_t -- and ended by a rigorous bound of what is left:
-     * <= 1.1e-10 of scale against the rule at 1e-13 over a thousand random multi-scale mixtures; quad_order is then only
-     * the points per panel of the inner rule a Lognormal mode's self-collision integral needs, default 8) -- within 1e-9
-     * of scale of the adaptive result.  Lognormal modes: that inner rule takes panels of at most 3 sigma
-     * (up to 256 of them): <= 1.5e-12 of scale down to sigma = 0.003, 1e-9 ... 2e-6 at sigma = 0.001, growing below
+     * (panels walked from large sizes down, bisected until |K15 - G7| <= 1e-7 of the accumulated value -- every kernel
+     * function since round 5: the Long kernel's panel above x_t, where G(s) ~ (s - x_t)^k, is integrated in xi with
+     * s - x_t ~ xi^4, its range [x_t, 2 x_t] in a second phase from a per-rule incomplete-beta table -- and ended by a
+     * rigorous bound of what is left; quad_order is then only the points per panel of the inner rule a Lognormal mode's
+     * self-collision integral needs under the hydrodynamic or Long kernel, default 8).  ERROR: the guaranteed bound is
+     * 1e-8 of scale against nested adaptive quadrature of the reference integrals (asserted on the device on the golden
+     * cases); measured <= 5.5e-10 there, and <= 1.1e-10 against the same rule at 1e-13 over a thousand random multi-scale
+     * mixtures (a statement about the rule's convergence, not about the reference integrals).  Lognormal modes: under the
+     * constant / linear kernels the inner integral is a trapezoidal rule of step min(sigma, 1/2) (<= 2e-13 of the density's
+     * peak, any sigma); under the hydrodynamic / Long kernels it takes Gauss-Legendre panels of at most 3 sigma (up to 256):
+     * <= 1.5e-12 of scale down to sigma = 0.003, 1e-9 ... 2e-6 at sigma = 0.001, growing below
      * (csrc/quad_conv.hpp).  quad_mode = CLOUDY_QUAD_FIXED (explicit opt-in; BASELINE configs[3] "via 10-pt Gauss
      * quadrature"): each integral by one fixed quad_order-point Gauss rule per distribution (generalised Gauss-Laguerre
      * for Gamma / Exponential modes, Gauss-Hermite in ln x for Lognormal modes; tensor product over a pair of modes after

@@ -39,12 +39,12 @@ CASES = [
     # test/examples/Numerical/single_particle_exp.jl, n_particles_exp.jl (LinearKernelFunction, Exponential modes)
     dict(name="1exp_linear", kf=(1, [5e-3]), pdists=[(0, 100.0, 0.1, 1.0)]),
     dict(name="2exp_linear", kf=(1, [5e-3]), pdists=[(0, 100.0, 0.1, 1.0), (0, 1.0, 10.0, 1.0)], mp=True),
-    dict(name="1gamma_long_at_threshold", kf=(3, LONG), pdists=[(1, 30.0, 0.2, 2.0)]),
+    dict(name="1gamma_long_at_threshold", kf=(3, LONG), pdists=[(1, 30.0, 0.2, 2.0)], mp=True),
     dict(name="2exp_hydrodynamic", kf=(2, [E_HYDRO]), pdists=[(0, 80.0, 0.1, 1.0), (0, 2.0, 6.0, 1.0)]),
     dict(name="exp_gamma_hydro_overlapping", kf=(2, [E_HYDRO]), pdists=[(0, 40.0, 1.0, 1.0), (1, 10.0, 1.5, 2.0)]),
     dict(name="2gamma_linear_shapes_far_apart", kf=(1, [5e-3]), pdists=[(1, 60.0, 0.4, 0.6), (1, 4.0, 1.2, 9.0)]),
     dict(name="2gamma_hydro_small_shapes", kf=(2, [E_HYDRO]), pdists=[(1, 90.0, 0.5, 0.75), (1, 5.0, 20.0, 0.9)]),
-    dict(name="exp_2gamma_long", kf=(3, LONG), pdists=[(0, 200.0, 0.04, 1.0), (1, 8.0, 0.3, 2.5), (1, 0.2, 6.0, 4.0)]),
+    dict(name="exp_2gamma_long", kf=(3, LONG), pdists=[(0, 200.0, 0.04, 1.0), (1, 8.0, 0.3, 2.5), (1, 0.2, 6.0, 4.0)], mp=True),
     dict(name="2gamma_constant", kf=(0, [1e-4]), pdists=[(1, 100.0, 0.1, 2.0), (1, 3.0, 3.0, 3.5)]),
     dict(name="3gamma_hydro_overlapping", kf=(2, [E_HYDRO]), pdists=[(1, 50.0, 0.5, 2.0), (1, 20.0, 1.0, 3.0), (1, 5.0, 2.5, 4.0)]),
     dict(name="gamma_exp_long_threshold_in_rain", kf=(3, [4.0, LONG[1], LONG[2]]), pdists=[(1, 50.0, 0.3, 3.0), (0, 2.0, 5.0, 1.0)], mp=True),
@@ -57,9 +57,9 @@ CASES = [
     dict(name="2lognormal_hydrodynamic", kf=(2, [E_HYDRO]), pdists=[(3, 40.0, -1.0, 0.5), (3, 2.0, 1.5, 0.833)], mp=True),
     dict(name="lognormal_gamma_linear", kf=(1, [5e-3]), pdists=[(3, 80.0, -1.5, 0.7), (1, 2.0, 2.0, 3.0)], mp=True),
     dict(name="gamma_lognormal_hydrodynamic", kf=(2, [E_HYDRO]), pdists=[(1, 60.0, 0.2, 2.0), (3, 1.5, 1.2, 0.6)]),
-    dict(name="1lognormal_long", kf=(3, LONG), pdists=[(3, 30.0, -1.0, 0.7)]),
+    dict(name="1lognormal_long", kf=(3, LONG), pdists=[(3, 30.0, -1.0, 0.7)], mp=True),
     dict(name="2lognormal_constant", kf=(0, [1e-4]), pdists=[(3, 100.0, -2.0, 0.833), (3, 3.0, 0.3, 0.833)]),
-    dict(name="gamma_lognormal_long", kf=(3, LONG), pdists=[(1, 100.0, 0.05, 2.0), (3, 1.0, 1.0, 0.5)]),
+    dict(name="gamma_lognormal_long", kf=(3, LONG), pdists=[(1, 100.0, 0.05, 2.0), (3, 1.0, 1.0, 0.5)], mp=True),
     dict(name="gamma_lognormal_gamma_hydro", kf=(2, [E_HYDRO]), pdists=[(1, 100.0, 0.05, 3.0), (3, 5.0, 0.5, 0.5), (1, 0.1, 80.0, 4.0)]),
     # multi-scale mixtures: a narrow or much smaller neighbour puts sharp transitions of weighting_fn inside the bulk of a
     # mode (found by random search: a fixed 48 x 8 composite rule is off by 1e-7 ... 1e-3 of scale on these)
@@ -68,21 +68,27 @@ CASES = [
     dict(name="3gamma_linear_scales_apart", kf=(1, [5e-3]), pdists=[(1, 0.826, 21.94, 3.676), (1, 2.777, 0.469, 1.396), (1, 0.2078, 0.01068, 8.146)], mp=True),
     dict(name="2gamma_constant_small_neighbour", kf=(0, [0.7]), pdists=[(1, 0.946, 0.409, 1.42), (1, 0.1088, 0.01052, 6.567)]),
     dict(name="3gamma_hydro_scales_apart", kf=(2, [0.3]), pdists=[(1, 29.7, 9.82, 0.80), (1, 0.291, 0.01738, 9.92), (1, 0.9275, 0.01466, 0.985)]),
-    dict(name="3gamma_long_scales_apart", kf=(3, [0.3, 9.0, 5.0]), pdists=[(1, 21.26, 0.3454, 4.334), (1, 5.59, 24.65, 0.75), (1, 0.1831, 0.2123, 1.5)]),
+    dict(name="3gamma_long_scales_apart", kf=(3, [0.3, 9.0, 5.0]), pdists=[(1, 21.26, 0.3454, 4.334), (1, 5.59, 24.65, 0.75), (1, 0.1831, 0.2123, 1.5)], mp=True),
     dict(name="2gamma_hydro_small_neighbour", kf=(2, [0.3]), pdists=[(1, 5.0, 2.0, 0.75), (1, 1.0, 0.03, 4.0)], mp=True),
     # a Lognormal mode that is NOT the last one under the Long kernel: its T_m is the 2-D rule with the kernel's jump inside
     dict(name="lognormal_gamma_long", kf=(3, LONG), pdists=[(3, 80.0, -1.5, 0.7), (1, 2.0, 2.0, 3.0)], mp=True),
-    dict(name="gamma_narrow_lognormal_constant", kf=(0, [0.7]), pdists=[(1, 2.02, 0.17, 1.5), (3, 79.6, -1.888, 0.15)]),
+    dict(name="gamma_narrow_lognormal_constant", kf=(0, [0.7]), pdists=[(1, 2.02, 0.17, 1.5), (3, 79.6, -1.888, 0.15)], mp=True),
     # a NARROW Lognormal mode below a Gamma mode that sits at ~2 e^mu: the inner integrand of its T_m (over ln(x / y)) is a
     # Gaussian ~sqrt(2) sigma wide on the boundary t = 0 (round 4, ADVICE r3: 12 equal inner panels were off by 6e-7 at sigma = 0.01)
-    dict(name="narrow_lognormal_gamma_constant", kf=(0, [0.7]), pdists=[(3, 2.0, -1.0, 0.01), (1, 1.0, 0.9, 2.0)]),
-    dict(name="narrow_lognormal_gamma_hydro", kf=(2, [3.14]), pdists=[(3, 2.0, -1.0, 0.005), (1, 1.0, 0.9, 2.0)]),
-    dict(name="narrow_lognormal_gamma_long", kf=(3, [0.5, 2.0, 1.0]), pdists=[(3, 2.0, -1.0, 0.02), (1, 1.0, 0.9, 2.0)]),
+    dict(name="narrow_lognormal_gamma_constant", kf=(0, [0.7]), pdists=[(3, 2.0, -1.0, 0.01), (1, 1.0, 0.9, 2.0)], mp=True),
+    dict(name="narrow_lognormal_gamma_hydro", kf=(2, [3.14]), pdists=[(3, 2.0, -1.0, 0.005), (1, 1.0, 0.9, 2.0)], mp=True),
+    dict(name="narrow_lognormal_gamma_long", kf=(3, [0.5, 2.0, 1.0]), pdists=[(3, 2.0, -1.0, 0.02), (1, 1.0, 0.9, 2.0)], mp=True),
     # four modes (box_gamma_mixture_4modes.jl has four; NumericalCoalStyle plans take up to four), and two identical modes
     dict(name="4gamma_hydrodynamic", kf=(2, [3.14e-3]), pdists=[(1, 100.0, 0.02, 2.0), (1, 10.0, 0.5, 3.0), (1, 1.0, 8.0, 2.5), (1, 0.05, 100.0, 4.0)]),
     dict(name="exp_gamma_lognormal_gamma_linear", kf=(1, [5e-3]),
          pdists=[(0, 100.0, 0.02, 1.0), (1, 10.0, 0.5, 3.0), (3, 1.0, 2.0, 0.4), (1, 0.05, 100.0, 4.0)]),
-    dict(name="4gamma_long", kf=(3, [0.5, 2.0, 1.0]), pdists=[(1, 100.0, 0.02, 2.0), (1, 10.0, 0.3, 3.0), (1, 1.0, 2.0, 2.5), (1, 0.05, 30.0, 4.0)]),
+    dict(name="4gamma_long", kf=(3, [0.5, 2.0, 1.0]), pdists=[(1, 100.0, 0.02, 2.0), (1, 10.0, 0.3, 3.0), (1, 1.0, 2.0, 2.5), (1, 0.05, 30.0, 4.0)], mp=True),
+    # round 5: the exact configuration of test/examples/Numerical/n_particles_lognorm.jl:17-38 (two Lognormal
+    # modes, n = 1e7 / 1e5 per m^3, mass scales 1e-10 / 1e-9 kg, sigma = ln 2, LinearKernelFunction(5.0), norms (1e6, 1e-9)) -- the
+    # bench variant numerical_lognorm_example -- and a three-mode Gamma mixture of the bench batch's kind under the Long kernel
+    # (the bench variant cfg4q_converged_long)
+    dict(name="n_particles_lognorm_example", kf=(1, [5e-3]), pdists=[(3, 10.0, math.log(0.1), LN2), (3, 0.1, 0.0, LN2)], mp=True),
+    dict(name="3gamma_long_bench_like", kf=(3, LONG), pdists=[(1, 30.0, 0.04, 3.0), (1, 0.5, 2.0, 2.5), (1, 0.01, 40.0, 4.0)], mp=True),
     dict(name="2gamma_identical_hydrodynamic", kf=(2, [3.14e-3]), pdists=[(1, 10.0, 1.0, 2.0), (1, 10.0, 1.0, 2.0)]),
 ]
 

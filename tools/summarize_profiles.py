@@ -72,6 +72,8 @@ VARIANTS = {   # bench variant -> (kernel name prefix, items per launch in the b
     "cfg3a_fused_ssprk33": ("cloudy_jit_ssprk33_n2p3_f64", 10_000_000),
     "rainshaft_ssprk33_columns": (("cloudy_jit_rainshaft_ssprk33_n2p3_f64", "rainshaft_ssprk33_kernel<2, 3, 1, double>"), 10_000_000),
     "cfg4q_converged": ("cloudy_jit_quad_n3c8_hydro_f64", 12_500_000),
+    "cfg4q_converged_long": ("cloudy_jit_quad_n3c8_long_f64", 12_500_000),
+    "numerical_lognorm_example": ("cloudy_jit_quad_n2c8_linear_f64", 2_000_000),
     "cfg0_tsit5": ("cloudy_jit_tsit5_n1p2_f64", 10_000_000),
     "cfg3b_f32_fast": ("cloudy_jit_sorted_n2p3_f32fast", 10_000_000),
     "cfg5_f32_planes": ("cloudy_jit_sorted_rs_n2p3_f32", 12_500_000),
@@ -129,7 +131,9 @@ def kernel_table(tag):
             util = p["SQ_THREAD_CYCLES_VALU"] / (p["SQ_ACTIVE_INST_VALU"] * 64.0)
             flops = (2 * p["SQ_INSTS_VALU_FMA_F64"] + p["SQ_INSTS_VALU_MUL_F64"] + p["SQ_INSTS_VALU_ADD_F64"]) * 64.0 * util
             issue = p["SQ_INSTS_VALU"] * 4.0 / (1024 * 2.4e9 * avg * 1e-6)
-            cells += [str(p["grid_size"]), f"{p['SQ_INSTS_VALU'] * 64.0 / p['grid_size']:.0f}", f"{util:.2f}", f"{issue:.2f}",
+            # (the 4-cycle issue model holds for the fp64 kernels only: single-precision kernels measure > 1 with it)
+            issue_s = "n/a (fp32)" if short.endswith(("_f32fast", "_f32")) or issue > 1.0 else f"{issue:.2f}"
+            cells += [str(p["grid_size"]), f"{p['SQ_INSTS_VALU'] * 64.0 / p['grid_size']:.0f}", f"{util:.2f}", issue_s,
                       f"{flops / (avg * 1e-6) / 78.6e12:.2f}"]
         else:
             cells += [str(p["grid_size"]) if p else "", "", "", "", ""]
