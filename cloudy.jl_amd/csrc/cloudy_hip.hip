@@ -14,6 +14,7 @@
 
 #include <map>
 #include <mutex>
+#include <mutex>
 #include <string>
 #include <utility>
 
@@ -42,7 +43,43 @@ struct cloudy_plan {
     // plans beyond the ahead-of-time families: diagnostics and parameter-plane entry points compiled on first use (jit.hpp part 7)
     mutable std::once_flag diag_once;
     mutable JitDiag diag;
+    // NumericalCoalStyle plans in converged mode: one byte per parcel, the cost hints of coal_rhs_quad_body (quad_kernels.hpp).
+    // Allocated on the first cloudy_coal_rhs call, grown when a larger batch arrives (never per call otherwise); CLOUDY_HIP_CONV_HINTS=0
+    // turns the mechanism off.  Kernels of concurrent calls may race on the bytes: a hint only orders lanes.
+    mutable unsigned char *hint_dev = nullptr;
+    mutable size_t hint_cap = 0;
+    mutable std::mutex hint_mu;
 };
+
+namespace {
+// the plan's hint bytes for a batch of n parcels (nullptr: off, or the allocation failed -- the kernel then keeps the natural order)
+unsigned char *conv_hints(const cloudy_plan *plan, size_t n, hipStream_t stream) {
+    static const bool on = [] {
+        const char *e = std::getenv("CLOUDY_HIP_CONV_HINTS");
+        return !(e && e[0] == '0');
+    }();
+    if (!on || n == 0) return nullptr;
+    std::lock_guard<std::mutex> lock(plan->hint_mu);
+    if (plan->hint_cap < n) {
+        unsigned char *p = nullptr;
+        if (hipMalloc((void **)&p, n) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        if (hipMemsetAsync(p, 0, n, stream) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(p);
+            return nullptr;
+        }
+        if (plan->hint_dev) {   // kernels of earlier calls may still read the old bytes: hipFree waits for the device
+            (void)hipFree(plan->hint_dev);
+        }
+        plan->hint_dev = p;
+        plan->hint_cap = n;
+    }
+    return plan->hint_dev;
+}
+}  // namespace
 
 namespace {
 
@@ -154,7 +191,8 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
             return hipModuleLaunchKernel(plan->int_ssprk33, (unsigned)((n + qb - 1) / qb), 1, 1, qb, 1, 1, 0, r.stream, args,
                                          nullptr);
         }
-        void *args[] = {&n, &ld, &in, &out};
+        unsigned char *hint = h.q.mode == QUAD_CONVERGED ? conv_hints(plan, n, r.stream) : nullptr;
+        void *args[] = {&n, &ld, &in, &out, &hint};
         return hipModuleLaunchKernel(plan->jit.quad, (unsigned)((n + qb - 1) / qb), 1, 1, qb, 1, 1, 0, r.stream, args,
                                      nullptr);
     }
@@ -718,6 +756,7 @@ void cloudy_plan_destroy(cloudy_plan *plan) {
     if (plan->h.partial_dev) (void)hipFree(plan->h.partial_dev);
     if (plan->h.kargs_dev) (void)hipFree(plan->h.kargs_dev);
     if (plan->h.qtab_dev) (void)hipFree(plan->h.qtab_dev);
+    if (plan->hint_dev) (void)hipFree(plan->hint_dev);
     delete plan;
 }
 

@@ -948,7 +948,7 @@ template <int N, int KIND, bool LTAB, int PHASE, int NROW>
 __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensity (&lg)[N],
                                               const ConvRule<(N > 1 ? N - 1 : 1)> (&rb)[(N > 1 ? N - 1 : 1)],
                                               double (&Traw)[(N > 1 ? N - 1 : 1)][3], bool (&midneed)[(N > 1 ? N - 1 : 1)],
-                                              const double (&gtab)[NROW][kBlock]) {
+                                              const double (&gtab)[NROW][kBlock], int &cost) {
     constexpr int NM = N > 1 ? N - 1 : 1, NR = NM;
     static_assert((KIND == KF_LONG) == (PHASE != 0), "the Long kernel's rules are walked in two phases, the others in one");
     // The Long kernel's G(s) behaves like (s - x_t)^k just above x_t (the Beta(k, k) law of tau ends like tau^(k-1)), so K15
@@ -1162,6 +1162,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
     (void)next_panel(busy);
 #pragma unroll 1
     while (busy) {
+        ++cost;   // (panel evaluations of this lane: the cost hint of its parcel, coal_rhs_quad_body)
         // the panel in xi (its position inside the initial panel [a0, a0 + h]): centre (i + 1/2) 2^-L, half width 2^-(L+1)
         const double hx = ldexp(0.5, -L), cx = fma(2.0 * hx, double(i), hx);
         const double hw = h * hx, c = fma(h, cx, a0);   // half width and centre in t of a plain panel
@@ -1266,7 +1267,8 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
 template <int N, int KIND>
 __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs &Q, const double *__restrict__ tab,
                                                const double (&nn)[N], const double (&th)[N], const double (&kk)[N],
-                                               double (&acc)[N][3]) {
+                                               double (&acc)[N][3], int &cost) {
+    cost = 0;   // panel evaluations of the parcel's Gamma-weight rules (the only part whose length differs between parcels)
     ConvMode md[N];
     ConvLogDensity lg[N];
 #pragma unroll
@@ -1419,18 +1421,18 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
 #pragma unroll
             for (int j = 0; j < NM; ++j) midneed[j] = false;
             if (KIND != KF_LONG) {
-                conv_T_merged<N, KIND, false, (KIND == KF_LONG ? 1 : 0)>(Q, lg, rb, Traw, midneed, sh_gtab);
+                conv_T_merged<N, KIND, false, (KIND == KF_LONG ? 1 : 0)>(Q, lg, rb, Traw, midneed, sh_gtab, cost);
             } else {
                 // (the choice is wave-uniform, and a compile-time fact in a kernel compiled for the plan)
                 const bool tab = kTabFits && A.kmax <= kLongTabKmax;
-                conv_T_merged<N, KIND, false, (KIND == KF_LONG ? 1 : 0)>(Q, lg, rb, Traw, midneed, sh_gtab);
+                conv_T_merged<N, KIND, false, (KIND == KF_LONG ? 1 : 0)>(Q, lg, rb, Traw, midneed, sh_gtab, cost);
                 if (tab) {
 #pragma unroll
                     for (int j = 0; j < N - 1; ++j)
                         if (!lnj_[j] && kTabFits) conv_long_tab_build(kj_[j], sh_gtab, kTabFits ? j * kLongNT : 0);
-                    conv_T_merged<N, KIND, kTabFits, (KIND == KF_LONG ? 2 : 0)>(Q, lg, rb, Traw, midneed, sh_gtab);
+                    conv_T_merged<N, KIND, kTabFits, (KIND == KF_LONG ? 2 : 0)>(Q, lg, rb, Traw, midneed, sh_gtab, cost);
                 } else {
-                    conv_T_merged<N, KIND, false, (KIND == KF_LONG ? 2 : 0)>(Q, lg, rb, Traw, midneed, sh_gtab);
+                    conv_T_merged<N, KIND, false, (KIND == KF_LONG ? 2 : 0)>(Q, lg, rb, Traw, midneed, sh_gtab, cost);
                 }
             }
 #ifndef CLOUDY_CONV_NO_PARK
@@ -1475,6 +1477,14 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
         }
     }
 #endif
+}
+
+template <int N, int KIND>
+__device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs &Q, const double *__restrict__ tab,
+                                               const double (&nn)[N], const double (&th)[N], const double (&kk)[N],
+                                               double (&acc)[N][3]) {
+    int cost;
+    conv_coal_ints<N, KIND>(A, Q, tab, nn, th, kk, acc, cost);
 }
 
 }  // namespace cloudy

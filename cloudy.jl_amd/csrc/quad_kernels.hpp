@@ -194,17 +194,38 @@ __device__ __forceinline__ void quad_coal_ints(const KArgs<N, 1> &A, const QArgs
 }
 
 // CONV: the converged mode of quad_conv.hpp (closed forms + one 1-D rule per mode; kernel constants included in acc)
+//
+// hint (converged mode, kernels compiled for the plan; may be null): ONE BYTE PER PARCEL of the plan's scratch -- the number of
+// panel evaluations the parcel's adaptive rules took the last time this plan evaluated parcel i (0: never).  The adaptive
+// walk makes a wave run as long as its lane with the most evaluations: 0.79 active lanes on the cfg4q batch (round 4 PMC), and
+// no cheap a-priori predictor of a parcel's cost exists (the number of initial panels correlates 0.51 with it;
+// tools/conv_lab/experiments.py sim_sort).  The cost a parcel HAD is one: an ODE solver calls the operator on the same
+// parcels again and again (three times per SSPRK33 step) and the state moves by a fraction of a per cent between calls.  So
+// the workgroup ranks its 256 parcels by their hints (the counting sort of the threshold kernels) and lane t takes the parcel
+// of rank t -- waves of parcels of EQUAL cost: ranking by the true cost the simulation gives 0.93 lanes for workgroups of
+// 256.  Loads and stores are a permutation inside the workgroup's 2-KB window of each plane.  Which lane computes a parcel
+// changes nothing in its result (parcels are independent; the wave-level votes of the walk only skip code that is a no-op for
+// every lane), so results are bit-identical with and without hints, and a stale or foreign hint costs balance, never accuracy.
 template <int N, int KIND, int NQ, typename TIO, bool CONV = false>
 __device__ __forceinline__ void coal_rhs_quad_body(const KArgs<N, 1> &A, const QArgs &Q, const double *__restrict__ tab,
                                                    size_t n, size_t ld, const TIO *__restrict__ in,
-                                                   TIO *__restrict__ out) {
+                                                   TIO *__restrict__ out, unsigned char *__restrict__ hint = nullptr) {
     constexpr int QB = NQ ? quad_block(NQ) : kBlock;
-    const size_t i = (size_t)blockIdx.x * QB + threadIdx.x;
+    size_t i = (size_t)blockIdx.x * QB + threadIdx.x;
+    if (CONV && hint != nullptr) {   // (a kernel argument: the same for every lane)
+        __shared__ unsigned int sh_cnt[QB];
+        __shared__ unsigned short sh_perm[QB];
+        const bool valid = i < n;
+        const int hb = valid ? (int)hint[i] : 0;
+        regime_rank<QB>(valid, hb > QB - 2 ? QB - 2 : hb, sh_cnt, sh_perm);
+        i = (size_t)blockIdx.x * QB + sh_perm[threadIdx.x];   // (lanes without a parcel rank last)
+    }
     if (i >= n) return;
     double nn[N], th[N], kk[N], acc[N][3];
     load_parcel<N, 1, TIO>(A, i, ld, in, nn, th, kk);
+    int cost = 0;
     if (CONV)
-        conv_coal_ints<N, KIND>(A, Q, tab, nn, th, kk, acc);
+        conv_coal_ints<N, KIND>(A, Q, tab, nn, th, kk, acc, cost);
     else
         quad_coal_ints<N, KIND, NQ>(A, Q, tab, nn, th, kk, acc);
     const double ksc = CONV ? 1.0 : kf_scale<KIND>(Q);
@@ -215,6 +236,7 @@ __device__ __forceinline__ void coal_rhs_quad_body(const KArgs<N, 1> &A, const Q
         st_stream(out + (size_t)(off + 1) * ld + i, acc[k][1] * (ksc * A.out_scale[3 * k + 1]));
         if (A.np[k] == 3) st_stream(out + (size_t)(off + 2) * ld + i, acc[k][2] * (ksc * A.out_scale[3 * k + 2]));
     }
+    if (CONV && hint != nullptr) hint[i] = (unsigned char)(cost > 255 ? 255 : cost);
 }
 
 // solve(ODEProblem(make_box_model_rhs(NumericalCoalStyle()), m, tspan, p), SSPRK33(), dt) -- the Numerical drivers

@@ -626,3 +626,39 @@ def test_converged_mode_fused_ssprk33_and_full_size_properties(gpu_cloudy, oracl
     rhs(dm, dev(cloudy, 2.0 * mom), par, 0.0)
     d2 = dm.to_numpy()
     assert np.max(np.abs(d2 - 4.0 * d) / np.maximum(np.abs(4.0 * d), 1e-300)) < 1e-12
+
+
+@pytest.mark.parametrize("kname", ["hydro", "long"])
+def test_cost_hints_of_the_converged_kernel_change_no_bit(gpu_cloudy, kname):
+    """Round 5: the kernel compiled for a converged-mode plan ranks the parcels of a workgroup by the number of panel evaluations
+    each took in the plan's PREVIOUS call (one byte per parcel of plan-owned scratch; quad_kernels.hpp, coal_rhs_quad_body) so
+    that waves hold parcels of equal cost.  Which lane computes a parcel must not change a bit of its result: the first call of
+    a plan (no hints: natural order), the second (hints of the same batch), a call on OTHER parcels in between (foreign hints),
+    a slice of the batch evaluated alone with its own leading dimension, and a fresh plan all give identical tendencies."""
+    cloudy = gpu_cloudy
+    L = cloudy.lib()
+    n = 70_001          # not a multiple of the workgroup size: the last workgroup ranks lanes without a parcel last
+    kf = {"hydro": cloudy.HydrodynamicKernelFunction(1e2 * np.pi), "long": cloudy.LongKernelFunction(5.236e-10, 9.44e9, 5.78)}[kname]
+    kfn = cloudy.get_normalized_kernel_func(kf, bench.NORMS)
+    mom = bench.synth_moments(3, n, seed=41)
+    other = bench.synth_moments(3, n, seed=42)
+    m, mo, dm = dev(cloudy, mom), dev(cloudy, other), cloudy.DeviceArray.zeros(9, n)
+
+    def rhs(plan, src, count=n, ld=n, out=dm):
+        cloudy._lib.check(L.cloudy_coal_rhs(plan.handle, count, ld, src.ptr, out.ptr, None))
+        cloudy._lib.check(L.cloudy_stream_synchronize(None))
+        return out.to_numpy().copy()
+
+    plan = cloudy.NumericalPlan([1, 1, 1], kfn, bench.NORMS, 8, specialize=1, quad_mode=cloudy.QUAD_CONVERGED)
+    first = rhs(plan, m)
+    second = rhs(plan, m)                    # ranked by the costs of the first call
+    rhs(plan, mo)                            # leaves the hints of OTHER parcels behind
+    third = rhs(plan, m)
+    assert np.array_equal(first, second, equal_nan=True) and np.array_equal(first, third, equal_nan=True)
+    fresh = cloudy.NumericalPlan([1, 1, 1], kfn, bench.NORMS, 8, specialize=1, quad_mode=cloudy.QUAD_CONVERGED)   # (a new plan: no hints yet)
+    assert np.array_equal(first, rhs(fresh, m), equal_nan=True)
+    lo, cnt = 12_345, 30_011
+    ms, ds = dev(cloudy, np.ascontiguousarray(mom[:, lo:lo + cnt])), cloudy.DeviceArray.zeros(9, cnt)
+    alone = rhs(plan, ms, cnt, cnt, ds)      # the hints at these indices belong to other parcels of the batch
+    assert np.array_equal(alone, first[:, lo:lo + cnt], equal_nan=True)
+    assert np.isfinite(first).all(axis=0).mean() > 0.95
