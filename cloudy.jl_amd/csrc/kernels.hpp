@@ -1672,11 +1672,34 @@ __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__rest
             if (!SPEC) asm volatile("" : "+s"(opaque_zero2));
             const KArgs<N, P> &Ac = *(Ag + opaque_zero2);
             double acc[N][3];
+#ifdef CLOUDY_RS_PARK_F
+            // (experiment, round 5) the flux divergence waits in the flux-exchange buffer across the Simpson pass instead of in
+            // registers: every lane has read its neighbour's flux by the barrier below
+            if (MODE != MODE_ALLINF) {
+                CLOUDY_STAGE_BARRIER();
+                if (active) {
+#pragma unroll
+                    for (int m = 0; m < N; ++m)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) sh_flux[3 * m + q][pos] = f[m][q];
+                }
+            }
+#endif
             if (MODE == MODE_ALLINF) {
                 if (active) coal_ints_parcel<N, P, MODE, false, SPEC>(Ac, nodes, nn, th, kk, acc);
             } else {  // every lane of the workgroup: barriers inside
                 coal_ints_ranked<N, P, MODE, SPEC, BS>(Ac, nodes, active, nn, th, kk, acc);
             }
+#ifdef CLOUDY_RS_PARK_F
+            if (MODE != MODE_ALLINF && active) {
+                int pp = threadIdx.x;
+                asm volatile("" : "+v"(pp));
+#pragma unroll
+                for (int m = 0; m < N; ++m)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) f[m][q] = sh_flux[3 * m + q][pp];
+            }
+#endif
             if (active) {
 #pragma unroll
                 for (int m = 0; m < N; ++m)

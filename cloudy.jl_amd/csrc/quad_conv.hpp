@@ -325,9 +325,10 @@ struct ConvMarks {
 // comes from est(t, ve[NEST]), the NEST outputs est_idx[] of the full node, and an accepted panel is evaluated a
 // second time for all outputs.
 template <int NOUT, int NEST, bool TWO_PASS, int NM, class EstFn, class NodeFn>
-__device__ __forceinline__ void conv_adaptive(double tlo, double thi, ConvMarks<NM> &mk, const int (&est_idx)[NEST],
-                                              const double (&scaleS)[NOUT], int budget, EstFn &&est, NodeFn &&node,
-                                              double (&out)[NOUT]) {
+__device__ __forceinline__ int conv_adaptive(double tlo, double thi, ConvMarks<NM> &mk, const int (&est_idx)[NEST],
+                                             const double (&scaleS)[NOUT], int budget, EstFn &&est, NodeFn &&node,
+                                             double (&out)[NOUT]) {
+    const int budget0 = budget;   // (returns the number of panel evaluations spent: the cost hint of a Lognormal mode's rule)
     const double h0 = (thi - tlo) * (1.0 / double(kConvNInit)), gap = 1e-7 * (thi - tlo);
     double cur = tlo, a0 = tlo, h = 0.0;
     int io = 1, L = 0;
@@ -431,6 +432,7 @@ __device__ __forceinline__ void conv_adaptive(double tlo, double thi, ConvMarks<
         L = accept ? L - up : L + 1;
         next_panel(accept && L == 0);
     }
+    return budget0 - budget;
 }
 
 // P(L'_c < G'_a) for a Gamma-family mode G and a Lognormal mode L on the grid a = f + i (f = 0, 1/3; i = 0..3),
@@ -837,7 +839,7 @@ constexpr double kLnCut = 42.0;
 template <int N, int KIND>
 __device__ __forceinline__ void conv_T_lognormal_poly(const QArgs &Q, double n, double mu, double sg, const double (&cm)[N],
                                                       const double (&wm)[N], const ConvLogDensity (&lg)[N], int j,
-                                                      const double (&totals)[3], double &T0, double &T1, double &T2) {
+                                                      const double (&totals)[3], double &T0, double &T1, double &T2, int &cost) {
     static_assert(KIND == KF_CONSTANT || KIND == KF_LINEAR, "polynomial kernels only");
     constexpr double gtop = KIND == KF_LINEAR ? 1.0 : 0.0, ln2 = 0.6931471805599453;
     __shared__ double sh_q[kLnQTab][kBlock];
@@ -902,7 +904,8 @@ __device__ __forceinline__ void conv_T_lognormal_poly(const QArgs &Q, double n, 
     const double rp = 1.0 / pref;
     const double scaleS[3] = {totals[0] * rp, totals[1] * rp, totals[2] * rp};
     double T[3] = {0.0, 0.0, 0.0};
-    conv_adaptive<3, 3, false>(L0, L1, mk, est_idx, scaleS, kConvBudgetLn, node, node, T);
+    // (an evaluation of this rule -- 15 nodes x ~20 inner points -- costs about four of a Gamma-weight rule's: the hint's unit)
+    cost += 4 * conv_adaptive<3, 3, false>(L0, L1, mk, est_idx, scaleS, kConvBudgetLn, node, node, T);
     T0 = T[0] * pref;
     T1 = T[1] * pref;
     T2 = T[2] * pref;
@@ -1453,7 +1456,7 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
                 const double totals[3] = {0.5 * pr[0], pr[1], pr[2] + pr[3]};
                 if (KIND == KF_CONSTANT || KIND == KF_LINEAR)
                     conv_T_lognormal_poly<N, (KIND == KF_LINEAR ? KF_LINEAR : KF_CONSTANT)>(Q, nj_[j], thj_[j], kj_[j], cm, wm, lg, j,
-                                                                                          totals, T0, T1, T2);
+                                                                                          totals, T0, T1, T2, cost);
                 else
                     conv_T_lognormal<N, KIND>(Q, tab, nj_[j], thj_[j], kj_[j], cm, wm, lg, j, totals, T0, T1, T2);
             } else {

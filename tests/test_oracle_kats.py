@@ -404,3 +404,18 @@ def test_get_standard_N_q_with_a_lognormal_mode(oracle):
     for r in (a, b):
         assert r[0] + r[1] == pytest.approx(n_tot, rel=1e-14) and r[2] + r[3] == pytest.approx(m_tot, rel=1e-14)
     assert a[0] > b[0] and a[2] > b[2] and all(np.isfinite(a)) and all(np.isfinite(b))
+
+
+def test_bench_lognorm_example_batch_is_the_reference_configuration(oracle):
+    """bench.lognorm_example_moments: boxes of test/examples/Numerical/n_particles_lognorm.jl:17-24 -- two Lognormal modes,
+    sigma = ln 2 exactly, numbers / mass scales within a factor 2 of (1e7, 1e5) per m^3 and (1e-10, 1e-9) kg -- recovered by
+    update_dist_from_moments (ParticleDistributions.jl:483-505) in normalised units."""
+    import bench
+
+    O = oracle
+    mom = bench.lognorm_example_moments(2000, seed=5)
+    p = O.make_params([O.LOGNORMAL] * 2, np.zeros((1, 1)), (np.inf,) * 2, norms=bench.NORMS)
+    ntk = O.update_dist_batch(p, mom)
+    assert np.allclose(ntk[2], np.log(2.0), rtol=1e-9) and np.allclose(ntk[5], np.log(2.0), rtol=1e-9)
+    assert (ntk[0] >= 5.0 - 1e-9).all() and (ntk[0] <= 20.0 + 1e-9).all() and (ntk[3] >= 0.05 - 1e-12).all() and (ntk[3] <= 0.2 + 1e-12).all()
+    assert (np.abs(ntk[1] - np.log(0.1)) <= np.log(2.0) + 1e-9).all() and (np.abs(ntk[4]) <= np.log(2.0) + 1e-9).all()

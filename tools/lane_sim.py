@@ -174,3 +174,33 @@ for BS in (1024, 2048, 8192):
             cost=act*BASE + ser.any(axis=0)*CS*np.where(ser,gs[lanes],0).max(axis=0) + cfm.any(axis=0)*CC*np.where(cfm,gc[lanes],0).max(axis=0)+sh.any(axis=0)*CSH
             tot_cost+=64*cost.sum(); tot_useful+=own[lanes].sum()
     print("sort group size",BS,"utilisation",tot_useful/tot_cost,"cost/parcel",tot_cost/(n//BS*BS))
+
+# ---- round 5: a per-node algorithm whose cost does not depend on (z, a)? ------------------------------
+# "Fixed length" = every lane runs the same number of terms, so the wave pays no divergence -- but the number must cover the
+# worst node.  The counts below are the kernel's own recurrences stopped at the RELAXED tolerance (1e-10, the opt-in dtype's
+# neighbourhood), per late node of the batch: the series needs ceil(groups) x 4 terms where it is used today (z <= a + 1) and
+# far more beyond (it converges for every z, with ~z + 10 sqrt(z) terms); the continued fraction is the mirror image.
+print("---- fixed-length schemes (round 5)")
+def series_groups_tol(a, z, big):
+    invz = 1 / z; q = a * invz; Nn = np.ones_like(z); g = np.zeros(z.shape, int); done = np.zeros(z.shape, bool)
+    for it in range(400):
+        for u in range(4):
+            q = q + invz; Nn = np.where(done, Nn, Nn * q + 1)
+        g = np.where(done, g, g + 1)
+        done = done | ~(Nn < big)
+        if done.all(): break
+    return g
+with np.errstate(all='ignore'):
+    A2 = np.broadcast_to(a, z.shape)
+    zz = np.where(late & ~short, z, 1.0)
+    gs_all = series_groups_tol(A2, zz, 1e11)            # the series on EVERY late node that is not the P == 1 shortcut
+    gs_own = np.where(series, series_groups_tol(A2, np.where(series, z, 1.0), 1e11), 0)
+m_all = late & ~short
+for name, g in (("series where it is used today (z <= a + 1), tolerance 1e-10", gs_own[late & series]),
+                ("series on every late node (any z), tolerance 1e-10", gs_all[m_all])):
+    print(f"{name}: mean {4 * g.mean():.0f} terms, 99th percentile {4 * np.percentile(g, 99):.0f}, 99.9th {4 * np.percentile(g, 99.9):.0f}, max {4 * g.max()}")
+Lm = L[valid].mean()
+for T in (40, 60, 100):
+    frac_cov = (4 * gs_all[m_all] <= T).mean()
+    print(f"fixed {T}-term series on every late node: {BASE + 3.5 * T:.0f} instructions per node x {Lm:.1f} late nodes = {Lm * (BASE + 3.5 * T):.0f} per parcel "
+          f"at utilisation 1.0 (today {5374} at 0.58; the ideal queue 3108); covers {100 * frac_cov:.1f} % of the late nodes at 1e-10")
