@@ -33,13 +33,14 @@ struct cloudy_plan {
     JitKernels jit;
     std::string jit_log;   // why not, when jit_on is false
     // thresholded plans compile their fused integrator on the first cloudy_ssprk33_steps call
-    mutable std::once_flag int_once, rs_once, rsint_once, tsit5_once, rsint512_once, rsint1024_once;
+    mutable std::once_flag int_once, rs_once, rsint_once, tsit5_once, rsint512_once, rsint1024_once, rsint320_once;
     mutable hipFunction_t int_ssprk33 = nullptr, rs_coal = nullptr, rs_int = nullptr, int_tsit5 = nullptr;
     mutable hipFunction_t rs_int512 = nullptr, rs_int1024 = nullptr;  // the column integrator for 256 < nz <= 512 / 1024
+    mutable hipFunction_t rs_int320 = nullptr;                        // ... with 320-thread workgroups (jit_rainshaft_part)
     // one log per once-flag (a single string written from seven independent call_once lambdas raced when two host
     // threads made first calls to different entry points of one plan, and a later successful compile overwrote the log an
     // earlier failure's message refers to); each is written once, inside its call_once, and read only after it
-    mutable std::string int_log, rs_log, rsint_log, rsint512_log, rsint1024_log, tsit5_log, diag_log;
+    mutable std::string int_log, rs_log, rsint_log, rsint512_log, rsint1024_log, rsint320_log, tsit5_log, diag_log;
     // plans beyond the ahead-of-time families: diagnostics and parameter-plane entry points compiled on first use (jit.hpp part 7)
     mutable std::once_flag diag_once;
     mutable JitDiag diag;
@@ -163,9 +164,10 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
         int nz = (int)r.nz, n_steps = r.n_steps;
         size_t n_columns = r.n / r.nz;
         double dt = r.dt, dz = r.dz;
-        const int part = jit_rainshaft_part(r.nz);
+        int part = jit_rainshaft_part(r.nz);
+        if (part == 8 && plan->rs_int320 == nullptr) part = 3;   // (as run() decided)
         const unsigned bs = (unsigned)jit_rainshaft_block(part);
-        hipFunction_t fn = part == 3 ? plan->rs_int : part == 5 ? plan->rs_int512 : plan->rs_int1024;
+        hipFunction_t fn = part == 3 ? plan->rs_int : part == 5 ? plan->rs_int512 : part == 8 ? plan->rs_int320 : plan->rs_int1024;
         const size_t cpb = bs / r.nz;
         void *args[] = {&nodes, &nz, &n_columns, &ld, &in, &out, &dt, &dz, &n_steps};
         return hipModuleLaunchKernel(fn, (unsigned)((n_columns + cpb - 1) / cpb), 1, 1, bs, 1, 1, 0, r.stream, args, nullptr);
@@ -303,14 +305,19 @@ int run(const cloudy_plan *plan, const LaunchReq &r) {
         return fail(CLOUDY_EUNSUPPORTED, "cloudy_tsit5_steps of a NumericalCoalStyle plan runs the kernel compiled for the plan "
                                          "(hiprtc); plan-time compilation is off or failed: %s", plan->tsit5_log.c_str());
     if (use_jit && r.op == OP_RAINSHAFT_SSPRK33) {
-        const int part = jit_rainshaft_part(r.nz);
-        if (part == 3)
+        int part = jit_rainshaft_part(r.nz);
+        if (part == 8) {   // (falls back to the 256-thread kernel if this one does not compile)
+            std::call_once(plan->rsint320_once, [&] { (void)jit_get_rainshaft_integrator(plan->h, plan->rs_int320, plan->rsint320_log, 8); });
+            if (plan->rs_int320 == nullptr) part = 3;
+        }
+        if (part == 8) {
+        } else if (part == 3)
             std::call_once(plan->rsint_once, [&] { (void)jit_get_rainshaft_integrator(plan->h, plan->rs_int, plan->rsint_log); });
         else if (part == 5)
             std::call_once(plan->rsint512_once, [&] { (void)jit_get_rainshaft_integrator(plan->h, plan->rs_int512, plan->rsint512_log, 5); });
         else
             std::call_once(plan->rsint1024_once, [&] { (void)jit_get_rainshaft_integrator(plan->h, plan->rs_int1024, plan->rsint1024_log, 6); });
-        hipFunction_t fn = part == 3 ? plan->rs_int : part == 5 ? plan->rs_int512 : plan->rs_int1024;
+        hipFunction_t fn = part == 3 ? plan->rs_int : part == 5 ? plan->rs_int512 : part == 8 ? plan->rs_int320 : plan->rs_int1024;
         use_jit = fn != nullptr && plan->h.mode != MODE_MOVING;  // otherwise the ahead-of-time integrator (nz <= 256)
     }
     if (!use_jit && r.op == OP_RAINSHAFT_SSPRK33 && r.nz > (size_t)kRainshaftBlock)
