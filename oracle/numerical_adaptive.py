@@ -128,15 +128,32 @@ def mp_matrices(case):
         return d[2] if d[0] == 0 else d[2] * d[3] if d[0] == 1 else math.exp(d[2] + 0.5 * d[3] ** 2)
 
     def ladder(ds):
-        return sorted({scale(d) * m for d in ds for m in (0.1, 1, 4, 15, 60)})
+        pts = {scale(d) * m for d in ds for m in (0.1, 1, 4, 15, 60)}
+        # round 5: a NARROW Lognormal mode (sigma <= 0.1) puts a spike of relative width sigma at e^mu -- and its self-sum one of
+        # width sigma / sqrt(2) at 2 e^mu, its sum with another mode's bulk one at e^mu + that mode's scale -- into the OUTER
+        # variable; tanh-sinh between the coarse points above reported convergence 1.6e-6 away (narrow_lognormal_gamma_constant,
+        # S matrix, found against the closed forms and the adaptive values, which agree to 3e-15 there): break points around them
+        for d in ds:
+            if d[0] == 3 and d[3] <= 0.1:
+                c = math.exp(d[2])
+                for j in (-8, -4, -2, -1, 0, 1, 2, 4, 8):
+                    pts.add(c * math.exp(j * d[3]))
+                    pts.add(2.0 * c * math.exp(j * d[3] / math.sqrt(2.0)))
+                    for o in ds:
+                        if o is not d:
+                            for m in (0.1, 1, 4):
+                                pts.add(c * math.exp(j * d[3]) + scale(o) * m)
+        return sorted(pts)
 
     def outer(f, ds, extra=()):
         pts = [0] + sorted(set(ladder(ds)) | set(extra)) + [mp.inf]
         return mp.quad(f, pts)
 
     def inner(f, x, ds):
+        narrow = [q for d in ds if d[0] == 3 and d[3] <= 0.1 for j in (-8, -4, -2, -1, 1, 2, 4, 8)
+                  for q in (math.exp(d[2] + j * d[3]), x - math.exp(d[2] + j * d[3]))]
         pts = sorted({p for p in ([0.5 * x] + [q for d in ds for m in (0.1, 1, 6, 40)
-                                                for q in (scale(d) * m, x - scale(d) * m)]
+                                                for q in (scale(d) * m, x - scale(d) * m)] + narrow
                                   + ([prm[0], x - prm[0]] if kind == 3 else [])) if 0 < p < x})
         return mp.quad(f, [0] + pts + [x])
 
