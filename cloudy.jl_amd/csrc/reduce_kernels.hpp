@@ -76,4 +76,34 @@ __global__ void __launch_bounds__(kBlock)
     }
 }
 
+// One SSPRK33 stage update of the staged column stepping (cloudy_rainshaft_ssprk33_steps for columns too tall for the fused
+// kernel): OrdinaryDiffEq's formulas on the CLAMPED stage argument -- the reference's rhs clamps negative moments of its argument
+// in place before it evaluates (rainshaft_helpers.jl:52), and f = rhs(u) was computed on the clamped values.
+//   stage 0: uc = max(u, 0); up = uc; u = uc + dt f         stage 1: u = (3 up + uc + dt f) / 4
+//   stage 2: u = (up + 2 uc + 2 dt f) / 3                   stage 3: u = max(u, 0)  (the FSAL evaluation on the final state)
+template <typename TIO>
+__global__ void __launch_bounds__(kBlock)
+    rainshaft_stage_kernel(int stage, size_t n, size_t ld, int planes, TIO *__restrict__ up, TIO *__restrict__ u,
+                           const TIO *__restrict__ f, double dt) {
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    for (int q = 0; q < planes; ++q) {
+        const size_t e = (size_t)q * ld + i;
+        const double uq = (double)u[e], uc = uq < 0.0 ? 0.0 : uq;
+        if (stage == 3) {
+            u[e] = (TIO)uc;
+            continue;
+        }
+        const double fq = (double)f[e];
+        if (stage == 0) {
+            up[e] = (TIO)uc;
+            u[e] = (TIO)(uc + dt * fq);
+        } else if (stage == 1) {
+            u[e] = (TIO)((3.0 * (double)up[e] + uc + dt * fq) * 0.25);
+        } else {
+            u[e] = (TIO)(((double)up[e] + 2.0 * uc + 2.0 * dt * fq) / 3.0);
+        }
+    }
+}
+
 }  // namespace cloudy

@@ -321,8 +321,9 @@ int cloudy_rainshaft_rhs(const cloudy_plan *plan, size_t nz, size_t n_columns, s
  * evaluation first clamps negative moments of its argument to zero in place (rainshaft_helpers.jl:52), including the
  * FSAL evaluation on each step's result, so the returned state is clamped.  u_out_dev may equal u_in_dev.
  * nz <= 256: several columns per 256-thread workgroup; 256 < nz <= 1024 (round 4): one column per workgroup of 512 or 1024
- * threads, in the kernel compiled for the plan (CLOUDY_EUNSUPPORTED without hiprtc).  CLOUDY_EUNSUPPORTED for nz > 1024:
- * the reference's cell loop is unbounded in nz (rainshaft_helpers.jl:55-78); step such columns with cloudy_rainshaft_rhs. */
+ * threads, in the kernel compiled for the plan (CLOUDY_EUNSUPPORTED without hiprtc).  nz > 1024 (round 5; the reference's cell
+ * loop is unbounded in nz, rainshaft_helpers.jl:55-78): the same steps stage by stage on the stream -- cloudy_rainshaft_rhs and
+ * one update launch per stage, three stream-ordered scratch arrays of the state's size per call -- not fused, any nz. */
 int cloudy_rainshaft_ssprk33_steps(const cloudy_plan *plan, size_t nz, size_t n_columns, size_t ld,
                                    const void *u_in_dev, void *u_out_dev, double dz, double dt, int n_steps,
                                    void *stream);

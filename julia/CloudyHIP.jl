@@ -359,8 +359,9 @@ end
     solve_rainshaft_ssprk33!(u, plan, nz, dz, dt, n_steps; stream = nothing, sync = true)
 
 `solve(ODEProblem(make_rainshaft_rhs(AnalyticalCoalStyle()), m, tspan, p), SSPRK33(), dt = p.dt)` of
-test/examples/Analytical/rainshaft_gamma_mixture.jl:59-60 for `size(u, 1) ÷ nz` independent columns of `nz <= 1024`
-cells stacked along the first axis (the reference's `m[nz, nmom]` layout for one column), final state only.
+test/examples/Analytical/rainshaft_gamma_mixture.jl:59-60 for `size(u, 1) ÷ nz` independent columns of `nz`
+cells (fused in one launch for `nz <= 1024`, stepped stage by stage inside the library above that) stacked along the first axis
+(the reference's `m[nz, nmom]` layout for one column), final state only.
 """
 function solve_rainshaft_ssprk33!(u, plan::Plan, nz, dz, dt, n_steps; stream = nothing, sync::Bool = true)
     n, ld = batch_shape(u, plan.nmom)
