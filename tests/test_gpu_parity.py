@@ -1646,8 +1646,10 @@ def test_error_returns_of_the_column_and_integrator_entry_points(gpu_cloudy):
     assert L.cloudy_rainshaft_ssprk33_steps(with_vel.handle, 20, 2, 39, u.ptr, u.ptr, 150.0, 1.0, 1, None) == E.EINVAL  # ld < n
     assert L.cloudy_rainshaft_ssprk33_steps(with_vel.handle, 20, 2, 40, None, u.ptr, 150.0, 1.0, 1, None) == E.EINVAL
     assert L.cloudy_rainshaft_ssprk33_steps(None, 20, 2, 40, u.ptr, u.ptr, 150.0, 1.0, 1, None) == E.EINVAL
-    # columns taller than the largest workgroup of the fused integrator (1024 cells): refused before any launch
-    assert L.cloudy_rainshaft_ssprk33_steps(with_vel.handle, 1030, 1, 1030, u.ptr, u.ptr, 150.0, 1.0, 1, None) == E.EUNSUPPORTED
+    # columns taller than the largest workgroup of the fused integrator (1024 cells) are stepped stage by stage (round 5)
+    ut = cloudy.DeviceArray.zeros(3, 1030)
+    assert L.cloudy_rainshaft_ssprk33_steps(with_vel.handle, 1030, 1, 1030, ut.ptr, ut.ptr, 150.0, 1.0, 1, None) == 0
+    assert np.array_equal(ut.to_numpy(), np.zeros((3, 1030)))
     # an empty batch is fine
     assert L.cloudy_rainshaft_ssprk33_steps(with_vel.handle, 20, 0, 0, None, None, 150.0, 1.0, 1, None) == 0
     # MovingThreshold plans have no rainshaft driver in the reference
