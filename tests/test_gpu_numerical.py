@@ -662,3 +662,11 @@ def test_cost_hints_of_the_converged_kernel_change_no_bit(gpu_cloudy, kname):
     alone = rhs(plan, ms, cnt, cnt, ds)      # the hints at these indices belong to other parcels of the batch
     assert np.array_equal(alone, first[:, lo:lo + cnt], equal_nan=True)
     assert np.isfinite(first).all(axis=0).mean() > 0.95
+    # a LARGER batch than the plan has seen: the hint bytes are re-allocated (zeroed) on the stream of the call
+    nb = 90_003
+    big = bench.synth_moments(3, nb, seed=43)
+    mb, db = dev(cloudy, big), cloudy.DeviceArray.zeros(9, nb)
+    got_big = rhs(plan, mb, nb, nb, db)
+    fresh2 = cloudy.NumericalPlan([1, 1, 1], kfn, bench.NORMS, 8, specialize=1, quad_mode=cloudy.QUAD_CONVERGED)
+    assert np.array_equal(got_big, rhs(fresh2, mb, nb, nb, db), equal_nan=True)
+    assert np.array_equal(first, rhs(plan, m), equal_nan=True)   # and back to the first batch, under the big batch's hints

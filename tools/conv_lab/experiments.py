@@ -465,6 +465,27 @@ def trap3():
                   f" rel err max {errs.max():.1e} p99.9 {np.percentile(errs,99.9):.1e}; of-scale max {errss.max():.1e}; dmin p1 {np.percentile(dm,1):.3f} p50 {np.median(dm):.3f}")
 
 
+@experiment("xmarks", "round 5: marks graded around the crossings rho_m = 1 (the transitions of weighting_fn) next to / instead of the cores")
+def xmarks():
+    ntk = batch_ntk(6400)
+    ref, _, _ = run(ntk, params(ninit=64, tol=1e-14))
+    base = dict(tol=1e-7, desc=1, tol_skip=-1e-10)
+    for ni in (10, 8, 6):
+        for xm in (0, 1, 2):
+            report(f"desc {ni}/1e-7 xmarks {xm}", ntk, params(ninit=ni, xmarks=xm, **base), ref)
+
+
+@experiment("graded5", "round 5: the a-priori graded layout against the current rule (with cost hints the lane balance no longer decides)")
+def graded5():
+    ntk = batch_ntk(6400)
+    ref, _, _ = run(ntk, params(ninit=64, tol=1e-14))
+    report("current: desc 10/1e-7 term 1e-10", ntk, params(ninit=10, tol=1e-7, desc=1, tol_skip=-1e-10), ref)
+    for cs, ce in ((3.5, 12.0), (2.5, 8.0), (5.0, 12.0)):
+        for tn in (1e-5, 1e-6, 1e-7):
+            for td, sk in ((1, 1e-10), (0, 0.0)):
+                report(f"graded K15 {cs}/{ce} net {tn:g} td{td} skip {sk:g}", ntk, gparams(c_step=cs, c_exp=ce, tol_net=tn, topdown=td, skip_tol=sk), ref)
+
+
 if __name__ == "__main__":
     args = sys.argv[1:]
     if not args or args[0] in ("-l", "--list"):

@@ -109,6 +109,7 @@ typedef struct {
     double tol_skip; /* > 0: skip an initial panel whose rigorous bound is below tol_skip * max(|acc|, floor * scale) */
     int est;         /* 0: |K15 - G7|; 1: QUADPACK qk15's estimate |K - G| min(1, (200 |K - G| / resasc)^1.5) */
     double est_pow, est_fac;
+    int xmarks;      /* round 5: 1 = ALSO graded marks around the points where rho_m = 1 (the transitions of weighting_fn); 2 = those INSTEAD of the core marks where a crossing exists */
 } lab_params;
 
 int lab_T_rule(int N, int j, const int *type, const double *th, const double *k, double gam, const lab_params *P, double *T,
@@ -120,11 +121,44 @@ int lab_T_rule(int N, int j, const int *type, const double *th, const double *k,
     range_of(A, P->range_eps, &tlo, &thi);
     const double scaleS[3] = {1.0, A * r.thj, A * (A + 1.0) * r.thj * r.thj};
     const double h0 = (thi - tlo) / P->ninit, gap = 1e-7 * (thi - tlo);
-    double marks[128];
+    double marks[256];
     int nm = 0;
     if (P->marks)
         for (int m = 0; m < N; ++m) {
             if (m == j) continue;
+            /* crossings lrho_m(t) = 0 in [tlo, thi]: scan + bisection (sandbox: robust, not cheap) */
+            int nx = 0;
+            double xr[4], xw[4];
+            if (P->xmarks) {
+                const int NS = 400;
+                double tp = tlo, fp = lrho(&r, m, tp, exp(tp));
+                for (int i = 1; i <= NS && nx < 4; ++i) {
+                    const double tc = tlo + (thi - tlo) * i / NS, fc = lrho(&r, m, tc, exp(tc));
+                    if ((fp > 0) != (fc > 0)) {
+                        double a = tp, b = tc, fa = fp;
+                        for (int it = 0; it < 60; ++it) {
+                            const double mid = 0.5 * (a + b), fm = lrho(&r, m, mid, exp(mid));
+                            if ((fm > 0) == (fa > 0)) { a = mid; fa = fm; } else b = mid;
+                        }
+                        const double t0 = 0.5 * (a + b), sl = fabs(2.0 * r.q2[m] * t0 + r.q1[m] + r.cb[m] * exp(t0));
+                        xr[nx] = t0;
+                        xw[nx] = sl > 0 ? 1.0 / sl : 1.0;
+                        ++nx;
+                    }
+                    tp = tc; fp = fc;
+                }
+                for (int x = 0; x < nx; ++x) {
+                    const double ratio = h0 / xw[x];
+                    int I = 0;
+                    if (ratio > 1.0) I = ratio < 4096.0 ? (int)ceil(log2(ratio)) : P->imax;
+                    if (I > P->imax) I = P->imax;
+                    for (int q = -(I + 1); q <= I + 1 && nm < 120; ++q) {
+                        const double off = q == 0 ? 0.0 : (q < 0 ? -1.0 : 1.0) * ldexp(xw[x], (q < 0 ? -q : q) - 1);
+                        marks[nm++] = xr[x] + off;
+                    }
+                }
+                if (P->xmarks == 2 && nx > 0) continue;
+            }
             const double c = r.lnmean[m], w = r.cwidth[m];
             const double ratio = h0 / w;
             int I = 0;

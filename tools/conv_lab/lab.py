@@ -14,7 +14,7 @@ from oracle import cloudy_oracle as O  # noqa: E402
 class Params(C.Structure):
     _fields_ = [("ninit", C.c_int), ("tol", C.c_double), ("marks", C.c_int), ("lmax", C.c_int), ("floor_", C.c_double),
                 ("range_eps", C.c_double), ("imax", C.c_int), ("desc", C.c_int), ("tol_skip", C.c_double), ("est", C.c_int),
-                ("est_pow", C.c_double), ("est_fac", C.c_double)]
+                ("est_pow", C.c_double), ("est_fac", C.c_double), ("xmarks", C.c_int)]
 
 
 class GradParams(C.Structure):
@@ -28,7 +28,7 @@ class Stats(C.Structure):
 
 
 def params(**kw):
-    d = dict(ninit=16, tol=1e-9, marks=1, lmax=12, floor_=1e-10, range_eps=float(np.log(1e-13)), imax=12, desc=0, tol_skip=0.0, est=0, est_pow=1.5, est_fac=200.0)
+    d = dict(ninit=16, tol=1e-9, marks=1, lmax=12, floor_=1e-10, range_eps=float(np.log(1e-13)), imax=12, desc=0, tol_skip=0.0, est=0, est_pow=1.5, est_fac=200.0, xmarks=0)
     d.update(kw)
     return Params(**d)
 
