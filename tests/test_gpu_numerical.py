@@ -8,6 +8,7 @@ polynomial kernels where the two closures coincide (one mode).  `scale` = sum of
 oracle reports it.  The discretisation error of the rule against adaptive quadrature is a CPU test
 (tests/test_numerical_oracle.py)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -16,6 +17,7 @@ import bench
 from test_gpu_parity import INF, _ssprk33_host, assert_close_scaled, dev, mixed_moments
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 TOL_SAME_RULE = 1e-11   # north_star allows 1e-8; the two implementations of the rule agree to ~1e-14
 NORMS = bench.NORMS
@@ -670,3 +672,31 @@ def test_cost_hints_of_the_converged_kernel_change_no_bit(gpu_cloudy, kname):
     fresh2 = cloudy.NumericalPlan([1, 1, 1], kfn, bench.NORMS, 8, specialize=1, quad_mode=cloudy.QUAD_CONVERGED)
     assert np.array_equal(got_big, rhs(fresh2, mb, nb, nb, db), equal_nan=True)
     assert np.array_equal(first, rhs(plan, m), equal_nan=True)   # and back to the first batch, under the big batch's hints
+
+
+def test_reference_driver_n_particles_lognorm_end_to_end(gpu_cloudy, oracle):
+    """examples/n_particles_lognorm.py = test/examples/Numerical/n_particles_lognorm.jl line for line through the Python mirror:
+    two Lognormal modes, LinearKernelFunction(5.0), NumericalCoalStyle, SSPRK33 with dt = 1 s to 50 s.  The trajectory is
+    unpinned by the reference (it asserts nothing); here the fused device integrator (converged mode) is compared with the same
+    150 stages driven on the host with the same-rule oracle RHS, and total mass must be conserved."""
+    import importlib.util
+
+    O = oracle
+    spec = importlib.util.spec_from_file_location("n_particles_lognorm", os.path.join(ROOT, "examples", "n_particles_lognorm.py"))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    u0 = ex.dist_moments[:, None].copy()
+    got = ex.solve(u0)[:, 0]
+    op = O.make_params([O.LOGNORMAL] * 2, np.zeros((1, 1)), (INF, INF), norms=ex.norms)
+    okf = O.get_normalized_kernel_func(O.kernel_func(O.KF_LINEAR, ex.coalescence_coeff), ex.norms)
+    f = lambda u: O.rhs_coal_numerical_converged_batch(op, okf, 8, np.ascontiguousarray(u))   # noqa: E731
+    u = u0.copy()
+    for _ in range(int(round(ex.T_end / ex.dt))):   # OrdinaryDiffEq's SSPRK33
+        up = u
+        u = up + ex.dt * f(up)
+        u = (3.0 * up + u + ex.dt * f(u)) / 4.0
+        u = (up + 2.0 * u + 2.0 * ex.dt * f(u)) / 3.0
+    want = u[:, 0]
+    assert np.all(np.isfinite(got)) and np.allclose(got, want, rtol=1e-9, atol=0.0), (got, want)
+    assert abs((got[1] + got[4]) - (u0[1, 0] + u0[4, 0])) <= 1e-12 * (u0[1, 0] + u0[4, 0])      # mass
+    assert got[0] + got[3] < u0[0, 0] + u0[3, 0] and got[3] > u0[3, 0]                             # coalescence: fewer, larger
