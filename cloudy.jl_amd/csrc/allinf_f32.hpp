@@ -174,14 +174,16 @@ __device__ __forceinline__ void coal_ints_pair_f32(const KArgs<N, P> &A, const v
     }
 }
 
-// cloudy_coal_rhs of an all-Inf CLOUDY_F32_FAST plan: four parcels per lane (16-B aligned planes, ld % 4 == 0; the
-// caller falls back to the fp64-arithmetic kernels otherwise)
+// cloudy_coal_rhs of an all-Inf CLOUDY_F32_FAST plan: four parcels per lane.  aligned16 (the same for every lane: 16-B aligned
+// planes and ld % 4 == 0): one 16-B nontemporal access per plane and lane; otherwise four scalar accesses -- the SAME
+// arithmetic either way (round 5, ADVICE r4: until then an unaligned batch or an odd stride took the fp64-arithmetic kernel, so
+// the precision of the plan depended on the layout of the batch -- e.g. on the offset of a shard)
 template <int N, int P, bool SPEC>
 __device__ __forceinline__ void coal_rhs_allinf4_f32_body(const KArgs<N, P> &A, size_t n, size_t ld, const float *__restrict__ in,
-                                                          float *__restrict__ out) {
+                                                          float *__restrict__ out, int aligned16 = 1) {
     const size_t i = ((size_t)blockIdx.x * kBlock + threadIdx.x) * 4;
     if (i >= n) return;
-    const bool full = i + 3 < n;
+    const bool whole = i + 3 < n, full = whole && aligned16 != 0;
     v2f nn[2][N], th[2][N], kk[2][N], acc[2][N][3];
 #pragma unroll
     for (int m = 0; m < N; ++m) {
@@ -199,6 +201,7 @@ __device__ __forceinline__ void coal_rhs_allinf4_f32_body(const KArgs<N, P> &A, 
                 q[o].x = p[0];
                 if (i + 1 < n) q[o].y = p[1];
                 if (i + 2 < n) q[o].z = p[2];
+                if (whole) q[o].w = p[3];
             }
         }
         const float r0 = (float)A.inv_norm[3 * m + 0], r1 = (float)A.inv_norm[3 * m + 1], r2 = (float)A.inv_norm[3 * m + 2];
@@ -227,6 +230,7 @@ __device__ __forceinline__ void coal_rhs_allinf4_f32_body(const KArgs<N, P> &A, 
                 dst[0] = a.x;
                 if (i + 1 < n) dst[1] = a.y;
                 if (i + 2 < n) dst[2] = b.x;
+                if (whole) dst[3] = b.y;
             }
         }
     }

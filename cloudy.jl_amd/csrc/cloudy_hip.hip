@@ -228,10 +228,13 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
     const bool aligned2 =
         ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & amask) == 0 && (ld % 2 == 0);
     void *args[] = {&n, &ld, &in, &out};
-    if (plan->jit.allinf4_f32 && !h.force_ppl1 && (ld % 4 == 0) &&
-        ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+    if (plan->jit.allinf4_f32 && !h.force_ppl1) {
+        // CLOUDY_F32_FAST without thresholds: the packed single-precision kernel for EVERY layout (16-B accesses where the
+        // planes allow them, scalar ones otherwise): the arithmetic is a property of the plan, not of the batch's alignment
+        int aligned16 = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+        void *args4[] = {&n, &ld, &in, &out, &aligned16};
         const unsigned g4 = (unsigned)(((n + 3) / 4 + kBlock - 1) / kBlock);
-        return hipModuleLaunchKernel(plan->jit.allinf4_f32, g4, 1, 1, kBlock, 1, 1, 0, r.stream, args, nullptr);
+        return hipModuleLaunchKernel(plan->jit.allinf4_f32, g4, 1, 1, kBlock, 1, 1, 0, r.stream, args4, nullptr);
     }
     if (aligned2 && !h.force_ppl1) {
         const unsigned g2 = (unsigned)(((n + 1) / 2 + kBlock - 1) / kBlock);

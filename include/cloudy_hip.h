@@ -148,11 +148,12 @@ typedef struct cloudy_plan_desc {
                                                 (packed v_pk_fma_f32, four parcels per lane): <= 1e-2 of scale,
                                                 99.9 % of parcels <= 1e-4, median 1e-8, and parcels whose closure is
                                                 clamped to k = eps may come out Inf / NaN where fp64 arithmetic stays
-                                                finite.  That packed kernel needs ld % 4 == 0 and 16-byte aligned
-                                                planes; any other layout of the same plan -- and cloudy_ssprk33_steps /
-                                                cloudy_tsit5_steps -- run fp64 arithmetic on the float planes (~2e-7):
-                                                the arithmetic of an all-Inf F32_FAST plan depends on the batch layout;
-                                                use CLOUDY_F32 where one answer per parcel matters), or
+                                                finite.  Every layout of a batch takes that arithmetic (16-byte
+                                                accesses where ld % 4 == 0 and the planes are aligned, scalar ones
+                                                otherwise: same bits).  cloudy_ssprk33_steps / cloudy_tsit5_steps of
+                                                such a plan run fp64 arithmetic on the float planes (~2e-7): their
+                                                right-hand side is more accurate than cloudy_coal_rhs of the same
+                                                plan; use CLOUDY_F32 where the two must agree), or
                                                 CLOUDY_F64_RELAXED (fp64 planes and arithmetic; the power series and the
                                                 continued fraction of the incomplete gamma function of the threshold
                                                 plans stop at 1e-11 instead of 1e-17 / 1e-16: <= 1e-9 of scale against
