@@ -177,7 +177,8 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
         int n_steps = r.n_steps;
         if (h.coal_style == CLOUDY_NUMERICAL_COAL) {
             const unsigned qb = h.q.mode == QUAD_CONVERGED ? (unsigned)kBlock : (unsigned)quad_block(h.q.nq);
-            void *args[] = {&n, &ld, &in, &out, &dt, &n_steps};
+            unsigned char *hint = h.q.mode == QUAD_CONVERGED ? conv_hints(plan, n, r.stream) : nullptr;
+            void *args[] = {&n, &ld, &in, &out, &dt, &n_steps, &hint};
             return hipModuleLaunchKernel(plan->int_tsit5, (unsigned)((n + qb - 1) / qb), 1, 1, qb, 1, 1, 0, r.stream, args, nullptr);
         }
         const double *nodes = h.nodes_dev;
@@ -189,7 +190,8 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
         if (r.op == OP_SSPRK33) {
             double dt = r.dt;
             int n_steps = r.n_steps;
-            void *args[] = {&n, &ld, &in, &out, &dt, &n_steps};
+            unsigned char *hint = h.q.mode == QUAD_CONVERGED ? conv_hints(plan, n, r.stream) : nullptr;
+            void *args[] = {&n, &ld, &in, &out, &dt, &n_steps, &hint};
             return hipModuleLaunchKernel(plan->int_ssprk33, (unsigned)((n + qb - 1) / qb), 1, 1, qb, 1, 1, 0, r.stream, args,
                                          nullptr);
         }

@@ -206,13 +206,12 @@ __device__ __forceinline__ void quad_coal_ints(const KArgs<N, 1> &A, const QArgs
 // 256.  Loads and stores are a permutation inside the workgroup's 2-KB window of each plane.  Which lane computes a parcel
 // changes nothing in its result (parcels are independent; the wave-level votes of the walk only skip code that is a no-op for
 // every lane), so results are bit-identical with and without hints, and a stale or foreign hint costs balance, never accuracy.
-template <int N, int KIND, int NQ, typename TIO, bool CONV = false>
-__device__ __forceinline__ void coal_rhs_quad_body(const KArgs<N, 1> &A, const QArgs &Q, const double *__restrict__ tab,
-                                                   size_t n, size_t ld, const TIO *__restrict__ in,
-                                                   TIO *__restrict__ out, unsigned char *__restrict__ hint = nullptr) {
-    constexpr int QB = NQ ? quad_block(NQ) : kBlock;
+// the parcel this lane takes: the natural one, or -- hints given -- the parcel of rank threadIdx.x among the workgroup's parcels
+// ordered by their hint bytes (every lane of the workgroup must call it: barriers)
+template <int QB>
+__device__ __forceinline__ size_t quad_ranked_parcel(size_t n, const unsigned char *__restrict__ hint) {
     size_t i = (size_t)blockIdx.x * QB + threadIdx.x;
-    if (CONV && hint != nullptr) {   // (a kernel argument: the same for every lane)
+    if (hint != nullptr) {   // (a kernel argument: the same for every lane)
         __shared__ unsigned int sh_cnt[QB];
         __shared__ unsigned short sh_perm[QB];
         const bool valid = i < n;
@@ -220,6 +219,15 @@ __device__ __forceinline__ void coal_rhs_quad_body(const KArgs<N, 1> &A, const Q
         regime_rank<QB>(valid, hb > QB - 2 ? QB - 2 : hb, sh_cnt, sh_perm);
         i = (size_t)blockIdx.x * QB + sh_perm[threadIdx.x];   // (lanes without a parcel rank last)
     }
+    return i;
+}
+
+template <int N, int KIND, int NQ, typename TIO, bool CONV = false>
+__device__ __forceinline__ void coal_rhs_quad_body(const KArgs<N, 1> &A, const QArgs &Q, const double *__restrict__ tab,
+                                                   size_t n, size_t ld, const TIO *__restrict__ in,
+                                                   TIO *__restrict__ out, unsigned char *__restrict__ hint = nullptr) {
+    constexpr int QB = NQ ? quad_block(NQ) : kBlock;
+    const size_t i = quad_ranked_parcel<QB>(n, CONV ? hint : nullptr);
     if (i >= n) return;
     double nn[N], th[N], kk[N], acc[N][3];
     load_parcel<N, 1, TIO>(A, i, ld, in, nn, th, kk);
@@ -246,10 +254,13 @@ __device__ __forceinline__ void coal_rhs_quad_body(const KArgs<N, 1> &A, const Q
 template <int N, int KIND, int NQ, typename TIO, bool CONV = false>
 __device__ __forceinline__ void quad_ssprk33_body(const KArgs<N, 1> &A, const QArgs &Q, const double *__restrict__ tab,
                                                   size_t n, size_t ld, const TIO *u_in, TIO *u_out, double dt,
-                                                  int n_steps) {
+                                                  int n_steps, unsigned char *__restrict__ hint = nullptr) {
+    // (converged mode: the lane keeps, for the whole call, the parcel its hint ranks it to -- the cost of a parcel moves little
+    // over a few stages -- and leaves the cost of its last evaluation behind; coal_rhs_quad_body shares the bytes)
     constexpr int QB = NQ ? quad_block(NQ) : kBlock;
-    const size_t i = (size_t)blockIdx.x * QB + threadIdx.x;
+    const size_t i = quad_ranked_parcel<QB>(n, CONV ? hint : nullptr);
     if (i >= n) return;
+    int cost = 0;
     double u[N][3], up[N][3];
 #pragma unroll
     for (int m = 0; m < N; ++m) {
@@ -275,10 +286,39 @@ __device__ __forceinline__ void quad_ssprk33_body(const KArgs<N, 1> &A, const QA
                 const double m2 = div_by_const(u[m][2], A.norm[3 * m + 2], A.inv_norm[3 * m + 2]);
                 invert_closure(A.dist_type[m], m0, m1, m2, A.kmin, A.kmax, nn[m], th[m], kk[m]);
             }
-            if (CONV)
-                conv_coal_ints<N, KIND>(A, Q, tab, nn, th, kk, acc);
-            else
+            if (CONV) {
+                // the state and the step's first value wait in the lane's own LDS slots across the walk (conflict-free, no
+                // barrier: a lane reads what it wrote) instead of in 36 registers the walk has no room for -- round 5: the fused
+                // converged integrator had 251 spilled registers and was 1.16 x SLOWER than three cloudy_coal_rhs launches
+                // (not under the Long kernel: its incomplete-beta tables already take 48 KB per workgroup, and 110 KB would leave
+                // one workgroup per CU)
+                constexpr bool kPark = CONV && KIND != KF_LONG;
+                __shared__ double sh_state[kPark ? 6 * N : 1][QB];
+                if (kPark) {
+                    const int t0 = threadIdx.x;
+#pragma unroll
+                    for (int m = 0; m < N; ++m)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            sh_state[kPark ? 3 * m + q : 0][t0] = u[m][q];
+                            sh_state[kPark ? 3 * N + 3 * m + q : 0][t0] = up[m][q];
+                        }
+                }
+                conv_coal_ints<N, KIND>(A, Q, tab, nn, th, kk, acc, cost);
+                if (kPark) {
+                    int t1 = threadIdx.x;
+                    asm volatile("" : "+v"(t1));
+#pragma unroll
+                    for (int m = 0; m < N; ++m)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            u[m][q] = sh_state[kPark ? 3 * m + q : 0][t1];
+                            up[m][q] = sh_state[kPark ? 3 * N + 3 * m + q : 0][t1];
+                        }
+                }
+            } else {
                 quad_coal_ints<N, KIND, NQ>(A, Q, tab, nn, th, kk, acc);
+            }
 #pragma unroll
             for (int m = 0; m < N; ++m) {
                 f[m][0] = acc[m][0] * (ksc * A.out_scale[3 * m + 0]);
@@ -311,16 +351,19 @@ __device__ __forceinline__ void quad_ssprk33_body(const KArgs<N, 1> &A, const QA
         u_out[(size_t)(off + 1) * ld + i] = (TIO)u[m][1];
         if (A.np[m] == 3) u_out[(size_t)(off + 2) * ld + i] = (TIO)u[m][2];
     }
+    if (CONV && hint != nullptr && n_steps > 0) hint[i] = (unsigned char)(cost > 255 ? 255 : cost);
 }
 
 // cloudy_tsit5_steps of a NumericalCoalStyle plan (round 4): the tableau of tsit5_advance (kernels.hpp) around the same
 // right-hand side as quad_ssprk33_body.  Plan-time compiled only (jit.hpp part 4).
 template <int N, int KIND, int NQ, typename TIO, bool CONV = false>
 __device__ __forceinline__ void quad_tsit5_body(const KArgs<N, 1> &A, const QArgs &Q, const double *__restrict__ tab,
-                                                size_t n, size_t ld, const TIO *u_in, TIO *u_out, double dt, int n_steps) {
+                                                size_t n, size_t ld, const TIO *u_in, TIO *u_out, double dt, int n_steps,
+                                                unsigned char *__restrict__ hint = nullptr) {
     constexpr int QB = NQ ? quad_block(NQ) : kBlock;
-    const size_t i = (size_t)blockIdx.x * QB + threadIdx.x;
+    const size_t i = quad_ranked_parcel<QB>(n, CONV ? hint : nullptr);   // (as quad_ssprk33_body)
     if (i >= n) return;
+    int cost = 0;
     double u[N][3];
 #pragma unroll
     for (int m = 0; m < N; ++m) {
@@ -340,7 +383,7 @@ __device__ __forceinline__ void quad_tsit5_body(const KArgs<N, 1> &A, const QArg
             invert_closure(A.dist_type[m], m0, m1, m2, A.kmin, A.kmax, nn[m], th[m], kk[m]);
         }
         if (CONV)
-            conv_coal_ints<N, KIND>(A, Q, tab, nn, th, kk, acc);
+            conv_coal_ints<N, KIND>(A, Q, tab, nn, th, kk, acc, cost);
         else
             quad_coal_ints<N, KIND, NQ>(A, Q, tab, nn, th, kk, acc);
 #pragma unroll
@@ -357,6 +400,7 @@ __device__ __forceinline__ void quad_tsit5_body(const KArgs<N, 1> &A, const QArg
         u_out[(size_t)(off + 1) * ld + i] = (TIO)u[m][1];
         if (A.np[m] == 3) u_out[(size_t)(off + 2) * ld + i] = (TIO)u[m][2];
     }
+    if (CONV && hint != nullptr && n_steps > 0) hint[i] = (unsigned char)(cost > 255 ? 255 : cost);
 }
 
 // ahead-of-time instance: run-time point count, the rule arrays in scratch (the plan-time compiled kernel of jit.hpp
