@@ -50,7 +50,7 @@ CASES = [
     dict(name="gamma_exp_long_threshold_in_rain", kf=(3, [4.0, LONG[1], LONG[2]]), pdists=[(1, 50.0, 0.3, 3.0), (0, 2.0, 5.0, 1.0)], mp=True),
     # test/examples/Numerical/n_particles_lognorm.jl: Lognormal(n, log(mass_scale), log(2)), LinearKernelFunction
     dict(name="1lognormal_linear", kf=(1, [5e-3]), pdists=[(3, 100.0, math.log(0.1), LN2)]),
-    dict(name="2lognormal_linear", kf=(1, [5e-3]), pdists=[(3, 100.0, math.log(0.1), LN2), (3, 1.0, math.log(10.0), LN2)]),
+    dict(name="2lognormal_linear", kf=(1, [5e-3]), pdists=[(3, 100.0, math.log(0.1), LN2), (3, 1.0, math.log(10.0), LN2)], mp=True),
     dict(name="3lognormal_linear", kf=(1, [5e-3]),
          pdists=[(3, 100.0, math.log(0.1), LN2), (3, 10.0, math.log(1.0), LN2), (3, 1.0, math.log(10.0), LN2)]),
     dict(name="1lognormal_hydrodynamic", kf=(2, [E_HYDRO]), pdists=[(3, 40.0, -0.5, 0.6)]),
@@ -58,7 +58,7 @@ CASES = [
     dict(name="lognormal_gamma_linear", kf=(1, [5e-3]), pdists=[(3, 80.0, -1.5, 0.7), (1, 2.0, 2.0, 3.0)], mp=True),
     dict(name="gamma_lognormal_hydrodynamic", kf=(2, [E_HYDRO]), pdists=[(1, 60.0, 0.2, 2.0), (3, 1.5, 1.2, 0.6)]),
     dict(name="1lognormal_long", kf=(3, LONG), pdists=[(3, 30.0, -1.0, 0.7)], mp=True),
-    dict(name="2lognormal_constant", kf=(0, [1e-4]), pdists=[(3, 100.0, -2.0, 0.833), (3, 3.0, 0.3, 0.833)]),
+    dict(name="2lognormal_constant", kf=(0, [1e-4]), pdists=[(3, 100.0, -2.0, 0.833), (3, 3.0, 0.3, 0.833)], mp=True),
     dict(name="gamma_lognormal_long", kf=(3, LONG), pdists=[(1, 100.0, 0.05, 2.0), (3, 1.0, 1.0, 0.5)], mp=True),
     dict(name="gamma_lognormal_gamma_hydro", kf=(2, [E_HYDRO]), pdists=[(1, 100.0, 0.05, 3.0), (3, 5.0, 0.5, 0.5), (1, 0.1, 80.0, 4.0)]),
     # multi-scale mixtures: a narrow or much smaller neighbour puts sharp transitions of weighting_fn inside the bulk of a
