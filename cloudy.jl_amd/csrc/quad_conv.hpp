@@ -962,7 +962,6 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
     // t = a0 + h xi.  Same tolerance as the other kernels now: 33 evaluations per parcel, <= 5e-12 of scale on 600 random
     // mixtures with shapes down to 1e-3 (against the rule at 1e-13).
     constexpr double kTolT = kConvTol;
-    constexpr bool kLong = KIND == KF_LONG;
     bool sing = false;   // PHASE 2: the initial panel in hand has x_t as its lower edge
     double stop = 0.0;   // the lower end of the walk: t_lo, or the lower end of the hole (PHASE 2)
     double hlo = 0.0, hhi = 0.0;   // the hole [x_t, 2 x_t] in the rule's variable, clamped to [t_lo, t_hi]
