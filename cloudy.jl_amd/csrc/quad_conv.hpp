@@ -700,13 +700,19 @@ __device__ __forceinline__ double conv_long_G_mid_tab(const QArgs &Q, double k, 
     const double x = xt * recip_fast(s), y = 1.0 - x;   // y in (0, 1/2)
     const double z2 = fma(8.0, y, -2.0);                // 2 z, z = 4 y - 1 in [-1, 1]
     double b1 = 0.0, b2 = 0.0;                           // Clenshaw: b_r = c_r + 2 z b_{r+1} - b_{r+2}
+    // (the lane index through an opaque copy: the twelve coefficients are READ here, per node -- left alone the compiler hoists
+    // the reads out of the node loop and keeps them in 24 registers the walk does not have: scratch instead of LDS)
+    int tl = threadIdx.x;
+#ifndef CLOUDY_LONG_TAB_HOIST
+    asm volatile("" : "+v"(tl));
+#endif
 #pragma unroll
     for (int r = kLongNT - 1; r >= 1; --r) {
-        const double b0 = fma(z2, b1, sh[row0 + r][threadIdx.x]) - b2;
+        const double b0 = fma(z2, b1, sh[row0 + r][tl]) - b2;
         b2 = b1;
         b1 = b0;
     }
-    const double g = fma(0.5 * z2, b1, sh[row0][threadIdx.x]) - b2;
+    const double g = fma(0.5 * z2, b1, sh[row0][tl]) - b2;
     const double yk = exp_fin(k * log_pos(y)) * c0;      // y^k / (k B(k, k))
     const double Dk = yk * exp_fin(k * lx);              // x^k y^k / (k B(k, k)) = D(k, k) / k
     const double Ikk = fma(-yk, g, 1.0);                 // I_x(k, k) = 1 - I_y(k, k)
