@@ -244,7 +244,7 @@ __device__ __forceinline__ void coal_rhs_quad_body(const KArgs<N, 1> &A, const Q
         st_stream(out + (size_t)(off + 1) * ld + i, acc[k][1] * (ksc * A.out_scale[3 * k + 1]));
         if (A.np[k] == 3) st_stream(out + (size_t)(off + 2) * ld + i, acc[k][2] * (ksc * A.out_scale[3 * k + 2]));
     }
-    if (CONV && hint != nullptr) hint[i] = (unsigned char)(cost > 255 ? 255 : cost);
+    if (CONV && hint != nullptr) hint[i] = conv_hint_byte<KIND>(cost);
 }
 
 // solve(ODEProblem(make_box_model_rhs(NumericalCoalStyle()), m, tspan, p), SSPRK33(), dt) -- the Numerical drivers
@@ -351,7 +351,7 @@ __device__ __forceinline__ void quad_ssprk33_body(const KArgs<N, 1> &A, const QA
         u_out[(size_t)(off + 1) * ld + i] = (TIO)u[m][1];
         if (A.np[m] == 3) u_out[(size_t)(off + 2) * ld + i] = (TIO)u[m][2];
     }
-    if (CONV && hint != nullptr && n_steps > 0) hint[i] = (unsigned char)(cost > 255 ? 255 : cost);
+    if (CONV && hint != nullptr && n_steps > 0) hint[i] = conv_hint_byte<KIND>(cost);
 }
 
 // cloudy_tsit5_steps of a NumericalCoalStyle plan (round 4): the tableau of tsit5_advance (kernels.hpp) around the same
@@ -400,7 +400,7 @@ __device__ __forceinline__ void quad_tsit5_body(const KArgs<N, 1> &A, const QArg
         u_out[(size_t)(off + 1) * ld + i] = (TIO)u[m][1];
         if (A.np[m] == 3) u_out[(size_t)(off + 2) * ld + i] = (TIO)u[m][2];
     }
-    if (CONV && hint != nullptr && n_steps > 0) hint[i] = (unsigned char)(cost > 255 ? 255 : cost);
+    if (CONV && hint != nullptr && n_steps > 0) hint[i] = conv_hint_byte<KIND>(cost);
 }
 
 // ahead-of-time instance: run-time point count, the rule arrays in scratch (the plan-time compiled kernel of jit.hpp
