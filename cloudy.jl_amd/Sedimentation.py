@@ -62,8 +62,9 @@ def make_rainshaft_rhs(coal_type=None):
 
 def solve_rainshaft_ssprk33(par, u, n_steps, out=None, stream=None):
     """`solve(ODEProblem(make_rainshaft_rhs(...), m, tspan, p), SSPRK33(), dt = p.dt)` of the rainshaft drivers
-    (rainshaft_gamma_mixture.jl:59-60), final state only, for a batch of independent columns of `par.nz` cells (fused in one launch up to 1024 cells -- above 256: one column per
-    workgroup, plan-time compiled kernel; taller columns stage by stage inside the library):
+    (rainshaft_gamma_mixture.jl:59-60), final state only, for a batch of independent columns of `par.nz` cells (fused in one launch up to 1024 cells -- workgroups of 256, 512 or
+    1024 threads holding whole columns, picked by `nz` in the plan-time compiled kernel; taller columns stage by stage inside
+    the library):
     one launch, state in registers, flux exchange through LDS (cloudy_rainshaft_ssprk33_steps).  `u` is advanced in
     place unless `out` is given."""
     from .box_model import _plan_for

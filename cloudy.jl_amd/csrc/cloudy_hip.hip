@@ -409,8 +409,6 @@ int build_host_plan(const cloudy_plan_desc *d, cloudy_plan **out, std::vector<do
     const int N = d->n_modes, P = numerical ? 1 : d->tensor_p;
     if (N < 1 || N > CLOUDY_MAX_MODES) return fail(CLOUDY_EUNSUPPORTED, "n_modes %d outside 1..%d", N, CLOUDY_MAX_MODES);
     if (P < 1 || P > CLOUDY_MAX_P) return fail(CLOUDY_EUNSUPPORTED, "tensor_p %d outside 1..%d", P, CLOUDY_MAX_P);
-    if (numerical && N > CLOUDY_AOT_MAX_MODES)
-        return fail(CLOUDY_EUNSUPPORTED, "NumericalCoalStyle plans have up to %d modes (n_modes = %d)", CLOUDY_AOT_MAX_MODES, N);
     if (!numerical && !d->kernel_c) return fail(CLOUDY_EINVAL, "kernel_c is NULL");
     if (numerical) {
         if (d->kernel_func < CLOUDY_KFUNC_CONSTANT || d->kernel_func > CLOUDY_KFUNC_LONG)
@@ -756,7 +754,7 @@ int cloudy_jit_selfcheck(const cloudy_plan_desc *d, const char *arch) {
     if (ok && !numerical && p->h.n_vel > 0 && p->h.mode != MODE_MOVING)
         ok = jit_compile(jit_source(p->h, 3), a, true, code, log);                     // fused column integrator
     if (ok && p->h.dtype != CLOUDY_F32_FAST) ok = jit_compile(jit_source(p->h, 4), a, true, code, log);  // cloudy_tsit5_steps
-    if (ok && !numerical && plan_beyond_aot(p->h)) ok = jit_compile(jit_source(p->h, 7), a, false, code, log);  // diagnostics
+    if (ok && plan_beyond_aot(p->h)) ok = jit_compile(jit_source(p->h, 7), a, false, code, log);  // diagnostics
     delete p;
     if (!ok) return fail(CLOUDY_EUNSUPPORTED, "plan-time compilation failed: %.440s", log.c_str());
     return CLOUDY_OK;

@@ -941,12 +941,15 @@ __device__ __forceinline__ void coal_ints_parcel(const KArgs<N, P> &A, const dou
 // evaluation, so their lanes are re-ranked on the CURRENT state of every stage, per thresholded mode; round 1 ranked them
 // once, on the initial state and the first thresholded mode only: 64 % active lanes in the rainshaft integrator).
 // Every lane of the workgroup must call it (barriers); `valid` = the lane holds a parcel.
-template <int N, int P, int MODE, bool SPEC, int BS>
-__device__ __forceinline__ void coal_ints_ranked(const KArgs<N, P> &A, const double *__restrict__ nodes, bool valid,
-                                                 const double (&nn)[N], const double (&th)[N], const double (&kk)[N],
-                                                 double (&acc)[N][3]) {
+// RELOAD: nn / th / kk come back as the lane's LDS slots hold them (the same bits for a valid lane; (0, 1, 1) otherwise), so
+// that a caller that needs them after the passes does not keep them in registers across the passes.
+template <int N, int P, int MODE, bool SPEC, int BS, bool RELOAD>
+__device__ __forceinline__ void coal_ints_ranked_impl(const KArgs<N, P> &A, const double *__restrict__ nodes, bool valid,
+                                                      double (&nn)[N], double (&th)[N], double (&kk)[N], double (&acc)[N][3],
+                                                      double (*&par_rows)[BS]) {
     constexpr int M_ = P + 2;
     __shared__ double sh_par[3 * N][BS];
+    par_rows = sh_par;  // (3N rows the caller may reuse once every lane has its parameters back: after its next barrier)
     __shared__ double sh_T[(N > 1 ? N - 1 : 1) * 3][BS];
     __shared__ unsigned int sh_cnt[BS];
     __shared__ unsigned short sh_perm[BS];
@@ -1019,6 +1022,28 @@ __device__ __forceinline__ void coal_ints_ranked(const KArgs<N, P> &A, const dou
         }
     }
     pair_terms<N, P, SPEC>(A, Mm, acc);
+    if (RELOAD) {
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+            nn[m] = nn2[m];
+            th[m] = th2[m];
+            kk[m] = kk2[m];
+        }
+    }
+}
+template <int N, int P, int MODE, bool SPEC, int BS>
+__device__ __forceinline__ void coal_ints_ranked(const KArgs<N, P> &A, const double *__restrict__ nodes, bool valid,
+                                                 const double (&nn)[N], const double (&th)[N], const double (&kk)[N],
+                                                 double (&acc)[N][3]) {
+    double a[N], b[N], c[N];
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        a[m] = nn[m];
+        b[m] = th[m];
+        c[m] = kk[m];
+    }
+    double (*unused)[BS];
+    coal_ints_ranked_impl<N, P, MODE, SPEC, BS, false>(A, nodes, valid, a, b, c, acc, unused);
 }
 
 struct SediArgs {
@@ -1583,18 +1608,34 @@ __global__ void __launch_bounds__(kBlock)
 // Every RHS evaluation first clamps negative moments of its argument to zero IN PLACE (rainshaft_helpers.jl:52 mutates
 // the array the integrator passed), which includes the FSAL evaluation on the final state of each step.
 // (SPEC: the plan constants Ag / Sg are compile-time objects of a kernel compiled for the plan, jit.hpp)
-// BS: workgroup size = cells per workgroup.  256 for columns of up to 256 cells (several columns per workgroup); the
-// plan-time compiled kernel also exists with 512 and 1024 threads for columns of up to 1024 cells, ONE column per
-// workgroup (round 4; taller columns would need a grid-wide exchange of the boundary flux).
+// BS: workgroup size = cells per workgroup (floor(BS / nz) whole columns).  The ahead-of-time kernel has 256 threads; the
+// kernel compiled for the plan exists with 256, 512 and 1024 threads, and jit_rainshaft_part() picks by column height (512 for
+// the reference's 20 cells: round 5; taller columns than 1024 cells are stepped stage by stage, cloudy_hip.hip).
 template <int N, int P, int MODE, typename TIO, bool SPEC = false, int BS = kRainshaftBlock>
 __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__restrict__ Ag, const SediArgs *__restrict__ Sg,
                                                        const double *__restrict__ nodes, int nz, size_t n_columns,
                                                        size_t ld, const TIO *u_in, TIO *u_out, double dt, double dz,
                                                        int n_steps) {
-    // (workgroup size, 20-cell columns: 384 threads -- a finer ranking, 4 instead of 16 idle lanes -- measured 40 % slower,
-    // two six-wave workgroups per CU overlap their per-stage barriers worse than three four-wave ones; 128 threads 8 %
-    // slower, the ranking over 128 cells is too coarse)
+    // (workgroup sizes that were measured and dropped, 20-cell columns: 384 threads 40 % slower, 320 threads 40 % slower --
+    // six- and five-wave workgroups do not spread evenly over four SIMDs; 128 threads 8 % slower, the ranking over 128 cells
+    // is too coarse)
     __shared__ double sh_flux[N * 3][BS];
+    // Round 5: (almost) NOTHING of the integrator's state is live across the Simpson passes of a stage (before: u, u_prev and
+    // the flux divergence, 18 doubles for two 3-moment modes -> 69 registers in scratch at the 4-wave occupancy target, 7.7 x
+    // the algorithmic HBM traffic; now 10 registers, 1.56 x).  (i) The sedimentation flux and its exchange come AFTER the
+    // passes, from (n, theta, k) read back from the ranking's LDS slots -- whose 3N rows, read by nobody but their owner once
+    // the passes are done, carry the exchange; (ii) of u and u_prev the update needs one combination per stage -- w = u_prev,
+    // 3 u_prev + u, u_prev + 2 u, formed BEFORE the passes exactly as the update formula forms it (same bits) -- and u_prev
+    // itself in stage 1 (for stage 2); (iii) w waits in sh_flux, as many rows of u_prev as fit at 16 waves per CU in sh_up
+    // (4 of 6 for N = 2), the empty-cell flag in a byte; (iv) the lane's place in its column is re-derived, not kept.
+    constexpr bool kPark = (MODE != MODE_ALLINF);
+    constexpr int kRowBytes = BS * 8;
+    constexpr int kLdsUsed = (3 * N + 3 * N + 3 * (N > 1 ? N - 1 : 1)) * kRowBytes + BS * 6;  // flux, sh_par, sh_T, cnt, perm
+    constexpr int kLdsBudget = 40960 * (BS / 256);  // 160 KB per CU, 16 waves: 4 / 2 / 1 workgroups of 256 / 512 / 1024 threads
+    constexpr int kLdsFreeRows = (kLdsBudget - kLdsUsed) / kRowBytes;
+    constexpr int NUP = !kPark ? 0 : kLdsFreeRows < 0 ? 0 : kLdsFreeRows > 3 * N ? 3 * N : kLdsFreeRows;
+    __shared__ double sh_up[NUP > 0 ? NUP : 1][BS];
+    __shared__ unsigned char sh_small[kPark ? BS : 1];  // the empty-cell flag of the stage (:67-72) waits here as well
     const KArgs<N, P> &A = *Ag;
     const int cpb = BS / nz;       // whole columns per workgroup
     const int pos = threadIdx.x;   // cell slot of the workgroup this lane integrates: column pos / nz, level pos % nz
@@ -1608,133 +1649,136 @@ __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__rest
 #pragma unroll
     for (int m = 0; m < N; ++m)
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
+        for (int q = 0; q < 3; ++q) {
             u[m][q] = (active && q < A.np[m]) ? (double)u_in[(size_t)(A.off[m] + q) * ld + i] : 0.0;
+            up[m][q] = 0.0;
+        }
 #pragma unroll 1
     for (int step = 0; step < n_steps; ++step) {
 #pragma unroll 1
         for (int stage = 0; stage < 3; ++stage) {
-            // The plan constants are re-derived through opaque zero offsets (see ssprk33_kernel), twice per stage: the
-            // closure inversion and the sedimentation flux see the norms and the velocity block, and only after the
-            // flux exchange are the tensors loaded for the coalescence integrals -- otherwise all of them are live in
-            // SGPRs at once and spill into VGPR lanes.
+            // The plan constants are re-derived through opaque zero offsets (see ssprk33_kernel), three times per stage: the
+            // closure inversion sees the norms, the coalescence integrals the tensors, the sedimentation flux the velocity
+            // block -- otherwise all of them are live in SGPRs at once and spill into VGPR lanes.
             size_t opaque_zero = 0;
             if (!SPEC) asm volatile("" : "+s"(opaque_zero));
             const KArgs<N, P> &As = *(Ag + opaque_zero);
-            const SediArgs &S = *(Sg + opaque_zero);
-            double f[N][3], nn[N], th[N], kk[N];
+            double nn[N], th[N], kk[N], w[N][3];
+            int ps = threadIdx.x;
+            if (kPark) asm volatile("" : "+v"(ps));
+            const int cl1 = ps / nz;
+            const bool active1 = kPark ? (cl1 < cpb) && ((size_t)blockIdx.x * cpb + cl1 < n_columns) : active;
             bool all_small = true;
+            // the clamp of the RHS (rainshaft_helpers.jl:52, in place), then OrdinaryDiffEq's SSPRK33 update, first half:
+            // w = u_prev (clamped) | 3 u_prev + u | u_prev + 2 u
+#pragma unroll
+            for (int m = 0; m < N; ++m)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    u[m][q] = u[m][q] < 0.0 ? 0.0 : u[m][q];
+                    if (stage == 0) up[m][q] = u[m][q];
+                    w[m][q] = stage == 0 ? u[m][q] : stage == 1 ? 3.0 * up[m][q] + u[m][q] : up[m][q] + 2.0 * u[m][q];
+                }
+            if (kPark) {
+#pragma unroll
+                for (int r = 0; r < 3 * N; ++r) {
+                    sh_flux[r][ps] = w[r / 3][r % 3];
+                    if (r < NUP) sh_up[r][ps] = up[r / 3][r % 3];
+                }
+            }
 #pragma unroll
             for (int m = 0; m < N; ++m) {
                 nn[m] = 0.0;
                 th[m] = 1.0;
                 kk[m] = 1.0;
             }
-            if (active) {
-                double fl[N][3];
+            if (active1) {
 #pragma unroll
                 for (int m = 0; m < N; ++m) {
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) u[m][q] = u[m][q] < 0.0 ? 0.0 : u[m][q];  // rainshaft_helpers.jl:52
                     const double m0 = div_by_const(u[m][0], As.norm[3 * m + 0], As.inv_norm[3 * m + 0]);
                     const double m1 = div_by_const(u[m][1], As.norm[3 * m + 1], As.inv_norm[3 * m + 1]);
                     const double m2 = div_by_const(u[m][2], As.norm[3 * m + 2], As.inv_norm[3 * m + 2]);
                     all_small = all_small && (m0 < kEps) && (m1 < kEps) && (As.np[m] != 3 || m2 < kEps);
                     invert_closure(As.dist_type[m], m0, m1, m2, As.kmin, As.kmax, nn[m], th[m], kk[m]);
                 }
-                sedi_flux_parcel<N>(As.dist_type, S, nn, th, kk, fl);
-#pragma unroll
-                for (int m = 0; m < N; ++m)
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        f[m][q] = (q < As.np[m]) ? fl[m][q] * As.out_scale[3 * m + q] : 0.0;
-                        sh_flux[3 * m + q][pos] = f[m][q];
-                    }
-                if (stage == 0) {
-#pragma unroll
-                    for (int m = 0; m < N; ++m)
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) up[m][q] = u[m][q];  // uprev (clamped)
-                }
             }
-            CLOUDY_STAGE_BARRIER();
-            if (active) {
-                const bool top = (iz == nz - 1);  // zero flux above the top cell (:80-81)
-#pragma unroll
-                for (int m = 0; m < N; ++m)
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const double f_up = top ? 0.0 : sh_flux[3 * m + q][pos + 1];
-                        f[m][q] = -(f_up - f[m][q]) / dz;  // :83-85
-                    }
-            }
+            if (kPark) sh_small[ps] = all_small ? 1 : 0;
             size_t opaque_zero2 = 0;
             if (!SPEC) asm volatile("" : "+s"(opaque_zero2));
             const KArgs<N, P> &Ac = *(Ag + opaque_zero2);
             double acc[N][3];
-#ifdef CLOUDY_RS_PARK_F
-            // (experiment, round 5) the flux divergence waits in the flux-exchange buffer across the Simpson pass instead of in
-            // registers: every lane has read its neighbour's flux by the barrier below
-            if (MODE != MODE_ALLINF) {
-                CLOUDY_STAGE_BARRIER();
-                if (active) {
-#pragma unroll
-                    for (int m = 0; m < N; ++m)
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) sh_flux[3 * m + q][pos] = f[m][q];
-                }
-            }
-#endif
+            double (*fx)[BS] = sh_flux;  // the flux-exchange rows of this stage
             if (MODE == MODE_ALLINF) {
                 if (active) coal_ints_parcel<N, P, MODE, false, SPEC>(Ac, nodes, nn, th, kk, acc);
-            } else {  // every lane of the workgroup: barriers inside
-                coal_ints_ranked<N, P, MODE, SPEC, BS>(Ac, nodes, active, nn, th, kk, acc);
+            } else {
+                // every lane of the workgroup: barriers inside.  (n, theta, k) come back from the lane's LDS slots, and those
+                // 3N rows -- read by nobody but their owner once the passes are done -- then carry the flux exchange
+                coal_ints_ranked_impl<N, P, MODE, SPEC, BS, true>(Ac, nodes, active1, nn, th, kk, acc, fx);
             }
-#ifdef CLOUDY_RS_PARK_F
-            if (MODE != MODE_ALLINF && active) {
-                int pp = threadIdx.x;
-                asm volatile("" : "+v"(pp));
+            // (the lane's place in its column is re-derived after the passes, not kept across them)
+            int pp = threadIdx.x;
+            if (kPark) asm volatile("" : "+v"(pp));
+            const int cl2 = pp / nz, iz2 = pp - cl2 * nz;
+            const bool active2 = kPark ? (cl2 < cpb) && ((size_t)blockIdx.x * cpb + cl2 < n_columns) : active;
+            const bool small2 = kPark ? sh_small[pp] != 0 : all_small;
+            size_t opaque_zero3 = 0;
+            if (!SPEC) asm volatile("" : "+s"(opaque_zero3));
+            const KArgs<N, P> &Af = *(Ag + opaque_zero3);
+            const SediArgs &S = *(Sg + opaque_zero3);
+            double f[N][3];
+            if (active2) {
+                double fl[N][3];
+                sedi_flux_parcel<N>(Af.dist_type, S, nn, th, kk, fl);
 #pragma unroll
                 for (int m = 0; m < N; ++m)
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) f[m][q] = sh_flux[3 * m + q][pp];
+                    for (int q = 0; q < 3; ++q) {
+                        f[m][q] = (q < Af.np[m]) ? fl[m][q] * Af.out_scale[3 * m + q] : 0.0;
+                        fx[3 * m + q][pp] = f[m][q];
+                    }
             }
-#endif
-            if (active) {
+            CLOUDY_STAGE_BARRIER();
+            if (kPark) {
 #pragma unroll
-                for (int m = 0; m < N; ++m)
-#pragma unroll
-                    for (int q = 0; q < 3; ++q)  // coal_source .+ sedi_source (:88), empty cells skip coalescence (:67-72)
-                        f[m][q] = ((q < Ac.np[m] && !all_small) ? acc[m][q] * Ac.out_scale[3 * m + q] : 0.0) + f[m][q];
-                if (stage == 0) {
-#pragma unroll
-                    for (int m = 0; m < N; ++m)
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) u[m][q] = up[m][q] + dt * f[m][q];
-                } else if (stage == 1) {
-#pragma unroll
-                    for (int m = 0; m < N; ++m)
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) u[m][q] = (3.0 * up[m][q] + u[m][q] + dt * f[m][q]) * 0.25;
-                } else {
-#pragma unroll
-                    for (int m = 0; m < N; ++m)
-#pragma unroll
-                        for (int q = 0; q < 3; ++q)
-                            u[m][q] = div_by_const(up[m][q] + 2.0 * u[m][q] + 2.0 * dt * f[m][q], 3.0, 1.0 / 3.0);
+                for (int r = 0; r < 3 * N; ++r) {
+                    w[r / 3][r % 3] = sh_flux[r][pp];
+                    if (r < NUP) up[r / 3][r % 3] = sh_up[r][pp];
                 }
+            }
+#pragma unroll
+            for (int m = 0; m < N; ++m)  // (a lane without a cell: so that no lane's u is live across the passes)
+                u[m][0] = u[m][1] = u[m][2] = 0.0;
+            if (active2) {
+                const bool top = (iz2 == nz - 1);  // zero flux above the top cell (:80-81)
+                const double c = stage == 2 ? 2.0 * dt : dt;
+#pragma unroll
+                for (int m = 0; m < N; ++m)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const double f_up = top ? 0.0 : fx[3 * m + q][pp + 1];
+                        const double fd = -(f_up - f[m][q]) / dz;  // :83-85
+                        // coal_source .+ sedi_source (:88), empty cells skip coalescence (:67-72)
+                        const double ft = ((q < Af.np[m] && !small2) ? acc[m][q] * Af.out_scale[3 * m + q] : 0.0) + fd;
+                        const double r = w[m][q] + c * ft;  // u_prev + dt f | 3 u_prev + u + dt f | u_prev + 2 u + 2 dt f
+                        u[m][q] = stage == 0 ? r : stage == 1 ? r * 0.25 : div_by_const(r, 3.0, 1.0 / 3.0);
+                    }
             }
             CLOUDY_STAGE_BARRIER();
         }
     }
-    if (active) {
+    int pe = threadIdx.x;
+    if (kPark) asm volatile("" : "+v"(pe));
+    const int cle = pe / nz;
+    const size_t cole = (size_t)blockIdx.x * cpb + cle;
+    if ((cle < cpb) && (cole < n_columns)) {
+        const size_t ie = cole * (size_t)nz + (pe - cle * nz);
 #pragma unroll
         for (int m = 0; m < N; ++m)
 #pragma unroll
             for (int q = 0; q < 3; ++q)
                 if (q < A.np[m]) {
                     const double v = (n_steps > 0 && u[m][q] < 0.0) ? 0.0 : u[m][q];  // the FSAL evaluation's clamp
-                    u_out[(size_t)(A.off[m] + q) * ld + i] = (TIO)v;
+                    u_out[(size_t)(A.off[m] + q) * ld + ie] = (TIO)v;
                 }
     }
 }

@@ -79,12 +79,13 @@ extern "C" {
 #define CLOUDY_MAX_P 8      /* P = tensor order + 1 */
 /* Plans of up to CLOUDY_AOT_MAX_MODES modes and order <= 4 (P <= CLOUDY_AOT_MAX_P; the reference's examples stop at 4
  * modes and order 4, box_gamma_mixture_4modes.jl:23, box_gamma_mixture_hydro.jl:23) have ahead-of-time compiled kernels
- * behind every entry point.  Larger AnalyticalCoalStyle plans (the reference's types bound neither N nor the order,
- * Coalescence.jl:55-104) run kernels compiled for the plan with hiprtc: the RHS / rainshaft / integrator kernels at
+ * behind every entry point.  Larger plans (the reference's types bound neither N nor the order, Coalescence.jl:55-104, and
+ * get_coal_ints(::NumericalCoalStyle) is generic in the number of modes, :470-489) run kernels compiled for the plan with hiprtc: the RHS / rainshaft / integrator kernels at
  * cloudy_plan_create (CLOUDY_EUNSUPPORTED there when plan-time compilation is off or fails -- there is no other path), the
  * per-mode diagnostics and the parameter-plane entry points (cloudy_update_dist_from_moments, cloudy_get_coal_ints,
  * cloudy_get_finite_2d_integrals, cloudy_compute_thresholds, cloudy_sedimentation_flux, cloudy_cond_evap_rhs,
- * cloudy_standard_N_q) on their first call.  A NumericalCoalStyle plan has at most CLOUDY_AOT_MAX_MODES modes. */
+ * cloudy_standard_N_q) on their first call.  A NumericalCoalStyle plan takes up to CLOUDY_MAX_MODES modes as well (round 5; 15 to
+ * 40 s of compilation per kernel for 5 to 8 modes, cached on disk; the order of its "tensor" is 0: P = 1). */
 #define CLOUDY_AOT_MAX_MODES 4
 #define CLOUDY_AOT_MAX_P 5
 #define CLOUDY_MAX_VEL 4    /* terms of the terminal-velocity power series */
@@ -318,11 +319,13 @@ int cloudy_rainshaft_rhs(const cloudy_plan *plan, size_t nz, size_t n_columns, s
 /* n_steps SSPRK33 steps of the rainshaft right-hand side above for n_columns independent columns of nz <= 1024 cells
  * (what `solve(ODEProblem(rhs, m, tspan, p), SSPRK33(), dt = p.dt)` does in rainshaft_single_gamma.jl:52-53,
  * rainshaft_gamma_mixture.jl:59-60), in ONE launch: a workgroup owns whole columns, the state stays in registers over
- * all stages and steps and the upwind flux of the cell above is exchanged through LDS.  As in the reference, every RHS
+ * all stages and steps (parked in LDS across the Simpson passes of a thresholded plan) and the upwind flux of the cell above
+ * is exchanged through LDS.  As in the reference, every RHS
  * evaluation first clamps negative moments of its argument to zero in place (rainshaft_helpers.jl:52), including the
  * FSAL evaluation on each step's result, so the returned state is clamped.  u_out_dev may equal u_in_dev.
- * nz <= 256: several columns per 256-thread workgroup; 256 < nz <= 1024 (round 4): one column per workgroup of 512 or 1024
- * threads, in the kernel compiled for the plan (CLOUDY_EUNSUPPORTED without hiprtc).  nz > 1024 (round 5; the reference's cell
+ * A workgroup of 256, 512 or 1024 threads holds floor(threads / nz) whole columns; the kernel compiled for the plan picks the
+ * size by nz (512 threads for the reference's 20 cells; results do not depend on it), the ahead-of-time kernel has 256 threads
+ * and nz <= 256 (256 < nz <= 1024 without hiprtc: CLOUDY_EUNSUPPORTED).  nz > 1024 (round 5; the reference's cell
  * loop is unbounded in nz, rainshaft_helpers.jl:55-78): the same steps stage by stage on the stream -- cloudy_rainshaft_rhs and
  * one update launch per stage, three stream-ordered scratch arrays of the state's size per call -- not fused, any nz. */
 int cloudy_rainshaft_ssprk33_steps(const cloudy_plan *plan, size_t nz, size_t n_columns, size_t ld,

@@ -126,12 +126,13 @@ MPMATH_CHECKED_MIN = 24   # (26 marked in oracle/numerical_adaptive.py; the two 
 
 
 def test_golden_set_is_what_the_verdict_asked_for():
-    """>= 44 cases, N = 1..4, Gamma / Exponential / Lognormal, hydrodynamic + Long + linear (+ constant), generated at
-    1e-10 by oracle/numerical_adaptive.py; the cases where the errors live carry an mpmath cross-check of every Q / R / S entry"""
+    """>= 47 cases, N = 1..4 and (round 5: plans of up to eight modes) 5, 6, 8, Gamma / Exponential / Lognormal, hydrodynamic +
+    Long + linear (+ constant), generated at 1e-10 by oracle/numerical_adaptive.py; the cases where the errors live carry an
+    mpmath cross-check of every Q / R / S entry"""
     g = _golden()
     cases = g["cases"]
-    assert len(cases) >= 44 and g["eps_outer"] <= 1e-10
-    assert {len(c["pdists"]) for c in cases} == {1, 2, 3, 4}
+    assert len(cases) >= 47 and g["eps_outer"] <= 1e-10
+    assert {len(c["pdists"]) for c in cases} == {1, 2, 3, 4, 5, 6, 8}
     assert {int(d[0]) for c in cases for d in c["pdists"]} == {0, 1, 3}
     assert {c["kf"][0] for c in cases} == {0, 1, 2, 3}
     # VERDICT r3 item 5 / r4 item 6: the golden set is pinned independently of the builder's own integrator -- mpmath (20 digits,

@@ -70,7 +70,8 @@ VARIANTS = {   # bench variant -> (kernel name prefix, items per launch in the b
     "moving4": ("cloudy_jit_sorted_n4p2_f64", 2_500_000),
     "cfg4q": ("cloudy_jit_quad_n3q10_hydro_f64", 12_500_000),
     "cfg3a_fused_ssprk33": ("cloudy_jit_ssprk33_n2p3_f64", 10_000_000),
-    "rainshaft_ssprk33_columns": (("cloudy_jit_rainshaft_ssprk33_n2p3_f64", "rainshaft_ssprk33_kernel<2, 3, 1, double>"), 10_000_000),
+    "rainshaft_ssprk33_columns": (("cloudy_jit_rainshaft_ssprk33_n2p3_f64_b512", "cloudy_jit_rainshaft_ssprk33_n2p3_f64",
+                                   "rainshaft_ssprk33_kernel<2, 3, 1, double>"), 10_000_000),
     "cfg4q_converged": ("cloudy_jit_quad_n3c8_hydro_f64", 12_500_000),
     "cfg4q_converged_long": ("cloudy_jit_quad_n3c8_long_f64", 12_500_000),
     "numerical_lognorm_example": ("cloudy_jit_quad_n2c8_linear_f64", 2_000_000),
