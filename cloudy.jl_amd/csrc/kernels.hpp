@@ -1022,12 +1022,14 @@ __device__ __forceinline__ void coal_ints_ranked_impl(const KArgs<N, P> &A, cons
         }
     }
     pair_terms<N, P, SPEC>(A, Mm, acc);
-    if (RELOAD) {
+    if (RELOAD) {  // (read again rather than kept across pair_terms: 3N doubles the moment rows and pair sums do not need)
+        int t3 = threadIdx.x;
+        asm volatile("" : "+v"(t3));
 #pragma unroll
         for (int m = 0; m < N; ++m) {
-            nn[m] = nn2[m];
-            th[m] = th2[m];
-            kk[m] = kk2[m];
+            nn[m] = sh_par[3 * m + 0][t3];
+            th[m] = sh_par[3 * m + 1][t3];
+            kk[m] = sh_par[3 * m + 2][t3];
         }
     }
 }
@@ -1622,12 +1624,13 @@ __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__rest
     __shared__ double sh_flux[N * 3][BS];
     // Round 5: (almost) NOTHING of the integrator's state is live across the Simpson passes of a stage (before: u, u_prev and
     // the flux divergence, 18 doubles for two 3-moment modes -> 69 registers in scratch at the 4-wave occupancy target, 7.7 x
-    // the algorithmic HBM traffic; now 10 registers, 1.56 x).  (i) The sedimentation flux and its exchange come AFTER the
+    // the algorithmic HBM traffic; now none, 1.01 x).  (i) The sedimentation flux and its exchange come AFTER the
     // passes, from (n, theta, k) read back from the ranking's LDS slots -- whose 3N rows, read by nobody but their owner once
     // the passes are done, carry the exchange; (ii) of u and u_prev the update needs one combination per stage -- w = u_prev,
     // 3 u_prev + u, u_prev + 2 u, formed BEFORE the passes exactly as the update formula forms it (same bits) -- and u_prev
     // itself in stage 1 (for stage 2); (iii) w waits in sh_flux, as many rows of u_prev as fit at 16 waves per CU in sh_up
-    // (4 of 6 for N = 2), the empty-cell flag in a byte; (iv) the lane's place in its column is re-derived, not kept.
+    // (4 of 6 for N = 2), the empty-cell flag in a byte; (iv) the lane's place in its column is re-derived, not kept; (v) the
+    // lane's own flux is read back from the exchange rows after the barrier (kept, it was the last thing the allocator spilled).
     constexpr bool kPark = (MODE != MODE_ALLINF);
     constexpr int kRowBytes = BS * 8;
     constexpr int kLdsUsed = (3 * N + 3 * N + 3 * (N > 1 ? N - 1 : 1)) * kRowBytes + BS * 6;  // flux, sh_par, sh_T, cnt, perm
@@ -1725,17 +1728,14 @@ __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__rest
             if (!SPEC) asm volatile("" : "+s"(opaque_zero3));
             const KArgs<N, P> &Af = *(Ag + opaque_zero3);
             const SediArgs &S = *(Sg + opaque_zero3);
-            double f[N][3];
             if (active2) {
                 double fl[N][3];
                 sedi_flux_parcel<N>(Af.dist_type, S, nn, th, kk, fl);
 #pragma unroll
                 for (int m = 0; m < N; ++m)
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        f[m][q] = (q < Af.np[m]) ? fl[m][q] * Af.out_scale[3 * m + q] : 0.0;
-                        fx[3 * m + q][pp] = f[m][q];
-                    }
+                    for (int q = 0; q < 3; ++q)  // (the lane reads its own flux back after the barrier as well: not kept)
+                        fx[3 * m + q][pp] = (q < Af.np[m]) ? fl[m][q] * Af.out_scale[3 * m + q] : 0.0;
             }
             CLOUDY_STAGE_BARRIER();
             if (kPark) {
@@ -1756,7 +1756,7 @@ __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__rest
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
                         const double f_up = top ? 0.0 : fx[3 * m + q][pp + 1];
-                        const double fd = -(f_up - f[m][q]) / dz;  // :83-85
+                        const double fd = -(f_up - fx[3 * m + q][pp]) / dz;  // :83-85
                         // coal_source .+ sedi_source (:88), empty cells skip coalescence (:67-72)
                         const double ft = ((q < Af.np[m] && !small2) ? acc[m][q] * Af.out_scale[3 * m + q] : 0.0) + fd;
                         const double r = w[m][q] + c * ft;  // u_prev + dt f | 3 u_prev + u + dt f | u_prev + 2 u + 2 dt f

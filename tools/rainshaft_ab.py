@@ -57,6 +57,7 @@ def main():
         run(plan, nz, ncol, u, out, 2)
         pkg._lib.check(L.cloudy_stream_synchronize(None))
         res = np.ascontiguousarray(out.to_numpy())
+        res[np.isnan(res)] = np.nan   # (one NaN pattern: the sign of a NaN is not a result)
         h = hashlib.sha256(res.tobytes()).hexdigest()[:16]
         if os.environ.get("RS_AB_DUMP") and n <= 50000:
             np.save(os.path.join(os.environ["RS_AB_DUMP"], f"rsab_{tag}_{name}_{nz}.npy"), res)
