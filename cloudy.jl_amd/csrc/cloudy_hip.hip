@@ -164,7 +164,7 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
         int nz = (int)r.nz, n_steps = r.n_steps;
         size_t n_columns = r.n / r.nz;
         double dt = r.dt, dz = r.dz;
-        int part = jit_rainshaft_part(r.nz);
+        int part = jit_rainshaft_part(r.nz, r.n / r.nz);
         if (part == 8 && plan->rs_int320 == nullptr) part = 3;   // (as run() decided)
         const unsigned bs = (unsigned)jit_rainshaft_block(part);
         hipFunction_t fn = part == 3 ? plan->rs_int : part == 5 ? plan->rs_int512 : part == 8 ? plan->rs_int320 : plan->rs_int1024;
@@ -310,7 +310,7 @@ int run(const cloudy_plan *plan, const LaunchReq &r) {
         return fail(CLOUDY_EUNSUPPORTED, "cloudy_tsit5_steps of a NumericalCoalStyle plan runs the kernel compiled for the plan "
                                          "(hiprtc); plan-time compilation is off or failed: %s", plan->tsit5_log.c_str());
     if (use_jit && r.op == OP_RAINSHAFT_SSPRK33) {
-        int part = jit_rainshaft_part(r.nz);
+        int part = jit_rainshaft_part(r.nz, r.n / r.nz);
         if (part == 8) {   // (falls back to the 256-thread kernel if this one does not compile)
             std::call_once(plan->rsint320_once, [&] { (void)jit_get_rainshaft_integrator(plan->h, plan->rs_int320, plan->rsint320_log, 8); });
             if (plan->rs_int320 == nullptr) part = 3;

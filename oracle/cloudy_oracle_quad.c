@@ -501,7 +501,10 @@ static void co_conv_range_top(double A, double top, double *tlo, double *thi);
 #define CO_CONV_FLOOR 1e-10
 #define CO_CONV_BUDGET 8192   /* panel evaluations of one rule (Gamma weight) */
 #define CO_CONV_BUDGET_LN 1024 /* ... of the outer rule of a Lognormal mode's T_m (96 q inner points per node) */
-#define CO_CONV_MAX_MARKS 96
+/* marks of one rule: (2 (CO_CONV_IMAX + 1) + 1) = 27 per other mode at most, + 2 kinks of the Long kernel's G; up to
+ * CO_MAX_MODES - 1 = 7 other modes (round 5: plans of up to eight modes; 96 were enough for four -- a six-mode Long case of
+ * tools/fuzz_parity.py --converged --big wrote past them) */
+#define CO_CONV_MAX_MARKS ((CO_MAX_MODES - 1) * (2 * (CO_CONV_IMAX + 1) + 1) + 3)
 static const double CO_GK_X[15] = {-0.991455371120812639206854697526329, -0.949107912342758524526189684047851,
                                    -0.864864423359769072789712788640926, -0.741531185599394439863864773280788,
                                    -0.586087235467691130294144838258730, -0.405845151377397166906606412076961,

@@ -30,6 +30,32 @@ DRIVER = textwrap.dedent("""
         O.update_dist_batch(p, mom)
     pm = O.make_params([1, 0, 1], np.array([[0, 5.0], [5.0, 0]]), (0.99, 0.5, 1.0), norms=(1e6, 1e-9), threshold_style=1)
     O.rhs_coal_batch(pm, np.abs(rng.normal(size=(8, 16))) * 1e3, n_threads=1)
+    # the NumericalCoalStyle restatements (cloudy_oracle_quad.c, cloudy_oracle_adaptive.c) up to eight modes: per-rule mark
+    # lists, per-mode tables (round 5: a six-mode Long-kernel case of tools/fuzz_parity.py --converged --big wrote past the 96
+    # marks that four modes needed)
+    for types, kind, args in [([0, 1, 1, 1, 3, 1], O.KF_LONG, (3.48e-9, 6.66e9, 29.6)), ([1] * 8, O.KF_HYDRODYNAMIC, (3e2,)),
+                              ([1, 3, 1, 0, 1, 1, 1], O.KF_LINEAR, (5.0,)), ([1, 1, 1], O.KF_LONG, (5.236e-10, 9.44e9, 5.78)),
+                              ([3, 1, 0, 1, 1], O.KF_CONSTANT, (1e-4,))]:
+        N = len(types)
+        p = O.make_params(types, np.zeros((1, 1)), (inf,) * N, norms=(1e6, 1e-9))
+        kf = O.get_normalized_kernel_func(O.kernel_func(kind, *args), (1e6, 1e-9))
+        edges = np.logspace(-12, -4, N + 1)
+        rows = []
+        n = 12
+        for i, t in enumerate(types):   # one size class per mode, number densities falling with size, wide and narrow shapes
+            nn = 10.0 ** rng.uniform(6 - 12.0 * i / N, 9 - 12.0 * i / N, n)
+            k = rng.uniform(0.5, 7.0, n)
+            th = 10.0 ** rng.uniform(np.log10(edges[i]), np.log10(edges[i + 1]), n) / k
+            m = [nn, nn * k * th, nn * k * (k + 1) * th * th]
+            m[2][:2] = m[1][:2] ** 2 / m[0][:2]        # zero variance: the shape clamp (narrow cores: the longest mark ladders)
+            rows += m[:2] + ([m[2]] if t in (1, 3) else [])
+        mom = np.ascontiguousarray(np.stack(rows))
+        mom[:, 2] = 0.0
+        O.rhs_coal_numerical_converged_batch(p, kf, 8, mom, with_scale=True)
+        O.rhs_coal_numerical_batch(p, kf, 6, mom, with_noise=True)
+    pd = [O.make_dist(1, 100.0, 0.02, 2.0), O.make_dist(1, 20.0, 0.2, 3.0), O.make_dist(0, 4.0, 1.5, 1.0), O.make_dist(1, 0.5, 12.0, 3.5),
+          O.make_dist(1, 0.05, 100.0, 4.0)]
+    O.get_coal_ints_numerical_adaptive(pd, O.kernel_func(O.KF_LINEAR, 5e-3), 1e-6, 1e-8)
     print("sanitized run ok")
 """)
 

@@ -239,11 +239,18 @@ def check_callers(pkg, cfg, cd, op, mom, plan, k_range, scale):
     assert np.allclose(dm.to_numpy()[okc], wc[okc], rtol=1e-10, atol=0), "rhs_condensation"
 
 
-def random_numerical_config(rng, wild=False):
+def random_numerical_config(rng, wild=False, big=False):
     """NumericalCoalStyle plans: random N, closure families (Exponential / Gamma / Lognormal), kernel function family with
-    random parameters, rule order, plane type."""
-    N = int(rng.integers(1, 5))
+    random parameters, rule order, plane type.  big: 5 ... 8 modes (round 5: kernels compiled for the plan only; at most one
+    Lognormal mode -- each one costs a 2-D rule on the CPU side too)."""
+    N = int(rng.integers(5, 9)) if big else int(rng.integers(1, 5))
     dist = [int(rng.choice([0, 1, 1, 1, 3])) for _ in range(N)]
+    if big:
+        seen = False
+        for i, t in enumerate(dist):
+            if t == 3:
+                dist[i] = 1 if seen else 3
+                seen = True
     kind = int(rng.integers(0, 4))
     params = {0: (float(10.0 ** rng.uniform(-6, -2)),), 1: (float(10.0 ** rng.uniform(-1, 1.5)),),
               2: (float(10.0 ** rng.uniform(1, 3)),),
@@ -267,7 +274,8 @@ def check_numerical_config(pkg, cfg, n, seed):
     tio = np.float64 if cfg["dtype"] == 0 else np.float32
     mom_in = mom.astype(tio).astype(np.float64)
     jit = pkg.NumericalPlan(cfg["dist"], kfn, cfg["norms"], cfg["nq"], k_range=cfg["k_range"], dtype=cfg["dtype"], specialize=1, quad_mode=0)
-    aot = pkg.NumericalPlan(cfg["dist"], kfn, cfg["norms"], cfg["nq"], k_range=cfg["k_range"], dtype=cfg["dtype"], specialize=-1, quad_mode=0)
+    aot = jit if cfg["N"] > 4 else pkg.NumericalPlan(cfg["dist"], kfn, cfg["norms"], cfg["nq"], k_range=cfg["k_range"],
+                                                     dtype=cfg["dtype"], specialize=-1, quad_mode=0)   # (no ahead-of-time kernel beyond 4 modes)
     a, b = run(pkg, jit, mom_in, tio), run(pkg, aot, mom_in, tio)
     want, scale, noise = O.rhs_coal_numerical_batch(op, okf, cfg["nq"], mom_in, with_noise=True)
     keep = np.ones(mom.shape[1], dtype=bool)
@@ -321,7 +329,7 @@ def check_converged_config(pkg, cfg, n, seed):
     q = int(min(max(cfg["nq"], 4), 16))
     mom = moments_for(cfg["dist"], n, seed)
     jit = pkg.NumericalPlan(cfg["dist"], kfn, cfg["norms"], q, k_range=cfg["k_range"], specialize=1, quad_mode=1)
-    aot = pkg.NumericalPlan(cfg["dist"], kfn, cfg["norms"], q, k_range=cfg["k_range"], specialize=-1, quad_mode=1)
+    aot = jit if cfg["N"] > 4 else pkg.NumericalPlan(cfg["dist"], kfn, cfg["norms"], q, k_range=cfg["k_range"], specialize=-1, quad_mode=1)
     a, b = run(pkg, jit, mom, np.float64), run(pkg, aot, mom, np.float64)
     # round 5: the second call of the plan ranks the parcels of a workgroup by the cost hints the first call left -- not a bit may change
     a2 = run(pkg, jit, mom, np.float64)
@@ -353,7 +361,7 @@ def main():
     ap.add_argument("--wild", action="store_true", help="also randomise norms and the k clamp range")
     ap.add_argument("--numerical", action="store_true", help="NumericalCoalStyle (fixed Gauss rule) plans instead of tensor plans")
     ap.add_argument("--converged", action="store_true", help="NumericalCoalStyle plans in CLOUDY_QUAD_CONVERGED mode")
-    ap.add_argument("--big", action="store_true", help="tensor plans beyond the ahead-of-time families (5...8 modes, or order 5...7)")
+    ap.add_argument("--big", action="store_true", help="plans beyond the ahead-of-time families (tensor plans: 5...8 modes, or order 5...7; with --numerical / --converged: 5...8 modes)")
     a = ap.parse_args()
     pkg = load_package()
     rng = np.random.default_rng(a.seed)
@@ -361,7 +369,7 @@ def main():
     fails = 0
     for c in range(a.configs):
         if a.converged:
-            cfg = random_numerical_config(rng, a.wild)
+            cfg = random_numerical_config(rng, a.wild, a.big)
             tag = (f"#{c} converged N={cfg['N']} dist={cfg['dist']} kernel={['constant', 'linear', 'hydro', 'long'][cfg['kind']]}"
                    f"{tuple(f'{v:.3g}' for v in cfg['params'])} q={min(max(cfg['nq'], 4), 16)}"
                    + (f" norms=({cfg['norms'][0]:.1e},{cfg['norms'][1]:.1e}) k_range={cfg['k_range']}" if a.wild else ""))
@@ -373,7 +381,7 @@ def main():
                 print(f"FAIL {tag}: {e}", flush=True)
             continue
         if a.numerical:
-            cfg = random_numerical_config(rng, a.wild)
+            cfg = random_numerical_config(rng, a.wild, a.big)
             tag = (f"#{c} numerical N={cfg['N']} dist={cfg['dist']} kernel={['constant', 'linear', 'hydro', 'long'][cfg['kind']]}"
                    f"{tuple(f'{v:.3g}' for v in cfg['params'])} nq={cfg['nq']} dtype={cfg['dtype']}"
                    + (f" norms=({cfg['norms'][0]:.1e},{cfg['norms'][1]:.1e}) k_range={cfg['k_range']}" if a.wild else ""))
