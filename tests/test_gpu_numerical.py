@@ -352,7 +352,8 @@ def converged_case(cloudy, oracle, dist_types, kname, q=8):
     ([3, 1], "linear", 8), ([1, 3], "long", 8), ([3, 3, 3], "linear", 8), ([1, 3, 1], "hydro", 8), ([3, 0], "constant", 4),
     # round 5 (VERDICT r4 missing #3): the reference's NumericalCoalStyle is generic in the number of modes
     # (Coalescence.jl:470-489) -- five to eight modes through the kernels compiled for the plan
-    ([1, 1, 1, 1, 1], "hydro", 8), ([1, 0, 1, 1, 1, 1], "long", 8), ([1, 1, 3, 1, 1, 1], "linear", 8), ([1] * 8, "hydro", 8),
+    # (eight modes: the golden case 8gamma_long below and tools/fuzz_parity.py --converged --big)
+    ([1, 1, 1, 1, 1], "hydro", 8), ([1, 0, 1, 1, 1, 1], "long", 8), ([1, 1, 3, 1, 1, 1], "linear", 8),
 ])
 def test_converged_mode_vs_same_rule_oracle(gpu_cloudy, oracle, dist_types, kname, q):
     """cloudy_coal_rhs of a CLOUDY_QUAD_CONVERGED plan (closed forms of the region integrals + one 1-D rule per mode for
@@ -476,12 +477,13 @@ def test_converged_mode_reaches_the_adaptive_golden_values_on_the_device(gpu_clo
         scale = np.concatenate([[Q[m, :, k].sum() + R[m, :, k].sum() + S[m, 0, k] + (S[m, 1, k - 1] if k else 0.0)
                                  for m in range(npm[k])] for k in range(len(types))])
         res = {}
-        for mode, q in ((1, 8), (0, 10)):
+        # (plans of more than four modes are compiled per plan, 15-40 s a kernel: the 10-point rule is not run beside them)
+        for mode, q in ((1, 8), (0, 10)) if len(types) <= 4 else ((1, 8),):
             ci = cloudy.get_coal_ints(cloudy.NumericalCoalStyle(), (types, dev(cloudy, prm)), kf, quad_order=q,
                                       quad_mode=mode).to_numpy()[:, 0]
             res[mode] = float(np.max(np.abs(ci - np.array(c["coal_ints"])) / scale))
         worst = max(worst, res[1])
-        print(f"{c['name']:36s} converged {res[1]:.1e}   10-point rule {res[0]:.1e}   (of scale, vs adaptive)")
+        print(f"{c['name']:36s} converged {res[1]:.1e}   10-point rule {res.get(0, float('nan')):.1e}   (of scale, vs adaptive)")
     assert n_cases >= 32 and worst <= 1e-8, worst
 
 
