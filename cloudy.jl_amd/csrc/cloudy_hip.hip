@@ -1008,14 +1008,50 @@ int cloudy_rainshaft_ssprk33_steps(const cloudy_plan *plan, size_t nz, size_t n_
         // kernel keeps a column inside one workgroup (<= 1024 cells).  Taller columns are stepped stage by stage on the stream:
         // cloudy_rainshaft_rhs (cell sources + flux divergence: two launches) and one update launch per stage, with three
         // stream-ordered scratch arrays of the state's size (allocated and released on the caller's stream per call).
+        //
+        // Experiment switch CLOUDY_HIP_GRAPH=1 (round 5, measured SLOWER on ROCm 7.2 and therefore off): from the second step on
+        // ONE step -- nine launches -- is captured into a hipGraph and replayed.  The first step runs eagerly (it builds whatever
+        // the plan still has to compile; nothing may be compiled or loaded during a capture), the second is recorded on a stream
+        // of this call (the caller's stream may be the legacy NULL stream, which cannot capture) ordered after the caller's
+        // stream by an event and before it by another.  Same bits (test_tall_columns_replay_a_captured_step); per step of
+        // 3 x 1500 / 64 x 1500 / 256 x 4000 cells: eager 0.143 / 0.128 / 0.52 ms, replayed 0.158 / 0.162 / 0.84 ms, plus 3-5 ms
+        // of capture and instantiation per call (tools/time_tall_columns.py, profiles/r05_tall_columns_graph_experiment.txt):
+        // the eager launches already queue back to back on the stream, and the graph's kernel nodes do not run closer together.
         DeviceGuard guard(plan->h.device);
         if (guard.err != hipSuccess) return fail_hip(guard.err, "selecting the plan's device");
-        hipStream_t st = (hipStream_t)stream;
+        hipStream_t user = (hipStream_t)stream, st = user;
         const size_t esz = plan->h.dtype != CLOUDY_F64 ? sizeof(float) : sizeof(double);
         const size_t bytes = (size_t)plan->h.nmom * ld * esz;
-        if (u_out_dev != u_in_dev) HIP_TRY(hipMemcpyAsync(u_out_dev, u_in_dev, bytes, hipMemcpyDeviceToDevice, st));
+        bool graph_on = false;
+        if (const char *e = std::getenv("CLOUDY_HIP_GRAPH")) graph_on = n_steps >= 4 && e[0] == '1';
+        if (graph_on) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(user, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) graph_on = false;
+            (void)hipGetLastError();
+        }
+        hipStream_t own = nullptr;
+        hipEvent_t ev_in = nullptr, ev_out = nullptr;
+        if (graph_on) {
+            graph_on = hipStreamCreateWithFlags(&own, hipStreamNonBlocking) == hipSuccess &&
+                       hipEventCreateWithFlags(&ev_in, hipEventDisableTiming) == hipSuccess &&
+                       hipEventCreateWithFlags(&ev_out, hipEventDisableTiming) == hipSuccess &&
+                       hipEventRecord(ev_in, user) == hipSuccess && hipStreamWaitEvent(own, ev_in, 0) == hipSuccess;
+            if (graph_on) st = own;
+            else (void)hipGetLastError();
+        }
+        const auto release = [&] {
+            if (ev_in) (void)hipEventDestroy(ev_in);
+            if (ev_out) (void)hipEventDestroy(ev_out);
+            if (own) (void)hipStreamDestroy(own);   // (returns at once; the stream goes when its work is done)
+        };
+        hipError_t e = hipSuccess;
+        if (u_out_dev != u_in_dev) e = hipMemcpyAsync(u_out_dev, u_in_dev, bytes, hipMemcpyDeviceToDevice, st);
         char *ws = nullptr;
-        HIP_TRY(hipMallocAsync((void **)&ws, 3 * bytes, st));
+        if (e == hipSuccess) e = hipMallocAsync((void **)&ws, 3 * bytes, st);
+        if (e != hipSuccess) {
+            release();
+            return fail_hip(e, "scratch of the stage-by-stage column integrator");
+        }
         void *up = ws, *f = ws + bytes, *flux = ws + 2 * bytes;
         const unsigned g = (unsigned)((n + kBlock - 1) / kBlock);
         const int planes = plan->h.nmom;
@@ -1029,16 +1065,45 @@ int cloudy_rainshaft_ssprk33_steps(const cloudy_plan *plan, size_t nz, size_t n_
             return hipGetLastError();
         };
         rc = CLOUDY_OK;
-        hipError_t e = hipSuccess;
-        for (int step = 0; step < n_steps && rc == CLOUDY_OK && e == hipSuccess; ++step)
+        const auto one_step = [&] {
             for (int sidx = 0; sidx < 3 && rc == CLOUDY_OK && e == hipSuccess; ++sidx) {
-                rc = cloudy_rainshaft_rhs(plan, nz, n_columns, ld, u_out_dev, dz, flux, f, stream);
+                rc = cloudy_rainshaft_rhs(plan, nz, n_columns, ld, u_out_dev, dz, flux, f, st);
                 if (rc == CLOUDY_OK) e = stage(sidx);
             }
+        };
+        int step = 0;
+        if (n_steps > 0) {
+            one_step();
+            ++step;
+        }
+        if (graph_on && rc == CLOUDY_OK && e == hipSuccess) {
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                one_step();   // recorded, not run
+                const hipError_t ec = hipStreamEndCapture(st, &graph);
+                const bool recorded = rc == CLOUDY_OK && e == hipSuccess && ec == hipSuccess && graph != nullptr;
+                rc = CLOUDY_OK;   // (a failure while recording leaves nothing half done: the eager loop below takes over)
+                e = hipSuccess;
+                if (recorded && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                    for (; step < n_steps && e == hipSuccess; ++step) e = hipGraphLaunch(exec, st);
+                    (void)hipGraphExecDestroy(exec);
+                }
+                if (graph) (void)hipGraphDestroy(graph);
+            }
+            (void)hipGetLastError();
+        }
+        for (; step < n_steps && rc == CLOUDY_OK && e == hipSuccess; ++step) one_step();
         if (rc == CLOUDY_OK && e == hipSuccess && n_steps > 0) e = stage(3);
         (void)hipFreeAsync(ws, st);
+        if (own != nullptr) {   // the caller's stream goes on after this call's work
+            hipError_t eo = hipEventRecord(ev_out, own);
+            if (eo == hipSuccess) eo = hipStreamWaitEvent(user, ev_out, 0);
+            if (eo != hipSuccess && e == hipSuccess) e = eo;
+        }
+        release();
         if (rc != CLOUDY_OK) return rc;
-        if (e != hipSuccess) return fail_hip(e, "column stage update launch");
+        if (e != hipSuccess) return fail_hip(e, "stage-by-stage column integrator");
         return CLOUDY_OK;
     }
     LaunchReq r{OP_RAINSHAFT_SSPRK33, IN_MOMENTS, 1, 1, n, ld, u_in_dev, u_out_dev, nullptr, (hipStream_t)stream};

@@ -1461,6 +1461,47 @@ def test_workgroup_size_of_the_column_integrator_changes_no_bit(gpu_cloudy, monk
     monkeypatch.delenv("CLOUDY_HIP_RS_BLOCK", raising=False)
 
 
+def test_tall_columns_replay_a_captured_step(gpu_cloudy, monkeypatch):
+    """Columns of more than 1024 cells are stepped stage by stage inside the library (nine launches per step).  Experiment
+    switch CLOUDY_HIP_GRAPH=1 (round 5; measured slower than the eager loop on ROCm 7.2, so off by default): from the second
+    step on ONE step is captured into a hipGraph and replayed.  Same bits as the eager loop, on the legacy NULL stream and on
+    a stream of the caller, out of place and in place; the caller's stream is ordered after the call's own stream (the result
+    is complete when the caller's stream has drained)."""
+    import ctypes
+    import time
+
+    cloudy = gpu_cloudy
+    L = cloudy.lib()
+    nz, ncol, n_steps = 1500, 3, 12
+    n = nz * ncol
+    wl = bench.make_workload("cfg3b", n, seed=31)
+    plan = wl["coal_data"].plan(wl["dist_types"], vel=((50.0, 1.0 / 6),))
+    hip = ctypes.CDLL("libamdhip64.so")
+    user = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(user)) == 0
+    res, ms = {}, {}
+    for tag, graph, stream in (("eager", "0", None), ("graph", "1", None), ("graph_user_stream", "1", user), ("eager_user_stream", "0", user)):
+        monkeypatch.setenv("CLOUDY_HIP_GRAPH", graph)
+        u = cloudy.DeviceArray.from_numpy(wl["mom"])
+        out = cloudy.DeviceArray.zeros(*wl["mom"].shape)
+        for rep in range(2):   # (the second call is timed: kernels compiled, caches warm)
+            t0 = time.perf_counter()
+            cloudy._lib.check(L.cloudy_rainshaft_ssprk33_steps(plan.handle, nz, ncol, n, u.ptr, out.ptr, 150.0, 1e-3, n_steps, stream))
+            cloudy._lib.check(L.cloudy_stream_synchronize(stream))
+            ms[tag] = (time.perf_counter() - t0) * 1e3
+        res[tag] = out.to_numpy()
+        assert np.isfinite(res[tag]).mean() > 0.9 and not np.array_equal(res[tag], wl["mom"])   # (the batch holds degenerate cells, and a NaN travels down its column)
+    for tag in ("graph", "graph_user_stream", "eager_user_stream"):
+        assert np.array_equal(res[tag], res["eager"], equal_nan=True), tag
+    monkeypatch.setenv("CLOUDY_HIP_GRAPH", "1")
+    u = cloudy.DeviceArray.from_numpy(wl["mom"])
+    cloudy._lib.check(L.cloudy_rainshaft_ssprk33_steps(plan.handle, nz, ncol, n, u.ptr, u.ptr, 150.0, 1e-3, n_steps, None))   # in place
+    assert np.array_equal(u.to_numpy(), res["eager"], equal_nan=True)
+    monkeypatch.delenv("CLOUDY_HIP_GRAPH", raising=False)
+    assert hip.hipStreamDestroy(user) == 0
+    print(f"{ncol} columns x {nz} cells, {n_steps} steps: eager {ms['eager']:.2f} ms, captured step replayed {ms['graph']:.2f} ms")
+
+
 def _rhs_with_plan(cloudy, plan, mom, dtype=np.float64):
     m = cloudy.DeviceArray.from_numpy(mom.astype(dtype))
     dm = cloudy.DeviceArray.zeros(mom.shape[0], mom.shape[1], dtype)
