@@ -1302,6 +1302,20 @@ def main():
         rl = _valu_roofline(measured, "rainshaft_ssprk33_columns", nz * ncol, msr)   # flops per cell per CALL (6 evaluations)
         if rl:
             variants["rainshaft_ssprk33_columns"]["roofline"] = rl
+        # ONE evaluation of the same right-hand side outside the fused integrator -- make_rainshaft_rhs(...)'s rhs!(dm, m, par, t),
+        # the drop-in boundary of the rainshaft drivers (rainshaft_helpers.jl:45-89): cell kernel + flux-divergence launch
+        fluxr = pkg.DeviceArray.zeros(nmom, nz * ncol)
+
+        def _col_rhs():
+            pkg._lib.check(L.cloudy_rainshaft_rhs(planr.handle, nz, ncol, nz * ncol, ur.ptr, 150.0, fluxr.ptr, outr.ptr, None))
+
+        msu = _sustained_ms(pkg, _col_rhs, min_reps=3)
+        variants["rainshaft_rhs_unfused"] = {
+            "workload": f"cloudy_rainshaft_rhs on the same batch: one RHS evaluation (cell sources + flux divergence, two launches), fp64; "
+                        f"the fused integrator above spends {msr / (3 * nst):.3f} ms per evaluation, update included",
+            "value": nz * ncol * world / (msu * 1e-3), "unit": "cell-RHS/s", "ms_per_call": msu,
+        }
+        del fluxr
         z = (np.arange(nz) + 0.5) * 150.0
         at = ((z >= 0.5 * z.max() - 75.0) & (z < 0.75 * z.max() - 75.0)).astype(float)
         kg = np.array([[2.220446049250313e-16 / 1e6, 5.0], [5.0, 0.0]])   # CoalescenceTensor(LinearKernelFunction(5), 1)
