@@ -1303,16 +1303,17 @@ def main():
         if rl:
             variants["rainshaft_ssprk33_columns"]["roofline"] = rl
         # ONE evaluation of the same right-hand side outside the fused integrator -- make_rainshaft_rhs(...)'s rhs!(dm, m, par, t),
-        # the drop-in boundary of the rainshaft drivers (rainshaft_helpers.jl:45-89): cell kernel + flux-divergence launch
+        # the drop-in boundary of the rainshaft drivers (rainshaft_helpers.jl:45-89): since round 5 one launch of the column body
+        # without the update (before: cell kernel + flux-divergence launch, 2.9 GB of HBM traffic per 1e7 cells instead of 1.45)
         fluxr = pkg.DeviceArray.zeros(nmom, nz * ncol)
 
         def _col_rhs():
             pkg._lib.check(L.cloudy_rainshaft_rhs(planr.handle, nz, ncol, nz * ncol, ur.ptr, 150.0, fluxr.ptr, outr.ptr, None))
 
         msu = _sustained_ms(pkg, _col_rhs, min_reps=3)
-        variants["rainshaft_rhs_unfused"] = {
-            "workload": f"cloudy_rainshaft_rhs on the same batch: one RHS evaluation (cell sources + flux divergence, two launches), fp64; "
-                        f"the fused integrator above spends {msr / (3 * nst):.3f} ms per evaluation, update included",
+        variants["rainshaft_rhs"] = {
+            "workload": f"cloudy_rainshaft_rhs on the same batch: ONE evaluation of the column right-hand side in one launch (cell sources, "
+                        f"fluxes, divergence), fp64; the fused integrator above spends {msr / (3 * nst):.3f} ms per evaluation, update included",
             "value": nz * ncol * world / (msu * 1e-3), "unit": "cell-RHS/s", "ms_per_call": msu,
         }
         del fluxr

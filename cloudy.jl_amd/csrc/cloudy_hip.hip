@@ -37,6 +37,7 @@ struct cloudy_plan {
     mutable hipFunction_t int_ssprk33 = nullptr, rs_coal = nullptr, rs_int = nullptr, int_tsit5 = nullptr;
     mutable hipFunction_t rs_int512 = nullptr, rs_int1024 = nullptr;  // the column integrator for 256 < nz <= 512 / 1024
     mutable hipFunction_t rs_int320 = nullptr;                        // ... with 320-thread workgroups (jit_rainshaft_part)
+    mutable hipFunction_t rs_rhs = nullptr, rs_rhs512 = nullptr, rs_rhs1024 = nullptr;  // one RHS evaluation, same modules
     // one log per once-flag (a single string written from seven independent call_once lambdas raced when two host
     // threads made first calls to different entry points of one plan, and a later successful compile overwrote the log an
     // earlier failure's message refers to); each is written once, inside its call_once, and read only after it
@@ -317,11 +318,11 @@ int run(const cloudy_plan *plan, const LaunchReq &r) {
         }
         if (part == 8) {
         } else if (part == 3)
-            std::call_once(plan->rsint_once, [&] { (void)jit_get_rainshaft_integrator(plan->h, plan->rs_int, plan->rsint_log); });
+            std::call_once(plan->rsint_once, [&] { (void)jit_get_rainshaft_integrator(plan->h, plan->rs_int, plan->rsint_log, 3, &plan->rs_rhs); });
         else if (part == 5)
-            std::call_once(plan->rsint512_once, [&] { (void)jit_get_rainshaft_integrator(plan->h, plan->rs_int512, plan->rsint512_log, 5); });
+            std::call_once(plan->rsint512_once, [&] { (void)jit_get_rainshaft_integrator(plan->h, plan->rs_int512, plan->rsint512_log, 5, &plan->rs_rhs512); });
         else
-            std::call_once(plan->rsint1024_once, [&] { (void)jit_get_rainshaft_integrator(plan->h, plan->rs_int1024, plan->rsint1024_log, 6); });
+            std::call_once(plan->rsint1024_once, [&] { (void)jit_get_rainshaft_integrator(plan->h, plan->rs_int1024, plan->rsint1024_log, 6, &plan->rs_rhs1024); });
         hipFunction_t fn = part == 3 ? plan->rs_int : part == 5 ? plan->rs_int512 : part == 8 ? plan->rs_int320 : plan->rs_int1024;
         use_jit = fn != nullptr && plan->h.mode != MODE_MOVING;  // otherwise the ahead-of-time integrator (nz <= 256)
     }
@@ -977,6 +978,37 @@ int cloudy_rainshaft_rhs(const cloudy_plan *plan, size_t nz, size_t n_columns, s
     int rc = check_batch(plan, n, ld, mom_dev, rhs_dev);
     if (rc) return rc;
     if (nz < 1 || !(dz > 0)) return fail(CLOUDY_EINVAL, "nz must be >= 1 and dz positive");
+    // Round 5: one launch when the plan has the column kernels compiled for it and a workgroup holds a column (nz <= 1024):
+    // the RHS_ONLY instance of the column integrator's body -- sources, flux, exchange through LDS, divergence, sum -- writes
+    // rhs and the cell fluxes; fp64 planes: the same bits as the two launches below (test).  CLOUDY_HIP_RS_FUSED_RHS=0: off.
+    if (n > 0 && nz <= 1024 && flux_work_dev != nullptr && plan->jit_on && plan->h.coal_style != CLOUDY_NUMERICAL_COAL &&
+        plan->h.n_vel > 0 && plan->h.mode != MODE_MOVING) {
+        const char *fe = std::getenv("CLOUDY_HIP_RS_FUSED_RHS");
+        if (!(fe && fe[0] == '0')) {
+            DeviceGuard guard(plan->h.device);
+            if (guard.err != hipSuccess) return fail_hip(guard.err, "selecting the plan's device");
+            int part = jit_rainshaft_part(nz, n_columns);
+            if (part == 8) part = 3;
+            if (part == 3)
+                std::call_once(plan->rsint_once, [&] { (void)jit_get_rainshaft_integrator(plan->h, plan->rs_int, plan->rsint_log, 3, &plan->rs_rhs); });
+            else if (part == 5)
+                std::call_once(plan->rsint512_once, [&] { (void)jit_get_rainshaft_integrator(plan->h, plan->rs_int512, plan->rsint512_log, 5, &plan->rs_rhs512); });
+            else
+                std::call_once(plan->rsint1024_once, [&] { (void)jit_get_rainshaft_integrator(plan->h, plan->rs_int1024, plan->rsint1024_log, 6, &plan->rs_rhs1024); });
+            hipFunction_t fn = part == 3 ? plan->rs_rhs : part == 5 ? plan->rs_rhs512 : plan->rs_rhs1024;
+            if (fn != nullptr) {
+                const double *nodes = plan->h.nodes_dev;
+                int nzi = (int)nz;
+                const unsigned bs = (unsigned)jit_rainshaft_block(part);
+                const size_t cpb = bs / nz;
+                void *args[] = {&nodes, &nzi, &n_columns, &ld, &mom_dev, &rhs_dev, &flux_work_dev, &dz};
+                hipError_t e = hipModuleLaunchKernel(fn, (unsigned)((n_columns + cpb - 1) / cpb), 1, 1, bs, 1, 1, 0, (hipStream_t)stream,
+                                                     args, nullptr);
+                if (e != hipSuccess) return fail_hip(e, "column right-hand side launch");
+                return CLOUDY_OK;
+            }
+        }
+    }
     rc = cloudy_rainshaft_sources(plan, n, ld, mom_dev, rhs_dev, flux_work_dev, stream);
     if (rc || n == 0) return rc;
     DeviceGuard guard(plan->h.device);

@@ -1613,11 +1613,15 @@ __global__ void __launch_bounds__(kBlock)
 // BS: workgroup size = cells per workgroup (floor(BS / nz) whole columns).  The ahead-of-time kernel has 256 threads; the
 // kernel compiled for the plan exists with 256, 512 and 1024 threads, and jit_rainshaft_part() picks by column height (512 for
 // the reference's 20 cells: round 5; taller columns than 1024 cells are stepped stage by stage, cloudy_hip.hip).
-template <int N, int P, int MODE, typename TIO, bool SPEC = false, int BS = kRainshaftBlock>
+// RHS_ONLY (round 5): ONE evaluation of the column right-hand side -- make_rainshaft_rhs(...)'s rhs!(dm, m, par, t), the drop-in
+// boundary of the rainshaft drivers -- in one launch: u_out receives coal_source .+ sedi_source of the (clamped) state, flux_out
+// the cell fluxes.  The same stage as the integrator's without the update and without anything parked (cloudy_rainshaft_rhs
+// otherwise runs the cell kernel and a divergence launch: 2.9 GB of HBM traffic per 1e7 cells instead of 1.4).
+template <int N, int P, int MODE, typename TIO, bool SPEC = false, int BS = kRainshaftBlock, bool RHS_ONLY = false>
 __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__restrict__ Ag, const SediArgs *__restrict__ Sg,
                                                        const double *__restrict__ nodes, int nz, size_t n_columns,
                                                        size_t ld, const TIO *u_in, TIO *u_out, double dt, double dz,
-                                                       int n_steps) {
+                                                       int n_steps, TIO *flux_out = nullptr) {
     // (workgroup sizes that were measured and dropped, 20-cell columns: 384 threads 40 % slower, 320 threads 40 % slower --
     // six- and five-wave workgroups do not spread evenly over four SIMDs; 128 threads 8 % slower, the ranking over 128 cells
     // is too coarse)
@@ -1631,12 +1635,13 @@ __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__rest
     // itself in stage 1 (for stage 2); (iii) w waits in sh_flux, as many rows of u_prev as fit at 16 waves per CU in sh_up
     // (4 of 6 for N = 2), the empty-cell flag in a byte; (iv) the lane's place in its column is re-derived, not kept; (v) the
     // lane's own flux is read back from the exchange rows after the barrier (kept, it was the last thing the allocator spilled).
-    constexpr bool kPark = (MODE != MODE_ALLINF);
+    constexpr bool kPark = (MODE != MODE_ALLINF);   // (also decides the re-derivation of the lane's place after the passes)
+    constexpr bool kParkState = kPark && !RHS_ONLY;
     constexpr int kRowBytes = BS * 8;
     constexpr int kLdsUsed = (3 * N + 3 * N + 3 * (N > 1 ? N - 1 : 1)) * kRowBytes + BS * 6;  // flux, sh_par, sh_T, cnt, perm
     constexpr int kLdsBudget = 40960 * (BS / 256);  // 160 KB per CU, 16 waves: 4 / 2 / 1 workgroups of 256 / 512 / 1024 threads
     constexpr int kLdsFreeRows = (kLdsBudget - kLdsUsed) / kRowBytes;
-    constexpr int NUP = !kPark ? 0 : kLdsFreeRows < 0 ? 0 : kLdsFreeRows > 3 * N ? 3 * N : kLdsFreeRows;
+    constexpr int NUP = !kParkState ? 0 : kLdsFreeRows < 0 ? 0 : kLdsFreeRows > 3 * N ? 3 * N : kLdsFreeRows;
     __shared__ double sh_up[NUP > 0 ? NUP : 1][BS];
     __shared__ unsigned char sh_small[kPark ? BS : 1];  // the empty-cell flag of the stage (:67-72) waits here as well
     const KArgs<N, P> &A = *Ag;
@@ -1656,10 +1661,11 @@ __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__rest
             u[m][q] = (active && q < A.np[m]) ? (double)u_in[(size_t)(A.off[m] + q) * ld + i] : 0.0;
             up[m][q] = 0.0;
         }
+    const int n_steps_run = RHS_ONLY ? 1 : n_steps;
 #pragma unroll 1
-    for (int step = 0; step < n_steps; ++step) {
+    for (int step = 0; step < n_steps_run; ++step) {
 #pragma unroll 1
-        for (int stage = 0; stage < 3; ++stage) {
+        for (int stage = 0; stage < (RHS_ONLY ? 1 : 3); ++stage) {
             // The plan constants are re-derived through opaque zero offsets (see ssprk33_kernel), three times per stage: the
             // closure inversion sees the norms, the coalescence integrals the tensors, the sedimentation flux the velocity
             // block -- otherwise all of them are live in SGPRs at once and spill into VGPR lanes.
@@ -1682,7 +1688,7 @@ __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__rest
                     if (stage == 0) up[m][q] = u[m][q];
                     w[m][q] = stage == 0 ? u[m][q] : stage == 1 ? 3.0 * up[m][q] + u[m][q] : up[m][q] + 2.0 * u[m][q];
                 }
-            if (kPark) {
+            if (kParkState) {
 #pragma unroll
                 for (int r = 0; r < 3 * N; ++r) {
                     sh_flux[r][ps] = w[r / 3][r % 3];
@@ -1738,7 +1744,7 @@ __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__rest
                         fx[3 * m + q][pp] = (q < Af.np[m]) ? fl[m][q] * Af.out_scale[3 * m + q] : 0.0;
             }
             CLOUDY_STAGE_BARRIER();
-            if (kPark) {
+            if (kParkState) {
 #pragma unroll
                 for (int r = 0; r < 3 * N; ++r) {
                     w[r / 3][r % 3] = sh_flux[r][pp];
@@ -1759,9 +1765,21 @@ __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__rest
                         const double fd = -(f_up - fx[3 * m + q][pp]) / dz;  // :83-85
                         // coal_source .+ sedi_source (:88), empty cells skip coalescence (:67-72)
                         const double ft = ((q < Af.np[m] && !small2) ? acc[m][q] * Af.out_scale[3 * m + q] : 0.0) + fd;
-                        const double r = w[m][q] + c * ft;  // u_prev + dt f | 3 u_prev + u + dt f | u_prev + 2 u + 2 dt f
-                        u[m][q] = stage == 0 ? r : stage == 1 ? r * 0.25 : div_by_const(r, 3.0, 1.0 / 3.0);
+                        if (RHS_ONLY) {
+                            u[m][q] = ft;
+                        } else {
+                            const double r = w[m][q] + c * ft;  // u_prev + dt f | 3 u_prev + u + dt f | u_prev + 2 u + 2 dt f
+                            u[m][q] = stage == 0 ? r : stage == 1 ? r * 0.25 : div_by_const(r, 3.0, 1.0 / 3.0);
+                        }
                     }
+                if (RHS_ONLY && flux_out != nullptr) {   // cloudy_rainshaft_rhs's flux_work_dev: the cell fluxes
+                    const size_t ie2 = ((size_t)blockIdx.x * cpb + cl2) * (size_t)nz + iz2;
+#pragma unroll
+                    for (int m = 0; m < N; ++m)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+                            if (q < Af.np[m]) flux_out[(size_t)(Af.off[m] + q) * ld + ie2] = (TIO)fx[3 * m + q][pp];
+                }
             }
             CLOUDY_STAGE_BARRIER();
         }
@@ -1777,7 +1795,7 @@ __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__rest
 #pragma unroll
             for (int q = 0; q < 3; ++q)
                 if (q < A.np[m]) {
-                    const double v = (n_steps > 0 && u[m][q] < 0.0) ? 0.0 : u[m][q];  // the FSAL evaluation's clamp
+                    const double v = (!RHS_ONLY && n_steps > 0 && u[m][q] < 0.0) ? 0.0 : u[m][q];  // the FSAL evaluation's clamp
                     u_out[(size_t)(A.off[m] + q) * ld + ie] = (TIO)v;
                 }
     }

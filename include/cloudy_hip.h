@@ -312,7 +312,9 @@ int cloudy_rainshaft_sources(const cloudy_plan *plan, size_t n_cells, size_t ld,
 /* the full right-hand side of make_rainshaft_rhs (rainshaft_helpers.jl:45-89) for n_columns columns of nz cells
  * (cell index fastest, bottom to top): coalescence source + upwind divergence of the sedimentation flux,
  * rhs[i] = coal[i] - (flux[i+1] - flux[i]) / dz with zero flux above the top cell.  flux_work_dev: nmom planes of
- * scratch (holds the cell fluxes on return). */
+ * scratch (holds the cell fluxes on return).  One launch for columns of up to 1024 cells when the plan's kernels are compiled
+ * for it (a workgroup holds whole columns, the flux of the cell above travels through LDS), the cell kernel and a divergence
+ * launch otherwise; the same bits on fp64 planes (float planes: the one launch does not round the fluxes in between). */
 int cloudy_rainshaft_rhs(const cloudy_plan *plan, size_t nz, size_t n_columns, size_t ld, const void *mom_dev, double dz,
                          void *flux_work_dev, void *rhs_dev, void *stream);
 

@@ -1461,6 +1461,60 @@ def test_workgroup_size_of_the_column_integrator_changes_no_bit(gpu_cloudy, monk
     monkeypatch.delenv("CLOUDY_HIP_RS_BLOCK", raising=False)
 
 
+def test_column_rhs_in_one_launch_matches_the_two_launch_path(gpu_cloudy, monkeypatch):
+    """Round 5: cloudy_rainshaft_rhs -- make_rainshaft_rhs(...)'s rhs!, the drop-in boundary of the rainshaft drivers -- runs
+    the RHS_ONLY instance of the column integrator's body when the plan has its kernels compiled for it and a workgroup holds a
+    column: ONE launch (sources, fluxes, exchange through LDS, divergence) instead of the cell kernel + the divergence launch.
+    fp64 planes: the same bits, rhs and fluxes, for every workgroup size; float planes: the one launch keeps fp64 between the
+    source and the divergence where the two launches round the fluxes to float in between."""
+    cloudy = gpu_cloudy
+    L = cloudy.lib()
+    for name, nz, ncol, dtype in (("cfg3b", 20, 131, np.float64), ("cfg3b", 100, 9, np.float64), ("cfg3a", 20, 57, np.float64),
+                                  ("cfg4", 33, 21, np.float64), ("cfg3b", 700, 3, np.float64), ("cfg3b", 20, 64, np.float32)):
+        n = nz * ncol
+        wl = bench.make_workload(name, n, seed=37)
+        code = 0 if dtype == np.float64 else 1
+        plan = wl["coal_data"].plan(wl["dist_types"], vel=((50.0, 1.0 / 6),), dtype=code)
+        mom = wl["mom"].astype(dtype)
+        mom[:, 5] = -np.abs(mom[:, 5]) * 1e-20          # negative round-off is clamped inside, the input stays as it is
+        u = cloudy.DeviceArray.from_numpy(mom)
+        res = {}
+        for tag, fused, block in (("two", "0", None), ("one", "1", None), ("one256", "1", "256"), ("one1024", "1", "1024")):
+            monkeypatch.setenv("CLOUDY_HIP_RS_FUSED_RHS", fused)
+            if block is None:
+                monkeypatch.delenv("CLOUDY_HIP_RS_BLOCK", raising=False)
+            elif nz > int(block):
+                continue
+            else:
+                monkeypatch.setenv("CLOUDY_HIP_RS_BLOCK", block)
+            rhs = cloudy.DeviceArray.zeros(mom.shape[0], n, dtype)
+            flux = cloudy.DeviceArray.zeros(mom.shape[0], n, dtype)
+            cloudy._lib.check(L.cloudy_rainshaft_rhs(plan.handle, nz, ncol, n, u.ptr, 150.0, flux.ptr, rhs.ptr, None))
+            res[tag] = (rhs.to_numpy(), flux.to_numpy())
+            assert np.array_equal(u.to_numpy(), mom, equal_nan=True)
+        for tag in res:
+            if tag == "two":
+                continue
+            if dtype == np.float64:
+                assert np.array_equal(res[tag][0], res["two"][0], equal_nan=True), (name, nz, tag, "rhs")
+                assert np.array_equal(res[tag][1], res["two"][1], equal_nan=True), (name, nz, tag, "flux")
+            else:
+                # rhs = coal + divergence is a difference of large terms: the scale of the rounding is |coal| + |fluxes| / dz
+                coal = cloudy.DeviceArray.zeros(mom.shape[0], n, dtype)
+                fl2 = cloudy.DeviceArray.zeros(mom.shape[0], n, dtype)
+                cloudy._lib.check(L.cloudy_rainshaft_sources(plan.handle, n, n, u.ptr, coal.ptr, fl2.ptr, None))
+                fl = np.abs(res["two"][1]).astype(np.float64)
+                fup = np.concatenate([fl[:, 1:], np.zeros((fl.shape[0], 1))], axis=1)
+                ref = np.abs(coal.to_numpy()).astype(np.float64) + (fl + fup) / 150.0
+                ok = np.isfinite(res["two"][0]) & np.isfinite(ref)
+                assert np.array_equal(res[tag][1], res["two"][1], equal_nan=True)
+                err = np.abs(res[tag][0].astype(np.float64) - res["two"][0].astype(np.float64))
+                assert np.all(err[ok] <= 2.5e-7 * ref[ok] + 1e-38), (name, nz, tag, float(np.max(err[ok] / (ref[ok] + 1e-300))))
+        assert np.isfinite(res["one"][0]).mean() > 0.9 and np.abs(res["one"][0][np.isfinite(res["one"][0])]).max() > 0.0
+    monkeypatch.delenv("CLOUDY_HIP_RS_BLOCK", raising=False)
+    monkeypatch.delenv("CLOUDY_HIP_RS_FUSED_RHS", raising=False)
+
+
 def test_tall_columns_replay_a_captured_step(gpu_cloudy, monkeypatch):
     """Columns of more than 1024 cells are stepped stage by stage inside the library (nine launches per step).  Experiment
     switch CLOUDY_HIP_GRAPH=1 (round 5; measured slower than the eager loop on ROCm 7.2, so off by default): from the second

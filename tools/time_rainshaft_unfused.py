@@ -1,5 +1,5 @@
-"""the unfused column RHS (cloudy_rainshaft_rhs: one launch of the cell body + the divergence launch) on the batch of
-tools/time_rainshaft_block.py: what one evaluation costs outside the fused integrator (PMC: tools/pmc_one.sh)"""
+"""the column RHS (cloudy_rainshaft_rhs) on the batch of tools/time_rainshaft_block.py: what one evaluation costs outside the fused
+integrator -- one launch (round 5), or with CLOUDY_HIP_RS_FUSED_RHS=0 the cell kernel + the divergence launch (PMC: tools/pmc_one.sh)"""
 import sys, os, ctypes as C, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, bench
@@ -17,4 +17,4 @@ pkg._lib.check(L.cloudy_stream_synchronize(None))
 t0 = time.perf_counter()
 for _ in range(10): run()
 pkg._lib.check(L.cloudy_stream_synchronize(None))
-print("unfused rhs: ms per evaluation of 1e7 cells", (time.perf_counter() - t0) / 10 * 1e3)
+print("cloudy_rainshaft_rhs, CLOUDY_HIP_RS_FUSED_RHS =", os.environ.get("CLOUDY_HIP_RS_FUSED_RHS", "1"), ": ms per evaluation of 1e7 cells", (time.perf_counter() - t0) / 10 * 1e3)
