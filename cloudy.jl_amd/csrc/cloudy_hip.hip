@@ -753,7 +753,10 @@ int cloudy_jit_selfcheck(const cloudy_plan_desc *d, const char *arch) {
     if (ok && !numerical && p->h.mode != MODE_ALLINF) ok = jit_compile(jit_source(p->h, 1), a, true, code, log);
     if (ok && !numerical) ok = jit_compile(jit_source(p->h, 2), a, false, code, log);  // rainshaft cell body
     if (ok && !numerical && p->h.n_vel > 0 && p->h.mode != MODE_MOVING)
-        ok = jit_compile(jit_source(p->h, 3), a, true, code, log);                     // fused column integrator
+    {
+        const char *l = std::getenv("CLOUDY_HIP_JIT_RS_LICM");  // (the experiment switch of jit_get_rainshaft_integrator)
+        ok = jit_compile(jit_source(p->h, 3), a, !(l && l[0] == '1'), code, log);      // fused column integrator + column RHS
+    }
     if (ok && p->h.dtype != CLOUDY_F32_FAST) ok = jit_compile(jit_source(p->h, 4), a, true, code, log);  // cloudy_tsit5_steps
     if (ok && plan_beyond_aot(p->h)) ok = jit_compile(jit_source(p->h, 7), a, false, code, log);  // diagnostics
     delete p;

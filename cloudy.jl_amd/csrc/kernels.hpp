@@ -1645,6 +1645,9 @@ __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__rest
     __shared__ double sh_up[NUP > 0 ? NUP : 1][BS];
     __shared__ unsigned char sh_small[kPark ? BS : 1];  // the empty-cell flag of the stage (:67-72) waits here as well
     const KArgs<N, P> &A = *Ag;
+#ifdef CLOUDY_RS_NZ_CONST   // (timing experiment only: what the divisions by a run-time column height cost)
+    nz = CLOUDY_RS_NZ_CONST;
+#endif
     const int cpb = BS / nz;       // whole columns per workgroup
     const int pos = threadIdx.x;   // cell slot of the workgroup this lane integrates: column pos / nz, level pos % nz
     // (With a finite threshold the Simpson passes of every stage run on cells re-ranked on that stage's state, per
@@ -1762,7 +1765,11 @@ __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__rest
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
                         const double f_up = top ? 0.0 : fx[3 * m + q][pp + 1];
+#ifdef CLOUDY_RS_MUL_RDZ     // (timing experiment only, not the reference's bits: what the IEEE divisions by dz cost)
+                        const double fd = -(f_up - fx[3 * m + q][pp]) * (1.0 / dz);
+#else
                         const double fd = -(f_up - fx[3 * m + q][pp]) / dz;  // :83-85
+#endif
                         // coal_source .+ sedi_source (:88), empty cells skip coalescence (:67-72)
                         const double ft = ((q < Af.np[m] && !small2) ? acc[m][q] * Af.out_scale[3 * m + q] : 0.0) + fd;
                         if (RHS_ONLY) {
