@@ -133,8 +133,10 @@ def check_callers(pkg, cfg, cd, op, mom, plan, k_range, scale):
         ok = np.isfinite(w)
         if t == 3:  # Lognormal: log / sqrt of the device and the host library differ in the last place, and
             # sigma^2 = log(M0 M2 / M1^2) is ill-conditioned for narrow distributions: compare where sigma > 0.05
+            # (mu = ln(M1^2 / sqrt(M0^3 M2)) is the logarithm of a number of order one: an ABSOLUTE accuracy of a few ulps of
+            # one -- a parcel whose mu happens to be -9e-6 in the plan's units showed 7e-11 RELATIVE, seed 32 --wild #14)
             wide = ok & (w[2] > 0.05)[None, :]
-            assert np.allclose(g[wide], w[wide], rtol=1e-11, atol=1e-300), f"update_dist_from_moments (Lognormal) mode {i}"
+            assert np.allclose(g[wide], w[wide], rtol=1e-11, atol=1e-14), f"update_dist_from_moments (Lognormal) mode {i}"
         else:
             assert np.array_equal(g[ok], w[ok]), f"update_dist_from_moments differs for mode {i}"
     # parcels for the time-stepping checks: closures away from the k clamps (at a clamp one rounding of a stage value
