@@ -76,7 +76,11 @@ CASES = [
     # a NARROW Lognormal mode below a Gamma mode that sits at ~2 e^mu: the inner integrand of its T_m (over ln(x / y)) is a
     # Gaussian ~sqrt(2) sigma wide on the boundary t = 0 (round 4, ADVICE r3: 12 equal inner panels were off by 6e-7 at sigma = 0.01)
     dict(name="narrow_lognormal_gamma_constant", kf=(0, [0.7]), pdists=[(3, 2.0, -1.0, 0.01), (1, 1.0, 0.9, 2.0)], mp=True),
-    dict(name="narrow_lognormal_gamma_hydro", kf=(2, [3.14]), pdists=[(3, 2.0, -1.0, 0.005), (1, 1.0, 0.9, 2.0)], mp=True),
+    # (no mp mark, round 5: mpmath's 3.2-hour recomputation of this case agrees to 1.5e-13 on Q and 7.5e-15 on S but is 1.2e-8 off on ONE
+    # R entry -- the kink of |x^(2/3) - y^(2/3)| on the diagonal lies inside the 0.5 % wide peak, between tanh-sinh break points;
+    # oracle/check_narrow_lognormal_R.py, a composite Gauss-Legendre rule split ON the diagonal, agrees with the adaptive values of
+    # every such R entry to <= 3e-13)
+    dict(name="narrow_lognormal_gamma_hydro", kf=(2, [3.14]), pdists=[(3, 2.0, -1.0, 0.005), (1, 1.0, 0.9, 2.0)]),
     dict(name="narrow_lognormal_gamma_long", kf=(3, [0.5, 2.0, 1.0]), pdists=[(3, 2.0, -1.0, 0.02), (1, 1.0, 0.9, 2.0)], mp=True),
     # four modes (box_gamma_mixture_4modes.jl has four; NumericalCoalStyle plans take up to four), and two identical modes
     dict(name="4gamma_hydrodynamic", kf=(2, [3.14e-3]), pdists=[(1, 100.0, 0.02, 2.0), (1, 10.0, 0.5, 3.0), (1, 1.0, 8.0, 2.5), (1, 0.05, 100.0, 4.0)]),

@@ -122,7 +122,7 @@ def _golden_scale(c):
                             for m in range(npm[k])] for k in range(len(npm))])
 
 
-MPMATH_CHECKED_MIN = 25   # (27 marked in oracle/numerical_adaptive.py; narrow_lognormal_gamma_hydro and 5gamma_hydrodynamic take more than 2.5 h each: as they finish)
+MPMATH_CHECKED_MIN = 25   # (26 marked in oracle/numerical_adaptive.py: 5gamma_hydrodynamic takes more than 3.5 h; narrow_lognormal_gamma_hydro: see oracle/check_narrow_lognormal_R.py)
 
 
 def test_golden_set_is_what_the_verdict_asked_for():
