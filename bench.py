@@ -150,33 +150,128 @@ def oracle_params(name):
 
 
 # ------------------------------------------------------------------------------------------------
+RANK_DONE_MARK = "bench.py rank done"     # last stderr line of a rank that ran to the end (see _spawn_ranks)
+EXIT_RANK_FAILED, EXIT_FEWER_DEVICES, EXIT_LAUNCH_TIMEOUT = 5, 4, 6
+
+
+def _rank_log_dir():
+    d = os.environ.get("CLOUDY_BENCH_LOG_DIR") or os.path.join(ROOT, "bench_rank_logs")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def _tail(path, n=12):
+    try:
+        with open(path, errors="replace") as f:
+            return [l.rstrip("\n") for l in f.readlines()[-n:]]
+    except OSError:
+        return []
+
+
 def _spawn_ranks(n_gpus, argv):
     """`python bench.py --gpus N` with N > 1 and no launcher (WORLD_SIZE unset): this parent -- which never touches the
     GPU, never imports torch and never loads libcloudy_hip.so -- starts N fresh child processes of this script, one rank
-    per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would), waits for them and relays
-    rank 0's JSON line.  Non-zero exit if any rank fails."""
+    per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would) and relays rank 0's JSON line.
+
+    VERDICT r5 item 1: the parent POLLS all children.  The first rank that exits non-zero -- or exits 0 without having
+    written the end-of-run mark, i.e. before the last barrier -- ends the run: the siblings (blocked in a collective that
+    will never complete) are terminated, and the parent exits non-zero with ONE line naming the rank, its exit code and
+    its last stderr lines.  Every rank has its own `rank<k>.out` / `rank<k>.err` under CLOUDY_BENCH_LOG_DIR (default
+    bench_rank_logs/); a wall-clock limit (CLOUDY_BENCH_LAUNCH_TIMEOUT, default 1500 s: inside the driver's 1800 s) covers a
+    rank that hangs without dying.  No re-exec anywhere: children are fresh processes."""
     import socket
     import subprocess
 
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
+    logs = _rank_log_dir()
+    limit = float(os.environ.get("CLOUDY_BENCH_LAUNCH_TIMEOUT", "1500"))
+    procs, files = [], []
     for r in range(n_gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CLOUDY_BENCH_SPAWNED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [q.wait() for q in procs[1:]]
-    sys.stdout.write(out0 or "")
+        fo = open(os.path.join(logs, f"rank{r}.out"), "w")
+        fe = open(os.path.join(logs, f"rank{r}.err"), "w")
+        files += [fo, fe]
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=fo, stderr=fe,
+                                      start_new_session=True))
+    t0 = time.monotonic()
+    reason, code = None, 0
+    live = set(range(n_gpus))
+    while live and reason is None:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            err_tail = _tail(os.path.join(logs, f"rank{r}.err"))
+            if rc != 0:
+                why = next((l for l in reversed(err_tail) if l.strip() and l.strip() != RANK_DONE_MARK), "(no stderr output)")
+                reason, code = f"rank {r} exited with code {rc}: {why.strip()[:300]}", (rc if rc in (3, EXIT_FEWER_DEVICES) else EXIT_RANK_FAILED)
+                break
+            if RANK_DONE_MARK not in err_tail:
+                reason, code = (f"rank {r} exited with code 0 before the end of the run (no '{RANK_DONE_MARK}' line in "
+                                f"{logs}/rank{r}.err)"), EXIT_RANK_FAILED
+                break
+        if reason is None and live:
+            if time.monotonic() - t0 > limit:
+                reason, code = (f"ranks {sorted(live)} still running after {limit:.0f} s (CLOUDY_BENCH_LAUNCH_TIMEOUT); "
+                                f"terminated"), EXIT_LAUNCH_TIMEOUT
+                break
+            time.sleep(0.1)
+    if reason is not None:
+        import signal
+
+        for r in sorted(live):                      # the siblings: blocked in a collective that will never complete
+            try:
+                os.killpg(procs[r].pid, signal.SIGTERM)
+            except (ProcessLookupError, PermissionError):
+                pass
+        t1 = time.monotonic()
+        for r in sorted(live):
+            try:
+                procs[r].wait(timeout=max(0.1, 5.0 - (time.monotonic() - t1)))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(procs[r].pid, signal.SIGKILL)
+                except (ProcessLookupError, PermissionError):
+                    pass
+                procs[r].wait()
+    for f in files:
+        f.close()
+    # rank 0's stderr (the full result object) and stdout (the line) are relayed; the other ranks' logs stay in their files
+    sys.stderr.write("".join(l + "\n" for l in _tail(os.path.join(logs, "rank0.err"), 400) if l.strip() != RANK_DONE_MARK))
+    if reason is not None:
+        sys.stderr.write(f"bench.py --gpus {n_gpus}: FAILED: {reason} (per-rank logs: {logs}/rank<k>.err)\n")
+        sys.stderr.flush()
+        raise SystemExit(code or EXIT_RANK_FAILED)
+    with open(os.path.join(logs, "rank0.out")) as f:
+        sys.stdout.write(f.read())
     sys.stdout.flush()
-    if any(codes):
-        raise SystemExit(f"bench.py --gpus {n_gpus}: rank exit codes {codes}")
+    return 0
 
 
 _COMM = {"comm": None, "collective": None, "own_gpu_per_rank": True, "fallback": False}
+
+
+def _fault(point, rank):
+    """Failure injection for the launcher tests (tests/test_sharding.py): CLOUDY_BENCH_FAULT="<what>@<point>:<rank>", what in
+    {raise, exit0, hang}, point in {after_init, before_barrier}.  Never set outside the tests."""
+    spec = os.environ.get("CLOUDY_BENCH_FAULT", "")
+    if not spec:
+        return
+    what, _, where = spec.partition("@")
+    pt, _, rk = where.partition(":")
+    if pt != point or int(rk or -1) != rank:
+        return
+    if what == "raise":
+        raise RuntimeError(f"injected failure on rank {rank} at {point} (CLOUDY_BENCH_FAULT)")
+    if what == "exit0":
+        os._exit(0)
+    if what == "hang":
+        time.sleep(10_000)
 
 
 def _dist_setup(n_gpus):
@@ -184,29 +279,84 @@ def _dist_setup(n_gpus):
     courier of the 128-byte RCCL id); -> (rank, world, local_rank, dist or None, torch or None).
     VERDICT r4 item 5 (ii): the control group is gloo (CPU tensors over MASTER_ADDR:MASTER_PORT) so that each rank opens
     exactly ONE RCCL communicator -- the one inside libcloudy_hip.so that carries the path's only collective
-    (cloudy_moment_sums_allreduce).  CLOUDY_BENCH_BACKEND=nccl restores torch's own RCCL group as the courier."""
+    (cloudy_moment_sums_allreduce).  CLOUDY_BENCH_BACKEND=nccl restores torch's own RCCL group as the courier.
+    VERDICT r5 item 1: every collective of the control plane has a timeout (CLOUDY_BENCH_DIST_TIMEOUT, default 300 s; a dead
+    peer is then an error on the survivors, not torch's 30 minutes), and FEWER VISIBLE DEVICES THAN LOCAL RANKS IS AN ERROR
+    (exit code 4) unless CLOUDY_BENCH_ALLOW_SHARED_GPU=1 (the 1-GPU test boxes): ranks are never mapped onto a shared GPU
+    silently -- that would print a 1x "scaling curve" with exit code 0."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world == 1:
         return 0, 1, 0, None, None
+    import datetime
+
     import torch  # imported BEFORE libcloudy_hip.so so that both share one HIP runtime (same SONAME)
     import torch.distributed as dist
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     backend = os.environ.get("CLOUDY_BENCH_BACKEND", "gloo")
-    n_dev = max(torch.cuda.device_count(), 1)      # (counting devices does not initialise the GPU)
-    _COMM["own_gpu_per_rank"] = int(os.environ.get("LOCAL_WORLD_SIZE", world)) <= n_dev
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    n_vis = torch.cuda.device_count()               # (counting devices does not initialise the GPU)
+    dry = os.environ.get("CLOUDY_BENCH_DRY_CONTROL_PLANE") == "1"
+    if n_vis < local_world and not dry:
+        if os.environ.get("CLOUDY_BENCH_ALLOW_SHARED_GPU") != "1":
+            sys.stderr.write(f"bench.py rank {rank}: {n_vis} HIP device(s) visible for {local_world} local rank(s): one GPU per "
+                             "rank is required (CLOUDY_BENCH_ALLOW_SHARED_GPU=1 lets ranks share devices on a test box)\n")
+            sys.stderr.flush()
+            raise SystemExit(EXIT_FEWER_DEVICES)
+        if n_vis < 1:
+            raise SystemExit("bench.py needs a HIP device: the coalescence RHS has no CPU fallback")
+    n_dev = max(n_vis, 1)
+    _COMM["own_gpu_per_rank"] = local_world <= n_dev
+    timeout = datetime.timedelta(seconds=float(os.environ.get("CLOUDY_BENCH_DIST_TIMEOUT", "300")))
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, timeout=timeout,
                                 device_id=torch.device("cuda", local_rank))
     else:
-        local_rank = local_rank % n_dev             # a 1-GPU test box: all ranks share GPU 0
-        torch.cuda.set_device(local_rank)           # (torch.cuda.synchronize() of the timing bracket looks at this device)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        local_rank = local_rank % n_dev             # only with CLOUDY_BENCH_ALLOW_SHARED_GPU=1 is this ever a wrap-around
+        if not dry:
+            torch.cuda.set_device(local_rank)       # (torch.cuda.synchronize() of the timing bracket looks at this device)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
+    _fault("after_init", rank)
     return rank, world, local_rank, dist, torch
+
+
+def _dry_control_plane(args, rank, world, dist, torch, json_out):
+    """CLOUDY_BENCH_DRY_CONTROL_PLANE=1 (launcher tests on a box without a GPU): the control plane of a multi-rank run and
+    nothing else -- rendezvous, the barrier + max-over-ranks bracket around K stub steps, the gather of the per-rank
+    records, the final barrier, rank 0's line -- with NO GPU work; the line says so ("data": "dry-run ...", value null) and
+    is not a measurement."""
+    _fault("before_barrier", rank)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    recs = _gather_objects({"rank": rank, "pid": os.getpid(), "device": None, "pci_bus_id": None, "kernel_ms": None}, dist)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        out = {"metric": "parcel moment-RHS evals/sec at 1e7 parcels; achieved HBM GB/s vs 8 TB/s peak", "value": None,
+               "unit": "parcel-RHS/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": 1e3 * float(t.item()) / max(args.steps, 1), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f64", "data": "dry-run of the control plane: NO GPU work, not a measurement",
+               "config": {"workload": "none (CLOUDY_BENCH_DRY_CONTROL_PLANE=1)"}, "per_rank_devices": recs}
+        emit(out, json_out, side_file=False)     # (a dry run never overwrites a measured bench_variants.json)
+    return 0
+
+
+def _gather_objects(obj, dist):
+    """[obj of rank 0, obj of rank 1, ...] on every rank (small JSON-able records; gloo or nccl control group)."""
+    if dist is None:
+        return [obj]
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, obj)
+    return parts
 
 
 def _comm_setup(pkg, world, local_rank, dist, torch):
@@ -911,9 +1061,15 @@ def compact_line(full, variants_file=VARIANTS_FILE):
     }
     if "launch" in cfg:
         line["config"]["launch"] = _clip(cfg["launch"], 120)
+    prd = full.get("per_rank_devices")
+    if prd and (full.get("n_gpus") or 1) > 1:   # a SCALE record shows which devices the ranks ran on (rank order)
+        line["devices"] = [_clip(d.get("pci_bus_id"), 16) if d.get("pci_bus_id") else None for d in prd]
+        line["distinct_devices"] = full.get("distinct_devices")
+        if full.get("ranks_share_a_gpu"):
+            line["ranks_share_a_gpu"] = True
     text = json.dumps(line, allow_nan=False, separators=(",", ":"))
     # a last guard: drop the optional parts, widest first, rather than print a line the driver cannot parse
-    for drop in ("process_wall_s", "variants"):
+    for drop in ("process_wall_s", "devices", "variants"):
         if len(text) <= LINE_LIMIT:
             break
         line.pop(drop, None)
@@ -923,10 +1079,10 @@ def compact_line(full, variants_file=VARIANTS_FILE):
     return text
 
 
-def emit(full, json_out):
+def emit(full, json_out, side_file=True):
     """full object -> side file + stderr; the compact line -> the real stdout, last."""
     full = _finite(full)
-    path = os.path.join(ROOT, VARIANTS_FILE)
+    path = os.path.join(ROOT, VARIANTS_FILE) if side_file else os.devnull
     try:
         with open(path, "w") as f:
             json.dump(full, f, indent=1, allow_nan=False)
@@ -1052,12 +1208,17 @@ def main():
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
     rank, world, local_rank, dist, torch = _dist_setup(args.gpus)
+    if dist is not None and os.environ.get("CLOUDY_BENCH_DRY_CONTROL_PLANE") == "1":
+        rc = _dry_control_plane(args, rank, world, dist, torch, json_out)
+        _rank_done()
+        return rc
     import __graft_entry__ as ge
 
     pkg = ge.load_package()
     if pkg.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the coalescence RHS has no CPU fallback")
     pkg._lib.check(pkg.lib().cloudy_set_device(local_rank))
+    _fault("before_barrier", rank)
     _comm_setup(pkg, world, local_rank, dist, torch)
 
     spec = workload_spec(args.workload)
@@ -1070,6 +1231,14 @@ def main():
     value = total * args.steps / res["wall"]
     achieved = bytes_per_eval * n_local / (res["event_ms"] * 1e-3) / 1e9
     per_rank_ms = _gather(res["event_ms"], dist, torch)   # every rank's HIP-event average of its own launches
+    # which device each rank ran on -- a SCALE record must show N distinct devices
+    import ctypes as _C
+
+    _bus = _C.create_string_buffer(64)
+    _rc = pkg.lib().cloudy_device_pci_bus_id(local_rank, _bus, 64)
+    per_rank_dev = _gather_objects({"rank": rank, "pid": os.getpid(), "device": local_rank,
+                                    "pci_bus_id": _bus.value.decode() if _rc == 0 else None,
+                                    "kernel_ms": res["event_ms"]}, dist)
 
     measured = _measured_latest()
     traffic = None
@@ -1407,6 +1576,9 @@ def main():
             "roofline": _headline_roofline(args.workload, res["plan"], n_local, nmom, res["event_ms"], per_rank_ms,
                                            traffic, measured),
             "cpu_baseline": cpu,
+            "per_rank_devices": per_rank_dev,
+            "ranks_share_a_gpu": not _COMM["own_gpu_per_rank"],
+            "distinct_devices": len({d.get("pci_bus_id") for d in per_rank_dev if d.get("pci_bus_id")}),
             "collective": _COMM["collective"],
             "collective_fallback": bool(_COMM["fallback"]),
             "mass_rate_residual": abs(res["mass_rate_sum"]) / max(res["mass_rate_gross"], 1e-300),
@@ -1423,8 +1595,35 @@ def main():
             sys.stderr.write("bench.py rank 0: RCCL communicator set-up hung; the line carries collective_fallback = true; exit 3\n")
             sys.stderr.flush()
             os._exit(3)   # (as the other ranks above: a thread is still inside ncclCommInitRank)
+    _rank_done()
     return 0
 
 
+def _rank_done():
+    """the end-of-run mark _spawn_ranks looks for: a rank that exits 0 without it left before the last barrier"""
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        sys.stderr.write(RANK_DONE_MARK + "\n")
+        sys.stderr.flush()
+
+
+def _main_guarded():
+    """main() with ONE line of reason on stderr when a rank dies of an exception (a failed control-plane collective after a
+    peer's death included), and an exit that does not wait on torch.distributed's destructors."""
+    try:
+        return main() or 0
+    except SystemExit:
+        raise
+    except BaseException as e:   # noqa: BLE001
+        import traceback
+
+        traceback.print_exc()
+        msg = (str(e).strip().splitlines() or [""])[0]
+        sys.stderr.write(f"bench.py rank {os.environ.get('RANK', '0')}: FAILED: {type(e).__name__}: {msg[:300]}\n")
+        sys.stderr.flush()
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            os._exit(EXIT_RANK_FAILED)
+        return EXIT_RANK_FAILED
+
+
 if __name__ == "__main__":
-    sys.exit(main() or 0)
+    sys.exit(_main_guarded())

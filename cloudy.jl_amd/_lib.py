@@ -97,6 +97,7 @@ SYMBOLS = {
     "cloudy_moment_sums_allreduce": (_i, [_vp, _vp, _sz, _sz, _i, _vp, _vp, _vp]),
     "cloudy_device_count": (_i, []),
     "cloudy_set_device": (_i, [_i]),
+    "cloudy_device_pci_bus_id": (_i, [_i, C.c_char_p, _i]),
     "cloudy_malloc": (_i, [C.POINTER(_vp), _sz]),
     "cloudy_free": (_i, [_vp]),
     "cloudy_memcpy_h2d": (_i, [_vp, _vp, _sz, _vp]),

@@ -1268,6 +1268,15 @@ int cloudy_set_device(int device) {
     HIP_TRY(hipSetDevice(device));
     return CLOUDY_OK;
 }
+int cloudy_device_pci_bus_id(int device, char *buf, int len) {
+    if (!buf || len < 13) return fail(CLOUDY_EINVAL, "buf is NULL or shorter than 13 bytes (\"0000:00:00.0\")");
+    buf[0] = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return fail(CLOUDY_ENODEVICE, "no HIP device");
+    if (device < 0 || device >= n) return fail(CLOUDY_EINVAL, "device ordinal out of range");
+    HIP_TRY(hipDeviceGetPCIBusId(buf, len, device));
+    return CLOUDY_OK;
+}
 int cloudy_malloc(void **dev_ptr, size_t bytes) {
     if (!dev_ptr) return fail(CLOUDY_EINVAL, "dev_ptr is NULL");
     HIP_TRY(hipMalloc(dev_ptr, bytes));

@@ -379,6 +379,9 @@ int cloudy_moment_sums_allreduce(const cloudy_plan *plan, cloudy_comm *comm, siz
 /* thin device-memory helpers so that a host without a HIP binding can keep state device-resident */
 int cloudy_device_count(void);
 int cloudy_set_device(int device);
+/* "dddd:bb:dd.f" of a device ordinal (hipDeviceGetPCIBusId), len >= 13: bench.py --gpus N records it per rank so that a
+ * scaling record shows N distinct devices */
+int cloudy_device_pci_bus_id(int device, char *buf, int len);
 int cloudy_malloc(void **dev_ptr, size_t bytes);
 int cloudy_free(void *dev_ptr);
 int cloudy_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream);

@@ -3,6 +3,7 @@ import os
 import subprocess
 import sys
 import textwrap
+import time
 
 import numpy as np
 import pytest
@@ -121,15 +122,100 @@ def test_bench_gpus_flag_rejects_mismatched_launch():
     assert p.returncode != 0 and "WORLD_SIZE=3" in (p.stderr + p.stdout)
 
 
+def _bench_dry(tmp_path, n, fault, extra_env=None, launcher="spawn", port=29641):
+    """`bench.py --gpus n` with the control plane only (no GPU here) and one injected failure; -> (CompletedProcess, seconds)"""
+    env = dict(os.environ, CLOUDY_BENCH_DRY_CONTROL_PLANE="1", CLOUDY_BENCH_LOG_DIR=str(tmp_path), OMP_NUM_THREADS="1",
+               CLOUDY_BENCH_FAULT=fault, **(extra_env or {}))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    bench = [os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1"]
+    if launcher == "spawn":
+        cmd = [sys.executable] + bench
+    else:   # the driver's launch line
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + bench
+    t0 = time.monotonic()
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=170)
+    return p, time.monotonic() - t0
+
+
+def test_launcher_control_plane_runs_clean_without_faults(tmp_path):
+    """the dry control plane itself (rendezvous, barriers, max over ranks, gather of the per-rank records, rank 0's line) at
+    world size 3 through the parent's own spawner: exit 0, one strict-JSON line that says it is NOT a measurement, a log
+    pair per rank with the end-of-run mark"""
+    import json
+
+    p, dt = _bench_dry(tmp_path, 3, "")
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads(p.stdout.splitlines()[-1])
+    assert out["n_gpus"] == 3 and out["value"] is None and "dry-run" in out["data"] and len(out["devices"]) == 3
+    for r in range(3):
+        assert "bench.py rank done" in (tmp_path / f"rank{r}.err").read_text()
+
+
+@pytest.mark.parametrize("fault, expect", [
+    ("raise@after_init:1", "rank 1 exited with code 5"),          # a rank that raises before the first barrier
+    ("raise@before_barrier:2", "rank 2 exited with code 5"),
+    ("exit0@before_barrier:1", "rank 1 exited with code 0 before the end of the run"),   # a rank that exits 0 early
+])
+def test_launcher_ends_the_run_when_a_rank_dies(tmp_path, fault, expect):
+    """`bench.py --gpus 3` (the parent's own spawner) with one rank that dies while its siblings
+    sit in a collective that will never complete: the parent notices within its polling interval, terminates the siblings
+    and exits NON-ZERO with one line naming the rank and the reason -- not after torch's 30-minute collective timeout."""
+    p, dt = _bench_dry(tmp_path, 3, fault)
+    assert p.returncode != 0 and dt < 60, (p.returncode, dt, p.stderr[-2000:])
+    last = [l for l in p.stderr.splitlines() if "FAILED" in l][-1]
+    assert expect in last and "rank<k>.err" in last, last
+    if fault.startswith("raise"):
+        assert "injected failure" in last
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]     # no line from a failed run
+    # nobody is left behind: every child of the parent has been reaped (its process group is gone)
+    assert (tmp_path / "rank0.err").exists() and (tmp_path / "rank2.err").exists()
+
+
+def test_launcher_wall_clock_limit_ends_a_hung_rank(tmp_path):
+    """a rank that neither dies nor arrives: the parent's wall-clock limit (CLOUDY_BENCH_LAUNCH_TIMEOUT) ends the run"""
+    p, dt = _bench_dry(tmp_path, 2, "hang@before_barrier:1", {"CLOUDY_BENCH_LAUNCH_TIMEOUT": "12"})
+    assert p.returncode == 6 and dt < 60, (p.returncode, dt, p.stderr[-2000:])
+    assert "still running after 12 s" in p.stderr
+
+
+@pytest.mark.parametrize("fault", ["raise@before_barrier:1", "exit0@before_barrier:1", "hang@before_barrier:1"])
+def test_driver_launch_line_survives_a_dead_or_hung_rank(tmp_path, fault):
+    """the same three failures under the DRIVER's launcher (`python -m torch.distributed.run ... bench.py --gpus 2`): the
+    surviving rank's control-plane collective fails -- at once when the peer's sockets close, after
+    CLOUDY_BENCH_DIST_TIMEOUT (default 300 s, 15 s here) when the peer hangs -- with a one-line reason, non-zero exit"""
+    p, dt = _bench_dry(tmp_path, 2, fault, {"CLOUDY_BENCH_DIST_TIMEOUT": "15"}, launcher="torchrun",
+                       port=29643 + len(fault) % 7)
+    assert p.returncode != 0 and dt < 60, (p.returncode, dt, p.stderr[-2000:])
+    assert "bench.py rank" in p.stderr and "FAILED" in p.stderr or "injected failure" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_fewer_devices_than_ranks_is_an_error(tmp_path, cloudy):
+    """ranks are never mapped onto a shared GPU silently.  Here: no device at all for 2 ranks."""
+    if cloudy.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 HIP devices")
+    env = dict(os.environ, CLOUDY_BENCH_LOG_DIR=str(tmp_path), OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "CLOUDY_BENCH_ALLOW_SHARED_GPU"):
+        env.pop(k, None)
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=170)
+    assert p.returncode == 4 and time.monotonic() - t0 < 60, (p.returncode, p.stderr[-2000:])
+    assert "HIP device(s) visible for 2 local rank(s)" in p.stderr and "FAILED" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
 @pytest.mark.gpu
-def test_bench_gpus_2_spawns_two_ranks(gpu_cloudy):
+def test_bench_gpus_2_spawns_two_ranks(gpu_cloudy, tmp_path):
     """`python bench.py --gpus 2` without a launcher: the parent starts two ranks (before touching the GPU), rank 0's
     JSON line reports n_gpus = 2, a per-rank roofline entry for each rank and the all-reduced mass residual.  On the
     1-GPU test box both ranks share GPU 0 and rendezvous over gloo (CLOUDY_BENCH_BACKEND); the driver's multi-GPU runs
     use nccl (= RCCL) with one GPU per rank."""
     import json
 
-    env = dict(os.environ, CLOUDY_BENCH_BACKEND="gloo")
+    env = dict(os.environ, CLOUDY_BENCH_BACKEND="gloo", CLOUDY_BENCH_ALLOW_SHARED_GPU="1", CLOUDY_BENCH_LOG_DIR=str(tmp_path))
     env.pop("WORLD_SIZE", None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--parcels", "400000", "--steps", "5",
                         "--warmup", "2", "--no-variants", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
@@ -143,6 +229,18 @@ def test_bench_gpus_2_spawns_two_ranks(gpu_cloudy):
     assert out["mass_rate_residual"] is not None and out["value"] > 0
     # both ranks share the one GPU of the test box: no RCCL communicator can be formed, and the line says so
     assert out["collective_fallback"] is True and "share one GPU" in out["collective"]
+    # which device every rank ran on (one PCI bus id here, shared; N distinct ones on a real node)
+    assert out["ranks_share_a_gpu"] is True and out["distinct_devices"] == 1
+    assert len(out["devices"]) == 2 and out["devices"][0] == out["devices"][1] and ":" in out["devices"][0]
+    assert os.path.exists(tmp_path / "rank1.err") and "bench.py rank done" in (tmp_path / "rank1.err").read_text()
+    # ... and without the opt-in, ranks that would share a GPU are an ERROR (exit code 4), not a 1x "scaling curve"
+    env.pop("CLOUDY_BENCH_ALLOW_SHARED_GPU")
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--parcels", "1000", "--steps", "1",
+                        "--warmup", "1", "--no-variants", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode == 4 and "1 HIP device(s) visible for 2 local rank(s)" in p.stderr, p.stderr[-2000:]
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")] and time.monotonic() - t0 < 60
 
 
 @pytest.mark.gpu
@@ -154,7 +252,8 @@ def test_bench_gpus_8_on_one_gpu_with_an_empty_jit_cache(gpu_cloudy, tmp_path):
 
     cache = tmp_path / "jit_cache"
     cache.mkdir()
-    env = dict(os.environ, CLOUDY_BENCH_BACKEND="gloo", CLOUDY_HIP_CACHE_DIR=str(cache))
+    env = dict(os.environ, CLOUDY_BENCH_BACKEND="gloo", CLOUDY_HIP_CACHE_DIR=str(cache), CLOUDY_BENCH_ALLOW_SHARED_GPU="1",
+               CLOUDY_BENCH_LOG_DIR=str(tmp_path / "logs"))
     env.pop("WORLD_SIZE", None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--parcels", "200000", "--steps", "3",
                         "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=1500)
