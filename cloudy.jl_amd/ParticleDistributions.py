@@ -111,6 +111,47 @@ def update_dist_from_moments(plan, mom, params_out=None, stream=None):
     return out
 
 
+def check_moment_consistency(m):
+    """check_moment_consistency(m) (ParticleDistributions.jl:437-449) for ONE tuple of moments, on the host: raises ValueError where
+    the reference raises (a negative moment; a negative even-ordered central moment), returns None otherwise (IEEE division as in
+    Julia: (0, 1, 2) gives Inf - Inf = NaN, which is not < 0).  The batched form is closure_stats."""
+    import math
+
+    import numpy as np
+
+    m = np.asarray(m, dtype=np.float64)
+    if (m < 0.0).any():
+        raise ValueError("all moments need to be nonnegative.")
+    with np.errstate(all="ignore"):
+        for order in range(2, len(m), 2):
+            cm = np.float64(0.0)
+            for i in range(order + 1):
+                cm = cm + (math.comb(order, i) * (-1) ** i) * (m[1] / m[0]) ** i * (m[order - i] / m[0])
+            if cm < 0.0:
+                raise ValueError("order central moment needs to be nonnegative.")
+    return None
+
+
+CLOSURE_STATS_FIELDS = ("fallback", "k_min", "k_max", "inconsistent")
+
+
+def closure_stats(plan, mom, stream=None):
+    """Batched validity diagnostic (cloudy_closure_stats): per mode, how many parcels of `mom` (nmom, n; device; physical units)
+    took the fallback distribution (0, 1, 1), have their shape at the lower / upper clamp, or fail check_moment_consistency.
+    -> (N, 4) integer array, columns CLOSURE_STATS_FIELDS.  The reference clamps silently and checks one tuple at a time
+    (ParticleDistributions.jl:437-449, 456-541)."""
+    import ctypes as C
+
+    import numpy as np
+
+    ptr, planes, n, ld = as_device(mom)
+    if planes != plan.nmom:
+        raise TypeError(f"closure_stats: expected {plan.nmom} moments, got {planes}")
+    buf = (C.c_uint64 * (4 * plan.N))()
+    _lib.check(_lib.lib().cloudy_closure_stats(plan.handle, n, ld, ptr, buf, stream))
+    return np.array(buf[:], dtype=np.int64).reshape(plan.N, 4)
+
+
 def compute_thresholds(plan, params, out=None, stream=None):
     """Per-parcel thresholds used by the S terms (ParticleDistributions.jl:734-761); (N, n) device array."""
     ptr, planes, n, ld = as_device(params)

@@ -18,7 +18,8 @@ from .KernelFunctions import (ConstantKernelFunction, HydrodynamicKernelFunction
 from .KernelTensors import CoalescenceTensor, check_symmetry, get_normalized_kernel_tensor, polyfit
 from .ParticleDistributions import (ExponentialPrimitiveParticleDistribution, GammaPrimitiveParticleDistribution,
                                     LognormalPrimitiveParticleDistribution, MonodispersePrimitiveParticleDistribution,
-                                    compute_thresholds, get_moments, get_standard_N_q, nparams, pack_params, update_dist_from_moments)
+                                    compute_thresholds, get_moments, get_standard_N_q, nparams, pack_params, update_dist_from_moments,
+                                    check_moment_consistency, closure_stats, CLOSURE_STATS_FIELDS)
 from .Coalescence import (CoalescenceData, NumericalPlan, Plan, get_coal_ints, get_finite_2d_integrals,
                           kernel_func_code, numerical_plan, QUAD_CONVERGED, QUAD_FIXED, F64, F32, F32_FAST,
                           F64_RELAXED)

@@ -72,6 +72,7 @@ SYMBOLS = {
     "cloudy_ssprk33_steps": (_i, [_vp, _sz, _sz, _vp, _vp, C.c_double, _i, _vp]),
     "cloudy_tsit5_steps": (_i, [_vp, _sz, _sz, _vp, _vp, C.c_double, _i, _vp]),
     "cloudy_update_dist_from_moments": (_i, [_vp, _sz, _sz, _vp, _vp, _vp]),
+    "cloudy_closure_stats": (_i, [_vp, _sz, _sz, _vp, C.POINTER(C.c_uint64), _vp]),
     "cloudy_finite_2d_integrals": (_i, [_vp, _sz, _sz, _vp, _vp, _vp]),
     "cloudy_compute_thresholds": (_i, [_vp, _sz, _sz, _vp, _vp, _vp]),
     "cloudy_sedimentation_flux": (_i, [_vp, _sz, _sz, _vp, _vp, _vp]),

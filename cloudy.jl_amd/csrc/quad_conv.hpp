@@ -927,6 +927,10 @@ __device__ __forceinline__ void conv_T_lognormal_poly(const QArgs &Q, double n, 
 // -- inside the loop: 328 registers and the set-up executed, masked, in almost every trip: slower.)  The arithmetic of
 // every rule is that of conv_adaptive<3, 3, false> with the node function below: results are bit-identical to running
 // the rules one after the other.
+template <int V>
+struct ConvInt {
+    static constexpr int value = V;
+};
 template <int NM>
 struct ConvRule {
     bool valid;
@@ -942,6 +946,98 @@ struct ConvRule {
     double mc[NM], mw[NM];         // the other modes' cores (ln mean size, width)
     int mI[NM];
 };
+
+// Everything the walk needs of the rule of mode j, prepared before the loop in straight-line code every lane runs through
+// together.  sc: the Long kernel's output scales (the caller has the self-pair closed forms they come from).  The same function
+// prepares the rules of phase 1 (on the lane that owns the parcel) and, for a Long plan whose holes are walked by another lane
+// (conv_coal_ints_long_split), those of phase 2 again from (n, theta, k) -- so the two agree to the bit whichever lane runs them.
+template <int N, int KIND>
+__device__ __forceinline__ void conv_rule_prepare(const QArgs &Q, int j, bool lnj, double nj, double kj, double thj, double lnthj,
+                                                  double lgkj, const double (&cm)[N], const double (&wm)[N],
+                                                  const ConvLogDensity (&lg)[N], const double (&sc)[3],
+                                                  ConvRule<(N > 1 ? N - 1 : 1)> &r) {
+    constexpr int NM = N > 1 ? N - 1 : 1;
+    constexpr double gam = KIND == KF_LINEAR ? 1.0 : KIND == KF_HYDRODYNAMIC ? 4.0 / 3.0 : 0.0;
+    r.valid = !lnj && nj > 0.0;
+    r.A = r.lgA = r.th = 1.0;
+    r.lnth = r.tlo = r.thi = r.kj = r.lgB = r.rB = r.gl = 0.0;
+    r.ex1 = r.ex2 = INFINITY;
+    r.c0 = 0.0;
+    r.sc[0] = r.sc[1] = r.sc[2] = 1.0;
+    r.tmode = r.lwmode = 0.0;
+    r.convex = false;
+#pragma unroll
+    for (int sl = 0; sl < NM; ++sl) {
+        r.ltlo[sl] = 0.0;
+        r.mc[sl] = 0.0;
+        r.mw[sl] = 1.0;
+        r.mI[sl] = 0;
+    }
+    if (lnj) return;  // (wave-uniform: the closure family of a mode is a plan constant)
+    const double Ash = fma(2.0, kj, gam);  // homogeneous kernels: T_m = 1/2 s0 E_{Gamma(2k + gamma)}[s^m (1 - w)]
+    r.A = Ash;
+    r.lgA = lgamma_pos(Ash);
+    r.th = thj;
+    r.lnth = lnthj;
+    conv_range(Ash, 2.0, r.lgA, r.tlo, r.thi);
+    // marks: the other modes' cores; Long: s = x_t and 2 x_t (kinks of G)
+    r.ex1 = KIND == KF_LONG ? log_pos(Q.kf[0] / thj) : INFINITY;
+    r.ex2 = KIND == KF_LONG ? log_pos(2.0 * Q.kf[0] / thj) : INFINITY;
+    {
+        ConvMarks<NM> mk;
+        int slot = 0;
+#pragma unroll
+        for (int m = 0; m < N; ++m)
+            if (m != j) {
+#pragma unroll
+                for (int sl = 0; sl < N - 1; ++sl)
+                    if (sl == slot) {
+                        mk.shift = lnthj;
+                        mk.core(sl, cm[m], wm[m], (r.thi - r.tlo) * (1.0 / double(kConvNInit)));
+                        r.mc[sl] = cm[m];
+                        r.mw[sl] = wm[m];
+                        r.mI[sl] = mk.I[sl];
+                    }
+                ++slot;
+            }
+    }
+    {
+        // for the bound of what is left below an edge (conv_T_merged): the weight's mode, ln rho of the others at t_lo
+        r.tmode = log_pos(Ash);
+        r.lwmode = Ash * r.tmode - Ash - r.lgA;
+        const double s_lo = exp_fin(r.tlo) * thj, ls_lo = r.tlo + lnthj;
+        double own_lo = 0.0;
+#pragma unroll
+        for (int m = 0; m < N; ++m)
+            if (m == j) own_lo = lg[m](s_lo, ls_lo);
+        bool cvx = true;
+        int slot = 0;
+#pragma unroll
+        for (int m = 0; m < N; ++m)
+            if (m != j) {
+#pragma unroll
+                for (int sl = 0; sl < N - 1; ++sl)
+                    if (sl == slot) r.ltlo[sl] = lg[m](s_lo, ls_lo) - own_lo;
+                double bj = 0.0;
+#pragma unroll
+                for (int m2 = 0; m2 < N; ++m2)
+                    if (m2 == j) bj = lg[m2].b;
+                if (m > j && (lg[m].lognormal || !(lg[m].b <= bj))) cvx = false;
+                ++slot;
+            }
+        r.convex = cvx;
+    }
+    r.kj = kj;
+    r.gl = (kj + 1.0) / fma(2.0, kj, 1.0);
+    if (KIND == KF_LONG) {
+        r.lgB = lgamma_pos(2.0 * kj) - 2.0 * lgkj;  // -ln B(k, k)
+        r.rB = kj / (2.0 * fma(2.0, kj, 1.0));      // B(k+1, k+1) / B(k, k)
+        r.c0 = exp_fin(r.lgB) / kj;                  // 1 / (k B(k, k))
+        r.sc[0] = sc[0];
+        r.sc[1] = sc[1];
+        r.sc[2] = sc[2];
+    }
+}
 
 // PHASE (the Long kernel only; 0 for the others): the range x_t < s < 2 x_t of a Long rule -- where G(s) needs the incomplete
 // beta table, ~115 instructions per node on top of the ~130 of any node -- is a few panels of a rule, but the lanes of a wave
@@ -1010,14 +1106,18 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
         mk.v[sl] = INFINITY;
     }
     // the next valid rule after j for the lanes with need = true (busy = false: none left); selects only
-    const auto next_rule = [&](bool need) {
+    // (rmin, a compile-time fact at each call site: the first call, before the loop, may take any rule; a call inside the loop
+    // comes from a lane that has finished one, so rule 0 cannot be its answer -- round 6: said so, the prepared rule 0, ~44
+    // registers for a three-mode plan, is dead across the loop instead of being carried through it and spilled around it)
+    const auto next_rule = [&](bool need, auto rmin_c) {
+        constexpr int rmin = decltype(rmin_c)::value;
         int jn = NR;
 #pragma unroll
-        for (int r = NR - 1; r >= 0; --r)
+        for (int r = NR - 1; r >= rmin; --r)
             if (rb[r].valid && (PHASE != 2 || midneed[r]) && r > j) jn = r;
         const bool go = need && jn < NR;
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
+        for (int r = rmin; r < NR; ++r) {
             const bool sel = go && jn == r;
             A = sel ? rb[r].A : A;
             lgA = sel ? rb[r].lgA : lgA;
@@ -1105,7 +1205,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
         }
         if (PHASE == 2) {   // the sums of phase 1 carry over
 #pragma unroll
-            for (int r = 0; r < NR; ++r)
+            for (int r = rmin; r < NR; ++r)
 #pragma unroll
                 for (int e = 0; e < 3; ++e) out[e] = (go && jn == r) ? Traw[r][e] : out[e];
         }
@@ -1166,7 +1266,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
         if (PHASE == 2) sing = need ? (go && nxt == mk.extra[1]) : sing;
         return need && !go;
     };
-    next_rule(true);
+    next_rule(true, ConvInt<0>{});
     (void)next_panel(busy);
 #pragma unroll 1
     while (busy) {
@@ -1264,18 +1364,139 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
                 Traw[r][2] = st ? out[2] : Traw[r][2];
                 if (PHASE == 1) midneed[r] = st ? mid_flag : midneed[r];
             }
-            next_rule(done);
+            next_rule(done, ConvInt<(NR > 1 ? 1 : 0)>{});
             (void)next_panel(done && busy);
         }
     }
 }
 
+struct ConvSplit {
+    bool valid;                 // this lane owns a parcel
+    int p2_hint;                // the trips phase 2 took for this lane's parcel the last time (0: unknown)
+    unsigned int *sh_cnt;       // the ranking's LDS arrays (QB counters, QB slots)
+    unsigned short *sh_perm;
+    int cost2;                  // out: the trips of phase 2 of THIS lane's parcel (walked by whichever lane)
+};
+
+// Phase 2 of a Long plan on the lane the second ranking picks (see ConvSplit).  In: the owner's rules, sums of phase 1 and
+// hole flags; out: the owner's sums after phase 2, sp.cost2.  xt: the table rows (exchange rows before and after the walk).
+template <int N, int NROW>
+__device__ __forceinline__ void conv_long_phase2_split(const KArgs<N, 1> &A, const QArgs &Q, const double (&nn)[N],
+                                                       const double (&th)[N], const double (&kk)[N],
+                                                       const ConvRule<(N > 1 ? N - 1 : 1)> (&rb)[(N > 1 ? N - 1 : 1)],
+                                                       double (&Traw)[(N > 1 ? N - 1 : 1)][3],
+                                                       const bool (&midneed)[(N > 1 ? N - 1 : 1)], double (&xt)[NROW][kBlock],
+                                                       ConvSplit &sp) {
+    constexpr int NM = N > 1 ? N - 1 : 1;
+    static_assert(NROW >= 3 * N + 6 * NM + 1 && NROW >= NM * kLongNT, "exchange rows");
+    const int t = threadIdx.x;
+    // ---- the owner leaves what phase 2 needs
+    int flags = 0;
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        xt[3 * m + 0][t] = nn[m];
+        xt[3 * m + 1][t] = th[m];
+        xt[3 * m + 2][t] = kk[m];
+    }
+#pragma unroll
+    for (int j = 0; j < NM; ++j) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            xt[3 * N + 3 * j + e][t] = rb[j].sc[e];
+            xt[3 * N + 3 * NM + 3 * j + e][t] = Traw[j][e];
+        }
+        flags |= (sp.valid && rb[j].valid && midneed[j]) ? (1 << j) : 0;
+    }
+    xt[3 * N + 6 * NM][t] = double(flags);
+    // ---- the second ranking: by the trips phase 2 took the last time (regime_rank brackets itself with barriers: the rows
+    // above are visible once it returns)
+    regime_rank<kBlock>(sp.valid, sp.p2_hint > kBlock - 2 ? kBlock - 2 : sp.p2_hint, sp.sh_cnt, sp.sh_perm);
+    const int src = sp.sh_perm[t];
+    double n2[N], th2[N], k2[N], sc2[NM][3], T2[NM][3];
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        n2[m] = xt[3 * m + 0][src];
+        th2[m] = xt[3 * m + 1][src];
+        k2[m] = xt[3 * m + 2][src];
+    }
+#pragma unroll
+    for (int j = 0; j < NM; ++j)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            sc2[j][e] = xt[3 * N + 3 * j + e][src];
+            T2[j][e] = xt[3 * N + 3 * NM + 3 * j + e][src];
+        }
+    const int flags2 = (int)xt[3 * N + 6 * NM][src];
+    __syncthreads();   // every lane has what it came for: the rows become the tables
+    // ---- the rules of the parcel in hand, prepared again (the function that prepared them for phase 1)
+    ConvLogDensity lg2[N];
+    double cm2[N], wm2[N], lnth2[N], lgk2[N];
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        ConvMode md;
+        md.lognormal = A.dist_type[m] == DIST_LOGNORMAL;
+        md.n = n2[m];
+        md.th = th2[m];
+        md.k = k2[m];
+        md.lnth = md.lognormal ? th2[m] : log_pos(th2[m]);
+        md.lgk = md.lognormal ? 0.0 : lgamma_pos(k2[m]);
+        lnth2[m] = md.lnth;
+        lgk2[m] = md.lgk;
+        lg2[m] = conv_log_density(md);
+        cm2[m] = conv_ln_mean(md);
+        wm2[m] = conv_core_width(md);
+    }
+    ConvRule<NM> rb2[NM];
+    bool mid2[NM];
+    int cost2 = 0;
+    // (no lane of the wave with a hole: nothing to prepare, no table, no walk -- the waves the second ranking fills with the
+    // parcels that have none)
+    if (__builtin_amdgcn_ballot_w64(flags2 != 0) != 0ull) {
+#pragma unroll
+        for (int j = 0; j < NM; ++j) {
+            const bool lnj = A.dist_type[j] == DIST_LOGNORMAL;
+            conv_rule_prepare<N, KF_LONG>(Q, j, lnj, n2[j], k2[j], th2[j], lnth2[j], lgk2[j], cm2, wm2, lg2, sc2[j], rb2[j]);
+            mid2[j] = (flags2 >> j) & 1;
+            rb2[j].valid = rb2[j].valid && mid2[j];
+            if (!lnj) conv_long_tab_build(k2[j], xt, j * kLongNT);
+        }
+        conv_T_merged<N, KF_LONG, true, 2>(Q, lg2, rb2, T2, mid2, xt, cost2);
+    }
+    __syncthreads();   // the tables are dead: the rows carry the sums back to the owners
+#pragma unroll
+    for (int j = 0; j < NM; ++j)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) xt[3 * j + e][src] = T2[j][e];
+    xt[3 * NM][src] = double(cost2 >> 16);
+    __syncthreads();
+    int tl = threadIdx.x;
+    asm volatile("" : "+v"(tl));
+#pragma unroll
+    for (int j = 0; j < NM; ++j)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) Traw[j][e] = xt[3 * j + e][tl];
+    sp.cost2 = (int)xt[3 * NM][tl];
+}
+
 // get_coal_ints(::NumericalCoalStyle, ...) for the parcel of this lane in converged mode: acc[k][m], normalised units,
 // kernel constants INCLUDED.  tab: nq Gauss-Legendre nodes on [-1, 1], then nq weights.
-template <int N, int KIND>
+// SPLIT (round 6; the Long kernel's table plans, the kernel behind cloudy_coal_rhs only): the holes of a parcel's rules (phase 2)
+// are walked by ANOTHER lane of the workgroup than the one that owns the parcel.  A wave runs each of the two loops for as long as
+// its lane with the most trips, and the two counts of a parcel are nearly independent: one ranking of the workgroup's parcels
+// (round 5: 4 bits of each count in one key) leaves 0.74 of the lanes active (tools/long_lane_sim.py reproduces the PMC figure
+// 0.73 from the oracle's counts), a ranking PER PHASE 0.83.  So the workgroup is ranked by phase 1's count when the parcels are
+// loaded and a second time, by phase 2's, between the loops.  What the second lane needs of a parcel -- (n, theta, k) of its
+// modes, the output scales and the sums of phase 1 of its rules, which rules have a hole: 3N + 6(N-1) + 1 doubles -- crosses in
+// the LDS rows that hold the incomplete-beta tables afterwards; the rules are prepared again by the same function that prepared
+// them for phase 1 (conv_rule_prepare: ~1 % of the parcel's instructions), and the three sums per rule and the trip count come
+// back the same way.  Nothing of phase 1 is live in phase 2 and the reverse.  Every lane of the workgroup must call (barriers):
+// lanes without a parcel come with valid = false and n = 0.
+
+template <int N, int KIND, bool SPLIT = false>
 __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs &Q, const double *__restrict__ tab,
                                                const double (&nn)[N], const double (&th)[N], const double (&kk)[N],
-                                               double (&acc)[N][3], int &cost) {
+                                               double (&acc)[N][3], int &cost, ConvSplit *sp = nullptr) {
+    static_assert(!SPLIT || (KIND == KF_LONG && N > 1 && N <= 3), "the split walk serves the Long kernel's table plans");
     cost = 0;   // panel evaluations of the parcel's Gamma-weight rules (the only part whose length differs between parcels)
     ConvMode md[N];
     ConvLogDensity lg[N];
@@ -1320,96 +1541,28 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
 #ifndef CLOUDY_ABLATE_CONV_T  // (timing experiment only: the closed forms alone)
     if (N > 1) {
         constexpr int NM = N > 1 ? N - 1 : 1;
-        constexpr double gam = KIND == KF_LINEAR ? 1.0 : KIND == KF_HYDRODYNAMIC ? 4.0 / 3.0 : 0.0;
         // the rules of the Gamma-family modes: everything prepared here, walked in ONE loop (conv_T_merged)
         ConvRule<NM> rb[NM];
         double Traw[NM][3], prefj[NM];
         bool any_gamma = false;
 #pragma unroll
         for (int j = 0; j < N - 1; ++j) {
-            ConvRule<NM> &r = rb[j];
             Traw[j][0] = Traw[j][1] = Traw[j][2] = 0.0;
-            r.valid = !lnj_[j] && nj_[j] > 0.0;
-            r.A = r.lgA = r.th = 1.0;
-            r.lnth = r.tlo = r.thi = r.kj = r.lgB = r.rB = r.gl = 0.0;
-            r.ex1 = r.ex2 = INFINITY;
-            r.c0 = 0.0;
-            r.sc[0] = r.sc[1] = r.sc[2] = 1.0;
-            r.tmode = r.lwmode = 0.0;
-            r.convex = false;
-#pragma unroll
-            for (int sl = 0; sl < NM; ++sl) {
-                r.ltlo[sl] = 0.0;
-                r.mc[sl] = 0.0;
-                r.mw[sl] = 1.0;
-                r.mI[sl] = 0;
-            }
-            prefj[j] = 0.0;
-            if (lnj_[j]) continue;  // (wave-uniform: the closure family of a mode is a plan constant) -> conv_T_lognormal below
-            any_gamma = true;
             const double (&pr)[4] = selfpr[j];
-            const double kj = kj_[j], thj = thj_[j], lnthj = lnthj_[j];
-            const double Ash = fma(2.0, kj, gam);  // homogeneous kernels: T_m = 1/2 s0 E_{Gamma(2k + gamma)}[s^m (1 - w)]
-            prefj[j] = KIND == KF_LONG ? 0.5 * (nj_[j] * nj_[j]) : 0.5 * pr[0];
-            r.A = Ash;
-            r.lgA = lgamma_pos(Ash);
-            r.th = thj;
-            r.lnth = lnthj;
-            conv_range(Ash, 2.0, r.lgA, r.tlo, r.thi);
-            // marks: the other modes' cores; Long: s = x_t and 2 x_t (kinks of G)
-            r.ex1 = KIND == KF_LONG ? log_pos(Q.kf[0] / thj) : INFINITY;
-            r.ex2 = KIND == KF_LONG ? log_pos(2.0 * Q.kf[0] / thj) : INFINITY;
-            {
-                ConvMarks<NM> mk;
-                int slot = 0;
-#pragma unroll
-                for (int m = 0; m < N; ++m)
-                    if (m != j) {
-#pragma unroll
-                        for (int sl = 0; sl < N - 1; ++sl)
-                            if (sl == slot) {
-                                mk.shift = lnthj;
-                                mk.core(sl, cm[m], wm[m], (r.thi - r.tlo) * (1.0 / double(kConvNInit)));
-                                r.mc[sl] = cm[m];
-                                r.mw[sl] = wm[m];
-                                r.mI[sl] = mk.I[sl];
-                            }
-                        ++slot;
-                    }
-            }
-            {
-                // for the bound of what is left below an edge (conv_T_merged): the weight's mode, ln rho of the others at t_lo
-                r.tmode = log_pos(Ash);
-                r.lwmode = Ash * r.tmode - Ash - r.lgA;
-                const double s_lo = exp_fin(r.tlo) * thj, ls_lo = r.tlo + lnthj;
-                const double own_lo = lg[j](s_lo, ls_lo);
-                bool cvx = true;
-                int slot = 0;
-#pragma unroll
-                for (int m = 0; m < N; ++m)
-                    if (m != j) {
-#pragma unroll
-                        for (int sl = 0; sl < N - 1; ++sl)
-                            if (sl == slot) r.ltlo[sl] = lg[m](s_lo, ls_lo) - own_lo;
-                        if (m > j && (lg[m].lognormal || !(lg[m].b <= lg[j].b))) cvx = false;
-                        ++slot;
-                    }
-                r.convex = cvx;
-            }
-            r.kj = kj;
-            r.gl = (kj + 1.0) / fma(2.0, kj, 1.0);
-            if (KIND == KF_LONG) {
-                r.lgB = lgamma_pos(2.0 * kj) - 2.0 * lgkj_[j];  // -ln B(k, k)
-                r.rB = kj / (2.0 * fma(2.0, kj, 1.0));           // B(k+1, k+1) / B(k, k)
-                r.c0 = exp_fin(r.lgB) / kj;                      // 1 / (k B(k, k))
+            prefj[j] = lnj_[j] ? 0.0 : KIND == KF_LONG ? 0.5 * (nj_[j] * nj_[j]) : 0.5 * pr[0];
+            double sc[3] = {1.0, 1.0, 1.0};
+            if (KIND == KF_LONG && !lnj_[j]) {
                 // (totals: T_m with 1 - w = 1 -- half the self-collision integrals of orders 0, 1, 2 -- the estimates' scale)
                 const double rp = 1.0 / prefj[j];
-                r.sc[0] = (0.5 * pr[0]) * rp;
-                r.sc[1] = pr[1] * rp;
-                r.sc[2] = (pr[2] + pr[3]) * rp;
+                sc[0] = (0.5 * pr[0]) * rp;
+                sc[1] = pr[1] * rp;
+                sc[2] = (pr[2] + pr[3]) * rp;
             }
+            conv_rule_prepare<N, KIND>(Q, j, lnj_[j], nj_[j], kj_[j], thj_[j], lnthj_[j], lgkj_[j], cm, wm, lg, sc, rb[j]);
+            if (lnj_[j]) continue;  // (wave-uniform: the closure family of a mode is a plan constant) -> conv_T_lognormal below
+            any_gamma = true;
         }
-        if (any_gamma) {
+        if (any_gamma || SPLIT) {   // (any_gamma is wave-uniform -- a plan constant --, and true for a SPLIT plan's first mode)
             // what the walk does not need waits in the lane's own LDS slots (conflict-free, no barrier: a lane reads what it
             // wrote): the 3N partial tendencies of phase 1 and the prefactors -- registers the allocator would otherwise
             // spill around (and, at three waves per SIMD, inside) the loop: 11 x the algorithmic HBM traffic in scratch
@@ -1424,7 +1577,9 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
             for (int j = 0; j < N - 1; ++j) sh_park[3 * N + j][t] = prefj[j];
 #endif
             constexpr bool kTabFits = KIND == KF_LONG && N <= 3;
-            __shared__ double sh_gtab[kTabFits ? (N > 1 ? N - 1 : 1) * kLongNT : 1][kBlock];
+            constexpr int kXRows = 3 * N + 6 * NM + 1;   // SPLIT: what crosses between the two lanes of a parcel
+            constexpr int kTabRows = kTabFits ? (SPLIT && kXRows > NM * kLongNT ? kXRows : NM * kLongNT) : 1;
+            __shared__ double sh_gtab[kTabRows][kBlock];
             bool midneed[NM];
 #pragma unroll
             for (int j = 0; j < NM; ++j) midneed[j] = false;
@@ -1434,7 +1589,9 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
                 // (the choice is wave-uniform, and a compile-time fact in a kernel compiled for the plan)
                 const bool tab = kTabFits && A.kmax <= kLongTabKmax;
                 conv_T_merged<N, KIND, false, (KIND == KF_LONG ? 1 : 0)>(Q, lg, rb, Traw, midneed, sh_gtab, cost);
-                if (tab) {
+                if constexpr (SPLIT) {
+                    conv_long_phase2_split<N, kTabRows>(A, Q, nn, th, kk, rb, Traw, midneed, sh_gtab, *sp);
+                } else if (tab) {
 #pragma unroll
                     for (int j = 0; j < N - 1; ++j)
                         if (!lnj_[j] && kTabFits) conv_long_tab_build(kj_[j], sh_gtab, kTabFits ? j * kLongNT : 0);

@@ -208,43 +208,101 @@ __device__ __forceinline__ void quad_coal_ints(const KArgs<N, 1> &A, const QArgs
 // every lane), so results are bit-identical with and without hints, and a stale or foreign hint costs balance, never accuracy.
 // the parcel this lane takes: the natural one, or -- hints given -- the parcel of rank threadIdx.x among the workgroup's parcels
 // ordered by their hint bytes (every lane of the workgroup must call it: barriers)
+// hint2 (Long plans; round 6): a second byte per parcel.  The Long kernel's walk has two loops (quad_conv.hpp, PHASE) whose trip
+// counts are nearly independent: byte 1 holds phase 1's count, byte 2 phase 2's.  The kernel behind cloudy_coal_rhs ranks its
+// workgroup once per loop (ConvSplit); the fused integrators, which rank once per call, use round 5's key: 4 bits of phase 2's
+// count first (it decides whether a wave enters the second loop at all), 4 bits of phase 1's (in units of four) second.
 template <int QB>
-__device__ __forceinline__ size_t quad_ranked_parcel(size_t n, const unsigned char *__restrict__ hint) {
+__device__ __forceinline__ size_t quad_ranked_parcel(size_t n, const unsigned char *__restrict__ hint, unsigned int *sh_cnt,
+                                                     unsigned short *sh_perm, const unsigned char *__restrict__ hint2 = nullptr,
+                                                     bool key44 = false) {
     size_t i = (size_t)blockIdx.x * QB + threadIdx.x;
     if (hint != nullptr) {   // (a kernel argument: the same for every lane)
-        __shared__ unsigned int sh_cnt[QB];
-        __shared__ unsigned short sh_perm[QB];
         const bool valid = i < n;
-        const int hb = valid ? (int)hint[i] : 0;
+        int hb = valid ? (int)hint[i] : 0;
+        if (key44 && hint2 != nullptr) {
+            const int p2 = valid ? (int)hint2[i] : 0, p1 = hb >> 2;
+            hb = ((p2 > 15 ? 15 : p2) << 4) | (p1 > 15 ? 15 : p1);
+        }
         regime_rank<QB>(valid, hb > QB - 2 ? QB - 2 : hb, sh_cnt, sh_perm);
         i = (size_t)blockIdx.x * QB + sh_perm[threadIdx.x];   // (lanes without a parcel rank last)
     }
     return i;
 }
+template <int QB>
+__device__ __forceinline__ size_t quad_ranked_parcel(size_t n, const unsigned char *__restrict__ hint,
+                                                     const unsigned char *__restrict__ hint2 = nullptr, bool key44 = false) {
+    __shared__ unsigned int sh_cnt[QB];
+    __shared__ unsigned short sh_perm[QB];
+    return quad_ranked_parcel<QB>(n, hint, sh_cnt, sh_perm, hint2, key44);
+}
+// what a parcel leaves behind for the next call from the `cost` of conv_coal_ints (Long: phase 2's count in the upper half)
+template <int KIND>
+__device__ __forceinline__ void quad_store_hints(unsigned char *__restrict__ hint, unsigned char *__restrict__ hint2, size_t i,
+                                                 int cost) {
+    if (KIND == KF_LONG && hint2 != nullptr) {
+        const int p1 = cost & 0xffff, p2 = cost >> 16;
+        hint[i] = (unsigned char)(p1 > 255 ? 255 : p1);
+        hint2[i] = (unsigned char)(p2 > 255 ? 255 : p2);
+    } else {
+        hint[i] = conv_hint_byte<KIND>(cost);
+    }
+}
 
-template <int N, int KIND, int NQ, typename TIO, bool CONV = false>
+template <int N, int KIND, int NQ, typename TIO, bool CONV = false, bool SPLIT = false>
 __device__ __forceinline__ void coal_rhs_quad_body(const KArgs<N, 1> &A, const QArgs &Q, const double *__restrict__ tab,
                                                    size_t n, size_t ld, const TIO *__restrict__ in,
-                                                   TIO *__restrict__ out, unsigned char *__restrict__ hint = nullptr) {
+                                                   TIO *__restrict__ out, unsigned char *__restrict__ hint = nullptr,
+                                                   unsigned char *__restrict__ hint2 = nullptr) {
     constexpr int QB = NQ ? quad_block(NQ) : kBlock;
-    const size_t i = quad_ranked_parcel<QB>(n, CONV ? hint : nullptr);
-    if (i >= n) return;
+    static_assert(!SPLIT || (CONV && KIND == KF_LONG), "SPLIT: the Long kernel's converged mode");
+    __shared__ unsigned int sh_cnt[CONV ? QB : 1];
+    __shared__ unsigned short sh_perm[CONV ? QB : 1];
+    const size_t i = quad_ranked_parcel<QB>(n, CONV ? hint : nullptr, sh_cnt, sh_perm, hint2, !SPLIT);
+    // (SPLIT: the workgroup meets again between the two loops of the walk -- lanes without a parcel stay, with an empty one)
+    const bool valid = i < n;
+    if (!SPLIT && !valid) return;
     double nn[N], th[N], kk[N], acc[N][3];
-    load_parcel<N, 1, TIO>(A, i, ld, in, nn, th, kk);
+    load_parcel<N, 1, TIO>(A, valid ? i : 0, ld, in, nn, th, kk);
     int cost = 0;
-    if (CONV)
+    if (SPLIT) {
+        if (!valid) {
+#pragma unroll
+            for (int m = 0; m < N; ++m) nn[m] = 0.0;
+        }
+        ConvSplit sp;
+        sp.valid = valid;
+        sp.p2_hint = (valid && hint2 != nullptr) ? (int)hint2[i] : 0;
+        sp.sh_cnt = sh_cnt;
+        sp.sh_perm = sh_perm;
+        sp.cost2 = 0;
+        conv_coal_ints<N, KIND, SPLIT>(A, Q, tab, nn, th, kk, acc, cost, &sp);
+        cost = (cost & 0xffff) | (sp.cost2 << 16);
+        if (!valid) return;
+    } else if (CONV) {
         conv_coal_ints<N, KIND>(A, Q, tab, nn, th, kk, acc, cost);
-    else
+    } else {
         quad_coal_ints<N, KIND, NQ>(A, Q, tab, nn, th, kk, acc);
+    }
     const double ksc = CONV ? 1.0 : kf_scale<KIND>(Q);
+    // A ranked workgroup stores a PERMUTATION of its 2-KB window of each plane: a wave's 64 values land in 64 different sectors,
+    // and the four waves of the workgroup finish milliseconds apart.  As nontemporal stores (round 5) every 8-B value went to
+    // HBM on its own: WRITE_SIZE 3.3 x the output (round 6 PMC: 945 MB for 288 MB of tendencies).  Plain stores let the L2
+    // assemble the lines before they leave.
+    const auto store = [&](TIO *p, double v) {
+        if (CONV)
+            *p = (TIO)v;
+        else
+            st_stream(p, v);
+    };
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         const int off = A.off[k];
-        st_stream(out + (size_t)(off + 0) * ld + i, acc[k][0] * (ksc * A.out_scale[3 * k + 0]));
-        st_stream(out + (size_t)(off + 1) * ld + i, acc[k][1] * (ksc * A.out_scale[3 * k + 1]));
-        if (A.np[k] == 3) st_stream(out + (size_t)(off + 2) * ld + i, acc[k][2] * (ksc * A.out_scale[3 * k + 2]));
+        store(out + (size_t)(off + 0) * ld + i, acc[k][0] * (ksc * A.out_scale[3 * k + 0]));
+        store(out + (size_t)(off + 1) * ld + i, acc[k][1] * (ksc * A.out_scale[3 * k + 1]));
+        if (A.np[k] == 3) store(out + (size_t)(off + 2) * ld + i, acc[k][2] * (ksc * A.out_scale[3 * k + 2]));
     }
-    if (CONV && hint != nullptr) hint[i] = conv_hint_byte<KIND>(cost);
+    if (CONV && hint != nullptr) quad_store_hints<KIND>(hint, hint2, i, cost);
 }
 
 // solve(ODEProblem(make_box_model_rhs(NumericalCoalStyle()), m, tspan, p), SSPRK33(), dt) -- the Numerical drivers
@@ -254,11 +312,12 @@ __device__ __forceinline__ void coal_rhs_quad_body(const KArgs<N, 1> &A, const Q
 template <int N, int KIND, int NQ, typename TIO, bool CONV = false>
 __device__ __forceinline__ void quad_ssprk33_body(const KArgs<N, 1> &A, const QArgs &Q, const double *__restrict__ tab,
                                                   size_t n, size_t ld, const TIO *u_in, TIO *u_out, double dt,
-                                                  int n_steps, unsigned char *__restrict__ hint = nullptr) {
+                                                  int n_steps, unsigned char *__restrict__ hint = nullptr,
+                                                  unsigned char *__restrict__ hint2 = nullptr) {
     // (converged mode: the lane keeps, for the whole call, the parcel its hint ranks it to -- the cost of a parcel moves little
     // over a few stages -- and leaves the cost of its last evaluation behind; coal_rhs_quad_body shares the bytes)
     constexpr int QB = NQ ? quad_block(NQ) : kBlock;
-    const size_t i = quad_ranked_parcel<QB>(n, CONV ? hint : nullptr);
+    const size_t i = quad_ranked_parcel<QB>(n, CONV ? hint : nullptr, hint2, true);
     if (i >= n) return;
     int cost = 0;
     double u[N][3], up[N][3];
@@ -351,7 +410,7 @@ __device__ __forceinline__ void quad_ssprk33_body(const KArgs<N, 1> &A, const QA
         u_out[(size_t)(off + 1) * ld + i] = (TIO)u[m][1];
         if (A.np[m] == 3) u_out[(size_t)(off + 2) * ld + i] = (TIO)u[m][2];
     }
-    if (CONV && hint != nullptr && n_steps > 0) hint[i] = conv_hint_byte<KIND>(cost);
+    if (CONV && hint != nullptr && n_steps > 0) quad_store_hints<KIND>(hint, hint2, i, cost);
 }
 
 // cloudy_tsit5_steps of a NumericalCoalStyle plan (round 4): the tableau of tsit5_advance (kernels.hpp) around the same
@@ -359,9 +418,10 @@ __device__ __forceinline__ void quad_ssprk33_body(const KArgs<N, 1> &A, const QA
 template <int N, int KIND, int NQ, typename TIO, bool CONV = false>
 __device__ __forceinline__ void quad_tsit5_body(const KArgs<N, 1> &A, const QArgs &Q, const double *__restrict__ tab,
                                                 size_t n, size_t ld, const TIO *u_in, TIO *u_out, double dt, int n_steps,
-                                                unsigned char *__restrict__ hint = nullptr) {
+                                                unsigned char *__restrict__ hint = nullptr,
+                                                unsigned char *__restrict__ hint2 = nullptr) {
     constexpr int QB = NQ ? quad_block(NQ) : kBlock;
-    const size_t i = quad_ranked_parcel<QB>(n, CONV ? hint : nullptr);   // (as quad_ssprk33_body)
+    const size_t i = quad_ranked_parcel<QB>(n, CONV ? hint : nullptr, hint2, true);   // (as quad_ssprk33_body)
     if (i >= n) return;
     int cost = 0;
     double u[N][3];
@@ -400,7 +460,7 @@ __device__ __forceinline__ void quad_tsit5_body(const KArgs<N, 1> &A, const QArg
         u_out[(size_t)(off + 1) * ld + i] = (TIO)u[m][1];
         if (A.np[m] == 3) u_out[(size_t)(off + 2) * ld + i] = (TIO)u[m][2];
     }
-    if (CONV && hint != nullptr && n_steps > 0) hint[i] = conv_hint_byte<KIND>(cost);
+    if (CONV && hint != nullptr && n_steps > 0) quad_store_hints<KIND>(hint, hint2, i, cost);
 }
 
 // ahead-of-time instance: run-time point count, the rule arrays in scratch (the plan-time compiled kernel of jit.hpp

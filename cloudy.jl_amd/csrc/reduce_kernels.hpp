@@ -59,6 +59,66 @@ __global__ void __launch_bounds__(kBlock)
     }
 }
 
+// cloudy_closure_stats: how many parcels of a batch had their closure inversion clamped or replaced, per mode (round 6).
+// update_dist_from_moments (ParticleDistributions.jl:456-541) never fails per parcel: moments at or below eps give the fallback
+// distribution (0, 1, 1), a Gamma shape outside k_range is clamped (:459-475), and nothing reports it -- with 1e7 parcels per
+// call a caller could only find out by pulling the (n, theta, k) planes to the host.  Four counters per mode:
+//   [0] fallback: the parcel took the (0, 1, 1) branch;   [1] shape at its lower clamp (Gamma: k = k_min; Lognormal: sigma = eps);
+//   [2] shape at its upper clamp (Gamma: k = k_max);      [3] check_moment_consistency (:437-449) would throw for the mode's
+//   normalised moments: a negative moment, or (three moments) a negative second central moment, summed in the reference's order.
+// One pass; a lane counts its parcels in registers, a wave adds its lanes, one atomic per wave and counter.
+struct ClosureStatsArgs {
+    int N;
+    int dist_type[CLOUDY_MAX_MODES], np[CLOUDY_MAX_MODES], off[CLOUDY_MAX_MODES];
+    double norm[3 * CLOUDY_MAX_MODES], inv_norm[3 * CLOUDY_MAX_MODES];
+    double kmin, kmax;
+};
+// the reference's check on one mode's (normalised) moments; NaN comparisons are false there as here
+__device__ __forceinline__ bool moments_inconsistent(int np, double m0, double m1, double m2) {
+    if (m0 < 0.0 || m1 < 0.0 || (np == 3 && m2 < 0.0)) return true;
+    if (np < 3) return false;
+    // order 2: sum_i binomial(2, i) (-1)^i (m[2]/m[1])^i (m[3-i]/m[1]), i = 0, 1, 2, left to right
+    const double r = m1 / m0;
+    const double cm = (m2 / m0 + (-2.0 * r) * (m1 / m0)) + (r * r) * (m0 / m0);
+    return cm < 0.0;
+}
+template <typename TIO>
+__global__ void __launch_bounds__(kBlock)
+    closure_stats_kernel(const ClosureStatsArgs a, size_t n, size_t ld, const TIO *__restrict__ mom,
+                         unsigned long long *__restrict__ counts) {
+    unsigned int c[4 * CLOUDY_MAX_MODES];
+#pragma unroll
+    for (int q = 0; q < 4 * CLOUDY_MAX_MODES; ++q) c[q] = 0u;
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+#pragma unroll
+        for (int m = 0; m < CLOUDY_MAX_MODES; ++m) {
+            if (m >= a.N) break;
+            const int off = a.off[m], np = a.np[m], dt = a.dist_type[m];
+            double m0 = (double)mom[(size_t)(off + 0) * ld + i], m1 = (double)mom[(size_t)(off + 1) * ld + i];
+            double m2 = np == 3 ? (double)mom[(size_t)(off + 2) * ld + i] : 0.0;
+            m0 = div_by_const(m0, a.norm[3 * m + 0], a.inv_norm[3 * m + 0]);   // mom ./ mom_norms, as load_parcel
+            m1 = div_by_const(m1, a.norm[3 * m + 1], a.inv_norm[3 * m + 1]);
+            m2 = div_by_const(m2, a.norm[3 * m + 2], a.inv_norm[3 * m + 2]);
+            double nn, th, kk;
+            invert_closure(dt, m0, m1, m2, a.kmin, a.kmax, nn, th, kk);
+            const bool fb = dt == DIST_LOGNORMAL ? !(m0 > kEps && m1 > kEps && m2 > kEps) : !(m0 > kEps && m1 > kEps);
+            c[4 * m + 0] += fb ? 1u : 0u;
+            c[4 * m + 1] += (!fb && ((dt == DIST_GAMMA && kk == a.kmin) || (dt == DIST_LOGNORMAL && kk == kEps))) ? 1u : 0u;
+            c[4 * m + 2] += (!fb && dt == DIST_GAMMA && kk == a.kmax) ? 1u : 0u;
+            c[4 * m + 3] += moments_inconsistent(np, m0, m1, m2) ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4 * CLOUDY_MAX_MODES; ++q) {
+        if (q >= 4 * a.N) break;
+        unsigned int v = c[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((threadIdx.x & 63) == 0 && v != 0u) atomicAdd(&counts[q], (unsigned long long)v);
+    }
+}
+
 // Upwind flux divergence of make_rainshaft_rhs (test/examples/utils/rainshaft_helpers.jl:80-86), columns of nz cells
 // stored contiguously (cell index fastest): rhs[q][i] = coal[q][i] - (flux[q][i+1] - flux[q][i]) / dz, flux above the
 // top cell of a column = 0.  `rhs` holds the coalescence source on entry.

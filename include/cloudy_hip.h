@@ -277,6 +277,18 @@ int cloudy_tsit5_steps(const cloudy_plan *plan, size_t n_parcels, size_t ld, con
 int cloudy_get_coal_ints(const cloudy_plan *plan, size_t n_parcels, size_t ld, const void *params_dev,
                          void *coal_ints_dev, void *stream);
 
+/* Batched validity diagnostic of the closure inversion (round 6): counts_host[4 * mode + c] = the number of parcels whose mode
+ *   c = 0: took the fallback distribution (0, 1, 1) (moments at or below eps; ParticleDistributions.jl:461, :473-475, :495, :519);
+ *   c = 1: has its shape at the lower clamp (Gamma: k = k_range[0], :459-469; Lognormal: sigma = eps, :499-502);
+ *   c = 2: has its shape at the upper clamp (Gamma: k = k_range[1]);
+ *   c = 3: fails check_moment_consistency (ParticleDistributions.jl:437-449) -- a negative moment, or a negative second central
+ *          moment -- evaluated on the normalised moments the closure sees (box_model_helpers.jl:30-31).
+ * The reference can only raise per call or clamp silently; a batch of 1e7 parcels cannot throw per parcel, so the counts are the
+ * batch form of both.  mom_dev: the plan's plane type, physical units, as cloudy_coal_rhs.  Synchronises `stream`; counts_host
+ * has 4 * n_modes entries (host memory). */
+int cloudy_closure_stats(const cloudy_plan *plan, size_t n_parcels, size_t ld, const void *mom_dev, uint64_t *counts_host,
+                         void *stream);
+
 /* closure inversion: mom (physical) -> params planes (n, theta, k), normalised units */
 int cloudy_update_dist_from_moments(const cloudy_plan *plan, size_t n_parcels, size_t ld, const void *mom_dev,
                                     void *params_dev, void *stream);

@@ -420,6 +420,23 @@ function moment_sums_allreduce(plan::Plan, comm::Ptr{Cvoid}, arr; stream = nothi
     return out
 end
 
+"""
+    closure_stats(plan, m; stream = nothing) -> Matrix{Int} (N x 4)
+
+How many parcels of the device array `m` (n_parcels, nmom; physical units) had a mode's closure inversion replaced or clamped:
+columns = fallback distribution `(0, 1, 1)`, shape at the lower clamp, shape at the upper clamp, and moments for which
+`check_moment_consistency` (ParticleDistributions.jl:437-449) would throw.  The reference clamps silently per call
+(:456-541); this is the batch form of both, one pass on the device (`cloudy_closure_stats`).
+"""
+function closure_stats(plan::Plan, m; stream = nothing)
+    N = Int(ccall((:cloudy_plan_nparams, lib), Cint, (Ptr{Cvoid},), plan.handle)) ÷ 3
+    counts = Vector{UInt64}(undef, 4 * N)
+    s = stream === nothing ? current_stream() : stream
+    check(ccall((:cloudy_closure_stats, lib), Cint, (Ptr{Cvoid}, Csize_t, Csize_t, Ptr{Cvoid}, Ptr{UInt64}, Ptr{Cvoid}),
+                plan.handle, size(m, 1), stride(m, 2), pointer(m), counts, s))
+    return permutedims(reshape(Int.(counts), 4, N))
+end
+
 function __init__()
     check_layout()
 end

@@ -982,6 +982,53 @@ int co_rainshaft_cell_batch(const co_params *p, long n, long ld, const double *m
 }
 
 /* normalise + update_dist_from_moments for a batch; params planes: (n, theta, k) per mode */
+/* check_moment_consistency, ParticleDistributions.jl:437-449: 0 = consistent, 1 = a negative moment (:439), 2 = a negative
+ * even-ordered central moment (:443-448; mapreduce(+) over i = 0..order: left to right).  IEEE division as in Julia. */
+int co_check_moment_consistency(const double *m, int n_moments) {
+    for (int i = 0; i < n_moments; ++i)
+        if (m[i] < 0.0) return 1;
+    for (int order = 2; order <= n_moments - 1; order += 2) {
+        double cm = 0.0;
+        for (int i = 0; i <= order; ++i) {
+            const double sgn = (i % 2) ? -1.0 : 1.0, r = m[1] / m[0];
+            double ri = 1.0;
+            for (int e = 0; e < i; ++e) ri *= r; /* (m[2] / m[1])^i: Julia's integer power by repeated multiplication for i <= 3 */
+            const double t = (co_binomial(order, i) * sgn) * ri * (m[order - i] / m[0]);
+            cm = (i == 0) ? t : cm + t;
+        }
+        if (cm < 0.0) return 2;
+    }
+    return 0;
+}
+
+/* the batch form of the reference's silent clamps and of check_moment_consistency (csrc: cloudy_closure_stats):
+ * out[4 * mode + c], c = 0 fallback (0, 1, 1), 1 shape at the lower clamp, 2 at the upper clamp, 3 inconsistent moments */
+int co_closure_stats(const co_params *p, long n, long ld, const double *mom, unsigned long long *out) {
+    double mom_norms[CO_MAX_MODES * 3];
+    int nmom = co_get_moments_normalizing_factors(p->NProgMoms, p->N, p->norms, mom_norms);
+    if (nmom < 0) return -1;
+    for (int q = 0; q < 4 * p->N; ++q) out[q] = 0;
+    for (long i = 0; i < n; ++i) {
+        double mz[CO_MAX_MODES * 3];
+        co_dist pd[CO_MAX_MODES];
+        for (int q = 0; q < nmom; ++q) mz[q] = mom[(size_t)q * ld + i] / mom_norms[q];
+        if (co_invert_all(p, mz, pd) < 0) return -1;
+        int off = 0;
+        for (int m = 0; m < p->N; ++m) {
+            const double *mm = mz + off;
+            const int np = p->NProgMoms[m], t = p->dist_type[m];
+            const int fb = t == CO_LOGNORMAL ? !(mm[0] > CO_EPS && mm[1] > CO_EPS && mm[2] > CO_EPS) : !(mm[0] > CO_EPS && mm[1] > CO_EPS);
+            const double kmin = p->k_range[0], kmax = p->k_range[1];
+            out[4 * m + 0] += fb;
+            out[4 * m + 1] += !fb && ((t == CO_GAMMA && pd[m].k == kmin) || (t == CO_LOGNORMAL && pd[m].k == CO_EPS));
+            out[4 * m + 2] += !fb && t == CO_GAMMA && pd[m].k == kmax;
+            out[4 * m + 3] += co_check_moment_consistency(mm, np) != 0;
+            off += np;
+        }
+    }
+    return 0;
+}
+
 int co_update_dist_batch(const co_params *p, long n, long ld, const double *mom, double *params) {
     double mom_norms[CO_MAX_MODES * 3];
     int nmom = co_get_moments_normalizing_factors(p->NProgMoms, p->N, p->norms, mom_norms);

@@ -134,6 +134,8 @@ int co_rainshaft_cell(const co_params *p, const double *mom, double *coal_source
 int co_rainshaft_cell_batch(const co_params *p, long n, long ld, const double *mom, double *coal_source,
                             double *sedi_flux, int n_threads);
 int co_update_dist_batch(const co_params *p, long n, long ld, const double *mom, double *params /* [3N][ld] */);
+int co_check_moment_consistency(const double *m, int n_moments); /* ParticleDistributions.jl:437-449: 0 ok, 1 / 2 = which check throws */
+int co_closure_stats(const co_params *p, long n, long ld, const double *mom, unsigned long long *out /* [4N] */);
 int co_max_threads(void);
 
 /* ---- Coalescence.jl (NumericalCoalStyle) with a FIXED Gauss rule in place of quadgk: cloudy_oracle_quad.c ---- */

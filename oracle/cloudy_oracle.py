@@ -436,6 +436,26 @@ def update_dist_batch(p, mom):
     return out
 
 
+def check_moment_consistency(m):
+    """ParticleDistributions.jl:437-449: 0 = consistent (the reference returns nothing), 1 / 2 = which of its two checks throws"""
+    a = _darr(np.asarray(m, dtype=np.float64))
+    f = lib().co_check_moment_consistency
+    f.argtypes, f.restype = [C.POINTER(C.c_double), C.c_int], C.c_int
+    return int(f(_d(a), int(a.size)))
+
+
+def closure_stats(p, mom):
+    """(N, 4) counts per mode: fallback (0, 1, 1), shape at the lower clamp, at the upper clamp, inconsistent moments"""
+    m = _darr(mom)
+    nm, n = m.shape
+    out = (C.c_ulonglong * (4 * p.N))()
+    f = lib().co_closure_stats
+    f.argtypes, f.restype = [C.c_void_p, C.c_long, C.c_long, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong)], C.c_int
+    if f(C.cast(C.byref(p), C.c_void_p), n, n, _d(m), out) < 0:
+        raise ValueError("closure_stats failed")
+    return np.array(out[:], dtype=np.int64).reshape(p.N, 4)
+
+
 def max_threads():
     return lib().co_max_threads()
 

@@ -532,6 +532,13 @@ static _Thread_local long co_conv_rule_nodes_[CO_MAX_MODES]; /* ... of the T_m r
 void co_conv_rule_node_counts(long *out) {
     for (int i = 0; i < CO_MAX_MODES; ++i) out[i] = co_conv_rule_nodes_[i];
 }
+static _Thread_local long co_conv_phase_evals_[3]; /* panel evaluations of the descending walk by phase (0: homogeneous kernels) */
+void co_conv_phase_evals(long *out, int reset) { /* tools/long_lane_sim.py: the per-parcel cost the device's hint bytes record */
+    for (int i = 0; i < 3; ++i) {
+        out[i] = co_conv_phase_evals_[i];
+        if (reset) co_conv_phase_evals_[i] = 0;
+    }
+}
 long co_conv_node_count(int reset) {
     const long n = co_conv_nodes_;
     if (reset) co_conv_nodes_ = 0;
@@ -665,6 +672,7 @@ static int co_conv_descending(double tlo, double thi, const double *marks, int n
             const double wx = ldexp(1.0, -L), hx = 0.5 * wx, cx = wx * i + hx;
             for (int o = 0; o < 3; ++o) K[o] = G[o] = 0.0;
             --budget;
+            ++co_conv_phase_evals_[phase];
             for (int g = 0; g < 15; ++g) {
                 const double xi = cx + hx * CO_GK_X[g];
                 double t = a0 + h * xi, jac = 1.0;

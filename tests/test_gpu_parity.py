@@ -1427,6 +1427,48 @@ def test_rainshaft_column_integrator_ssprk33(gpu_cloudy, oracle, case):
         assert gt.min() >= 0.0 and gt[1, : nz_t // 2].sum() > 0.0
 
 
+@pytest.mark.parametrize("N, nz, ncol", [(5, 20, 40), (6, 100, 7), (3, 300, 4), (4, 300, 3), (5, 300, 3), (3, 110, 9), (8, 20, 30)])
+def test_column_integrator_picks_a_workgroup_size_whose_lds_fits(gpu_cloudy, oracle, N, nz, ncol, monkeypatch):
+    """round 5 picked the 512- / 1024-thread column kernel from the column height alone; a thresholded plan's LDS
+    rows grow with the mode count (5 modes at 512 threads, 3 at 1024 exceed a workgroup's 160 KB), so plans of 5-8 modes with
+    more than 256 / nz columns, and 3- and 4-mode plans with nz in 257..341, got EUNSUPPORTED.  Now the pick skips sizes whose LDS
+    does not fit, falls back to smaller ones, and steps stage by stage when no workgroup size both holds a column and fits.
+    Every case: two SSPRK33 steps against the same steps driven from the host through make_rainshaft_rhs."""
+    cloudy = gpu_cloudy
+    thr = tuple(10.0 ** (-10 + i) for i in range(N - 1)) + (INF,)
+    par, op, _ = make_case(cloudy, oracle, [1] * N, [[EPS / 1e6, 5.0], [5.0, 0.0]], thr, bench.NORMS, vel=((50.0, 1.0 / 6),))
+    par.nz, par.dz, par.dt = nz, 3000.0 / nz, 0.02 if nz > 50 else 0.5
+    n = nz * ncol
+    u0 = bench.synth_moments(min(N, 4), n, seed=77)
+    if N > 4:   # (synth_moments has four size ranges: further modes repeat the last one, a decade up each)
+        u0 = np.concatenate([u0] + [u0[9:12] * np.array([[0.1], [1.0], [100.0]]) * 10.0 ** (m - 3) for m in range(4, N)], axis=0)
+    u0 = np.ascontiguousarray(u0[: 3 * N])
+    rhs = cloudy.make_rainshaft_rhs()
+    u = u0.copy()
+    for _ in range(2):
+        f = lambda x: rhs(dev(cloudy, np.maximum(x, 0.0, out=x)), par, 0.0).to_numpy()  # noqa: E731
+        up = u
+        u = up + par.dt * f(up)
+        u = (3.0 * up + u + par.dt * f(u)) / 4.0
+        u = (up + 2.0 * u + 2.0 * par.dt * f(u)) / 3.0
+    np.maximum(u, 0.0, out=u)
+    out = cloudy.DeviceArray.zeros(*u0.shape)
+    cloudy.solve_rainshaft_ssprk33(par, dev(cloudy, u0.copy()), 2, out=out)
+    got = out.to_numpy()
+    fin = np.isfinite(u)
+    assert np.array_equal(np.isfinite(got), fin)
+    assert np.allclose(got[fin], u[fin], rtol=1e-11, atol=1e-13 * np.abs(u[fin]).max()), (N, nz, ncol)
+    # the experiment switch for a size that cannot serve the plan is ignored, not an error (ADVICE r5, low: 320 threads used to
+    # fall back to 256 threads whatever the column height)
+    for block in ("320", "1024"):
+        monkeypatch.setenv("CLOUDY_HIP_RS_BLOCK", block)
+        out2 = cloudy.DeviceArray.zeros(*u0.shape)
+        cloudy.solve_rainshaft_ssprk33(par, dev(cloudy, u0.copy()), 2, out=out2)
+        g2 = out2.to_numpy()
+        assert np.array_equal(np.isfinite(g2), fin) and np.allclose(g2[fin], u[fin], rtol=1e-11, atol=1e-13 * np.abs(u[fin]).max())
+    monkeypatch.delenv("CLOUDY_HIP_RS_BLOCK", raising=False)
+
+
 def test_workgroup_size_of_the_column_integrator_changes_no_bit(gpu_cloudy, monkeypatch):
     """Round 5: the kernel compiled for the plan exists with 256, 512 and 1024 threads and picks by column
     height; across the Simpson passes of a stage the state waits in LDS, and the flux exchange runs after them.  Every
@@ -1757,6 +1799,62 @@ def test_randomised_plan_sweep(gpu_cloudy, oracle, seed):
         assert dj <= 1e-6
 
 
+def test_closure_stats_vs_oracle(gpu_cloudy, oracle):
+    """cloudy_closure_stats: per mode the number of parcels on the fallback distribution (0, 1, 1), with the
+    shape at its lower / upper clamp, and failing check_moment_consistency (ParticleDistributions.jl:437-449, 456-541) -- one pass
+    over the batch -- against the oracle's count, exactly (integers): the bench batch at 1e6 parcels (its ~1 % degenerate parcels
+    make every counter non-zero), a four-mode MovingThreshold plan, a plan with Exponential / Lognormal modes and another shape
+    range, a slice with its own leading dimension, float planes, and an empty batch."""
+    cloudy = gpu_cloudy
+    O = oracle
+    wl = bench.make_workload("cfg3b", 1_000_000, seed=3)
+    plan = wl["coal_data"].plan(wl["dist_types"])
+    m = dev(cloudy, wl["mom"])
+    got = cloudy.closure_stats(plan, m)
+    want = O.closure_stats(bench.oracle_params("cfg3b"), wl["mom"])
+    assert got.shape == (2, 4) and np.array_equal(got, want) and want.min() > 0, (got, want)
+    # the counts say what the parameter planes say
+    par = cloudy.update_dist_from_moments(plan, m).to_numpy()
+    assert got[0, 0] == ((par[0] == 0.0) & (par[1] == 1.0) & (par[2] == 1.0)).sum()
+    assert got[1, 2] == (par[5] == 10.0).sum()
+    # a slice of the batch with the batch's leading dimension
+    import ctypes as C
+
+    L = cloudy.lib()
+    buf = (C.c_uint64 * 8)()
+    lo, cnt, esz = 77_777, 123_457, 8
+    cloudy._lib.check(L.cloudy_closure_stats(plan.handle, cnt, 1_000_000, m.ptr + lo * esz, buf, None))
+    assert np.array_equal(np.array(buf[:]).reshape(2, 4), O.closure_stats(bench.oracle_params("cfg3b"), wl["mom"][:, lo:lo + cnt]))
+    cloudy._lib.check(L.cloudy_closure_stats(plan.handle, 0, 0, None, buf, None))
+    assert not any(buf[:])
+    assert L.cloudy_closure_stats(plan.handle, 10, 5, m.ptr, buf, None) == cloudy._lib.EINVAL
+    assert L.cloudy_closure_stats(plan.handle, 10, 10, m.ptr, None, None) == cloudy._lib.EINVAL
+    # four modes, MovingThreshold
+    w4 = bench.make_workload("moving4", 200_000, seed=4)
+    p4 = w4["coal_data"].plan(w4["dist_types"])
+    assert np.array_equal(cloudy.closure_stats(p4, dev(cloudy, w4["mom"])), O.closure_stats(bench.oracle_params("moving4"), w4["mom"]))
+    # Exponential + Gamma + Lognormal, k_range (0.5, 5): two-moment modes have no central-moment check, a Lognormal mode clamps sigma
+    dt = [0, 1, 3]
+    par3, op3, _ = make_case(cloudy, O, dt, [[EPS / 1e6, 5.0], [5.0, 0.0]], (INF, INF, INF), bench.NORMS, k_range=(0.5, 5.0))
+    mom3 = mixed_moments(dt, 150_000, seed=12)
+    rng = np.random.default_rng(8)
+    bad = rng.choice(150_000, 3000, replace=False)
+    mom3[0, bad[:500]] *= -1.0                       # a negative moment
+    mom3[7, bad[500:1500]] = 0.9 * mom3[6, bad[500:1500]] ** 2 / mom3[5, bad[500:1500]]   # Lognormal: M0 M2 < M1^2 -> sigma = eps
+    mom3[5, bad[1500:2000]] = 0.0                    # empty Lognormal mode
+    mom3[4, bad[2000:]] = 4.0 * mom3[3, bad[2000:]] ** 2 / mom3[2, bad[2000:]]          # a wide Gamma mode: k below k_min
+    plan3 = par3.coal_data.plan(dt, k_range=(0.5, 5.0))
+    g3 = cloudy.closure_stats(plan3, dev(cloudy, mom3))
+    w3 = O.closure_stats(op3, mom3)
+    assert np.array_equal(g3, w3), (g3, w3)
+    assert w3[0, 3] >= 500 and w3[2, 1] >= 900 and w3[2, 0] >= 500 and w3[1, 1] >= 900 and w3[0, 1] == 0 and w3[0, 2] == 0
+    # float planes: the counts of the ROUNDED moments (the oracle sees the same float values)
+    pf = wl["coal_data"].plan(wl["dist_types"], dtype=1)
+    mf = wl["mom"].astype(np.float32)
+    gf = cloudy.closure_stats(pf, cloudy.DeviceArray.from_numpy(mf))
+    assert np.array_equal(gf, O.closure_stats(bench.oracle_params("cfg3b"), mf.astype(np.float64)))
+
+
 def test_error_returns_of_the_column_and_integrator_entry_points(gpu_cloudy):
     """Argument checking of the newer entry points: status codes, never exceptions or launches."""
     cloudy = gpu_cloudy
@@ -1788,6 +1886,17 @@ def test_error_returns_of_the_column_and_integrator_entry_points(gpu_cloudy):
     pm = cdm.plan([1, 1], vel=((50.0, 1.0 / 6),))
     u6 = cloudy.DeviceArray.zeros(6, 40)
     assert L.cloudy_rainshaft_ssprk33_steps(pm.handle, 20, 2, 40, u6.ptr, u6.ptr, 150.0, 1.0, 1, None) == E.EINVAL
+    # ... whichever path would serve the call (a single-mode MovingThreshold plan has no threshold pass, and the
+    # one-launch column RHS of round 5 accepted it where the two-launch path returns EINVAL)
+    cd1 = cloudy.CoalescenceData(cloudy.CoalescenceTensor(kc), (3,), (1.0,), bench.NORMS, cloudy.MovingThreshold())
+    pm1 = cd1.plan([1], vel=((50.0, 1.0 / 6),))
+    f3, w3 = cloudy.DeviceArray.zeros(3, 40), cloudy.DeviceArray.zeros(3, 40)
+    for plan_m, arr in ((pm1, u), (pm, u6)):
+        fw, rw = (f3, w3) if plan_m is pm1 else (cloudy.DeviceArray.zeros(6, 40), cloudy.DeviceArray.zeros(6, 40))
+        assert L.cloudy_rainshaft_rhs(plan_m.handle, 20, 2, 40, arr.ptr, 150.0, fw.ptr, rw.ptr, None) == E.EINVAL
+        assert b"FixedThreshold" in L.cloudy_last_error()
+    assert L.cloudy_rainshaft_rhs(no_vel.handle, 20, 2, 40, u.ptr, 150.0, f3.ptr, w3.ptr, None) == E.EINVAL
+    assert L.cloudy_rainshaft_rhs(with_vel.handle, 20, 2, 40, u.ptr, 150.0, None, w3.ptr, None) == E.EINVAL
     assert L.cloudy_ssprk33_steps(pm.handle, 40, 40, u6.ptr, u6.ptr, float("nan"), 1, None) == E.EINVAL
     assert L.cloudy_ssprk33_steps(pm.handle, 40, 40, u6.ptr, u6.ptr, 1.0, -1, None) == E.EINVAL
     assert L.cloudy_plan_specialized(None) == E.EINVAL and L.cloudy_plan_jit_log(None) == b"plan is NULL"

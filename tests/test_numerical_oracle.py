@@ -141,7 +141,7 @@ def test_golden_set_is_what_the_verdict_asked_for():
     # T_m is the 2-D rule with the jump inside; narrow modes), multi-scale mixtures that broke the fixed composite rule, and the
     # two example configurations of round 5 (test/examples/Numerical/n_particles_lognorm.jl; a bench-like Long mixture)
     checked = {c["name"]: c["mpmath_max_rel_diff"] for c in cases if "mpmath_max_rel_diff" in c}
-    assert len(checked) >= MPMATH_CHECKED_MIN and all(v <= 1e-9 for v in checked.values()), checked
+    assert len(checked) >= MPMATH_CHECKED_MIN and all(v <= 1e-10 for v in checked.values()), checked   # (every recorded figure is <= 2.3e-11)
     for must in ("n_particles_lognorm_example", "3gamma_long_bench_like", "1gamma_long_at_threshold", "exp_2gamma_long",
                  "gamma_lognormal_long", "1lognormal_long", "gamma_narrow_lognormal_constant"):
         assert must in checked, must

@@ -419,3 +419,39 @@ def test_bench_lognorm_example_batch_is_the_reference_configuration(oracle):
     assert np.allclose(ntk[2], np.log(2.0), rtol=1e-9) and np.allclose(ntk[5], np.log(2.0), rtol=1e-9)
     assert (ntk[0] >= 5.0 - 1e-9).all() and (ntk[0] <= 20.0 + 1e-9).all() and (ntk[3] >= 0.05 - 1e-12).all() and (ntk[3] <= 0.2 + 1e-12).all()
     assert (np.abs(ntk[1] - np.log(0.1)) <= np.log(2.0) + 1e-9).all() and (np.abs(ntk[4]) <= np.log(2.0) + 1e-9).all()
+
+
+def test_check_moment_consistency_kats_and_closure_stats(oracle, kats, cloudy):
+    """check_moment_consistency (ParticleDistributions.jl:437-449): the reference's seven known answers
+    (test_ParticleDistributions_correctness.jl:221-234) through the oracle and through the host-side Python mirror; and
+    co_closure_stats -- the batch form of the reference's silent clamps and of this check, the checker of
+    cloudy_closure_stats -- against a plain numpy restatement on the bench batch (whose ~1 % degenerate parcels make every
+    counter non-zero)."""
+    import bench
+
+    O = oracle
+    for c in kats["check_moment_consistency"]:
+        assert (O.check_moment_consistency(c["m"]) != 0) == c["throws"], c
+        if c["throws"]:
+            with pytest.raises(ValueError):
+                cloudy.check_moment_consistency(c["m"])
+        else:
+            assert cloudy.check_moment_consistency(c["m"]) is None
+    assert O.check_moment_consistency([0.1, -1.0]) == 1 and O.check_moment_consistency([1.0, 3.0, 2.0]) == 2
+    n = 50_000
+    mom = bench.synth_moments(2, n, seed=5)
+    p = bench.oracle_params("cfg3b")
+    got = O.closure_stats(p, mom)
+    par = O.update_dist_batch(p, mom)
+    eps = np.finfo(np.float64).eps
+    norms = np.array([bench.NORMS[0] * bench.NORMS[1] ** q for q in range(3)])
+    with np.errstate(all="ignore"):
+        for m in range(2):
+            mz = mom[3 * m:3 * m + 3] / norms[:, None]
+            fb = ~((mz[0] > eps) & (mz[1] > eps))
+            assert np.array_equal(fb, (par[3 * m] == 0.0) & (par[3 * m + 1] == 1.0) & (par[3 * m + 2] == 1.0))
+            k = par[3 * m + 2]
+            cm = (mz[2] / mz[0] + (-2.0 * (mz[1] / mz[0])) * (mz[1] / mz[0])) + (mz[1] / mz[0]) ** 2 * (mz[0] / mz[0])
+            want = [fb.sum(), (~fb & (k == eps)).sum(), (~fb & (k == 10.0)).sum(), ((mz < 0).any(axis=0) | (cm < 0)).sum()]
+            assert list(got[m]) == want, (m, got[m], want)
+            assert min(want) > 0   # the batch exercises every counter
