@@ -222,7 +222,8 @@ int cloudy_plan_specialized(const cloudy_plan *plan);
 const char *cloudy_plan_jit_log(const cloudy_plan *plan);
 /* Build check without a GPU: validates `desc`, generates the plan's specialised translation unit(s) and compiles them
  * with hiprtc for `arch` (NULL = "gfx950"); nothing is loaded or launched.  CLOUDY_OK, or CLOUDY_EUNSUPPORTED with the
- * compiler log in cloudy_last_error(). */
+ * compiler log in cloudy_last_error().  arch = "source-only": every translation unit of the plan is generated and none compiled
+ * (the host-side sanitizer run of the tests). */
 int cloudy_jit_selfcheck(const cloudy_plan_desc *desc, const char *arch);
 /* Layout of cloudy_plan_desc as this library was compiled: for each field, in declaration order, name / byte offset /
  * byte size.  A binding in another language (julia/CloudyHIP.jl, the ctypes mirror) checks its own struct against this

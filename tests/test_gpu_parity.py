@@ -1437,12 +1437,15 @@ def test_column_integrator_picks_a_workgroup_size_whose_lds_fits(gpu_cloudy, ora
     cloudy = gpu_cloudy
     thr = tuple(10.0 ** (-10 + i) for i in range(N - 1)) + (INF,)
     par, op, _ = make_case(cloudy, oracle, [1] * N, [[EPS / 1e6, 5.0], [5.0, 0.0]], thr, bench.NORMS, vel=((50.0, 1.0 / 6),))
-    par.nz, par.dz, par.dt = nz, 3000.0 / nz, 0.02 if nz > 50 else 0.5
-    n = nz * ncol
-    u0 = bench.synth_moments(min(N, 4), n, seed=77)
+    par.nz, par.dz, par.dt = nz, 3000.0 / nz, 0.05 if nz > 50 else 0.5
+    # a slab of every mode in the upper half of each column (as rainshaft_gamma_mixture.jl:31-37), one amplitude per column
+    amp = bench.synth_moments(min(N, 4), 1, seed=77, degenerate_frac=0.0)[:, 0]
     if N > 4:   # (synth_moments has four size ranges: further modes repeat the last one, a decade up each)
-        u0 = np.concatenate([u0] + [u0[9:12] * np.array([[0.1], [1.0], [100.0]]) * 10.0 ** (m - 3) for m in range(4, N)], axis=0)
-    u0 = np.ascontiguousarray(u0[: 3 * N])
+        amp = np.concatenate([amp] + [amp[9:12] * np.array([0.1, 1.0, 100.0]) * 10.0 ** (m - 3) for m in range(4, N)])
+    amp = amp[: 3 * N]
+    z = (np.arange(nz) + 0.5) * par.dz
+    at = ((z >= 0.5 * z.max()) & (z < 0.75 * z.max())).astype(float)
+    u0 = np.ascontiguousarray(np.concatenate([np.outer(amp * (0.3 + 0.2 * c), at) for c in range(ncol)], axis=1))
     rhs = cloudy.make_rainshaft_rhs()
     u = u0.copy()
     for _ in range(2):
