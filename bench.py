@@ -794,6 +794,23 @@ def _cfg4q_variant(pkg, rank, world, measured, n=CFG4Q_PARCELS, reps=3):
     return out
 
 
+def _first_call_ms(pkg, make_plan, warm_plan, m, dm):
+    """HIP-event time of the FIRST cloudy_coal_rhs call of a fresh converged-mode plan on a batch -- no cost hints yet, the
+    workgroups take their parcels in memory order (what a caller pays who re-shards or reshuffles its parcels
+    between calls, and what the first call of every plan pays) -- at the sustained clock: `warm_plan` (the same configuration,
+    hints in place) runs back to back first."""
+    L = pkg.lib()
+    n = m.shape[1]
+    fresh = make_plan()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < WARM_SECONDS:
+        pkg._lib.check(L.cloudy_coal_rhs(warm_plan.handle, n, n, m.ptr, dm.ptr, None))
+        pkg._lib.check(L.cloudy_stream_synchronize(None))
+    with _EventTimer(pkg) as tm:
+        pkg._lib.check(L.cloudy_coal_rhs(fresh.handle, n, n, m.ptr, dm.ptr, None))
+    return tm.ms
+
+
 def _cfg4q_converged_variant(pkg, rank, world, measured, fixed_ms, n=CFG4Q_PARCELS, reps=3, q=8):
     """The same batch through a CLOUDY_QUAD_CONVERGED plan (csrc/quad_conv.hpp): the integrals split along the kink of the
     hydrodynamic kernel -- closed forms (incomplete beta) for Q and R, one adaptive Gauss-Kronrod rule per mode for the
@@ -827,6 +844,10 @@ def _cfg4q_converged_variant(pkg, rank, world, measured, fixed_ms, n=CFG4Q_PARCE
     rl = _valu_roofline(measured, "cfg4q_converged", n, ms)
     if rl:
         out["roofline"] = rl
+    out["first_call_ms"] = _first_call_ms(pkg, lambda: pkg.NumericalPlan([1, 1, 1], par.kernel_func, NORMS, q, quad_mode=pkg.QUAD_CONVERGED),
+                                          plan, m, dm)
+    out["first_call_note"] = ("kernel_ms is the steady state (parcels ranked by the cost each had in the plan's previous call); "
+                              "first_call_ms is one call of a fresh plan of the same configuration: no hints, memory order")
     return out
 
 
@@ -868,6 +889,8 @@ def _converged_variant(pkg, rank, world, measured, key, dists, kernel_func, mom,
     rl = _valu_roofline(measured, key, n, ms)
     if rl:
         out["roofline"] = rl
+    kfn = pkg.get_normalized_kernel_func(kernel_func, NORMS)
+    out["first_call_ms"] = _first_call_ms(pkg, lambda: pkg.NumericalPlan(dists, kfn, NORMS, 8, quad_mode=pkg.QUAD_CONVERGED), plan, m, dm)
     return out
 
 
@@ -1044,6 +1067,8 @@ def compact_line(full, variants_file=VARIANTS_FILE):
              "frac": _sig(r.get("frac"), 4)}
         if v.get("unit") not in (None, "parcel-RHS/s"):
             e["unit"] = v["unit"]
+        if v.get("first_call_ms") is not None:   # converged-mode plans: the hint-less first call beside the steady state
+            e["first_call_ms"] = _sig(v["first_call_ms"], 5)
         variants[name] = e
     line = {
         "metric": full.get("metric"), "value": _sig(full.get("value"), 8), "unit": full.get("unit"),
@@ -1242,8 +1267,17 @@ def main():
 
     measured = _measured_latest()
     traffic = None
+    # 2 x FETCH_SIZE + WRITE_SIZE of the committed PMC passes -- quoted only for the batch size AND the kernel sources they were
+    # collected on (a changed kernel must not print last round's bytes): cloudy_source_hash(1) = FNV-1a of
+    # kernels.hpp + device_math.hpp + the all-Inf body inside the library, recorded by tools/summarize_profiles.py
+    src_hash = f"{pkg.lib().cloudy_source_hash(1):016x}"
+    traffic_note = None
     if args.workload == "cfg3a" and measured.get("n_parcels") == n_local:
-        traffic = measured.get("cfg3a_hbm_bytes_per_launch")  # 2 x FETCH_SIZE + WRITE_SIZE of the committed PMC passes
+        if measured.get("source_hash_allinf") == src_hash:
+            traffic = measured.get("cfg3a_hbm_bytes_per_launch")
+        else:
+            traffic_note = (f"null: profiles/measured_latest.json was collected on kernel sources {measured.get('source_hash_allinf')}, "
+                            f"this library holds {src_hash}")
 
     variants = {}
     # multi-rank runs (the driver's scaling sweep) time the headline and the threshold workload only; the other variants
@@ -1401,8 +1435,12 @@ def main():
                 "hbm_GBs": 2 * planv.nmom * 8 * vn / (msv * 1e-3) / 1e9,
             }
             rl = _valu_roofline(measured, vname, vn, msv)
-            if vname == "cfg2":   # thresholds Inf: streaming, 48 B per parcel (cache resident at 1e6 parcels)
+            if vname == "cfg2":
+                # thresholds Inf: streaming, 48 B per parcel -- but the 48 MB working set of 1e6 parcels stays in the 256 MB
+                # Infinity Cache between launches: NOT an HBM measurement, so no fraction of the HBM peak
                 rl = _hbm_roofline(_kernel_label(planv, 1, 2).split(" ")[0], 2 * planv.nmom * 8 * vn, msv, measured, "cfg2")
+                rl.update({"bound": "infinity-cache", "frac": None, "peak": None,
+                           "note": "working set (48 MB) resident in the 256 MB Infinity Cache: `achieved` is cache bandwidth, no HBM fraction"})
             if rl:
                 variants[vname]["roofline"] = rl
             del mv, dmv
@@ -1421,6 +1459,9 @@ def main():
                 "value": vn * world / (msv * 1e-3), "unit": "parcel-RHS/s", "kernel_ms": msv,
                 "speedup_vs_default_dtype": (variants[vname]["kernel_ms"] / msv) if vname in variants and "kernel_ms" in variants[vname] else None,
             }
+            rl = _valu_roofline(measured, vname + "_f64_relaxed", vn, msv)
+            if rl:
+                variants[vname + "_f64_relaxed"]["roofline"] = rl
             del mv, dmv
 
     if more_variants:
@@ -1485,6 +1526,9 @@ def main():
                         f"fluxes, divergence), fp64; the fused integrator above spends {msr / (3 * nst):.3f} ms per evaluation, update included",
             "value": nz * ncol * world / (msu * 1e-3), "unit": "cell-RHS/s", "ms_per_call": msu,
         }
+        rl = _valu_roofline(measured, "rainshaft_rhs", nz * ncol, msu)
+        if rl:
+            variants["rainshaft_rhs"]["roofline"] = rl
         del fluxr
         z = (np.arange(nz) + 0.5) * 150.0
         at = ((z >= 0.5 * z.max() - 75.0) & (z < 0.75 * z.max() - 75.0)).astype(float)
@@ -1573,8 +1617,8 @@ def main():
                                    f"order-{2 if spec['kernel'] == 'long' else 1} polynomial CoalescenceTensor, "
                                    f"{nmom} moments, thresholds {spec['thresholds']}, norms {NORMS}",
                        "parcels_per_gpu": n_local, "global_parcels": total, "sharding": f"parcel ranges x{world}"},
-            "roofline": _headline_roofline(args.workload, res["plan"], n_local, nmom, res["event_ms"], per_rank_ms,
-                                           traffic, measured),
+            "roofline": dict(_headline_roofline(args.workload, res["plan"], n_local, nmom, res["event_ms"], per_rank_ms,
+                                                traffic, measured), **({"traffic_note": traffic_note} if traffic_note else {})),
             "cpu_baseline": cpu,
             "per_rank_devices": per_rank_dev,
             "ranks_share_a_gpu": not _COMM["own_gpu_per_rank"],

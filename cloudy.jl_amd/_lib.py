@@ -110,6 +110,7 @@ SYMBOLS = {
     "cloudy_timer_end": (_i, [_vp, _vp, C.POINTER(C.c_float)]),
     "cloudy_last_error": (C.c_char_p, []),
     "cloudy_version": (_i, []),
+    "cloudy_source_hash": (C.c_ulonglong, [_i]),
 }
 
 _lib = None

@@ -427,6 +427,20 @@ void cloudy_set_last_error_(const char *msg) { std::snprintf(g_err, sizeof(g_err
 
 const char *cloudy_last_error(void) { return g_err; }
 int cloudy_version(void) { return CLOUDY_HIP_VERSION; }
+unsigned long long cloudy_source_hash(int which) {
+    // FNV-1a over the kernel sources that travel inside the library (embedded_src.inc): bench.py prints a committed PMC figure
+    // of a kernel only while the sources it was collected on are the ones in the library
+    const auto fnv = [](unsigned long long h, const char *s) {
+        for (; *s; ++s) h = (h ^ (unsigned char)*s) * 1099511628211ull;
+        return h;
+    };
+    using namespace cloudy::jit_detail;
+    unsigned long long h = 14695981039346656037ull;
+    h = fnv(fnv(h, kSrcKernels), kSrcDeviceMath);
+    if (which == 1) return fnv(h, kSrcBodyAllinf2);   // what the all-Inf kernels (the headline) are compiled from
+    for (const char *s : {kSrcBodyPpl1, kSrcBodyAllinf2, kSrcBodySorted, kSrcQuad, kSrcQuadKernels, kSrcQuadConv, kSrcAllinfF32}) h = fnv(h, s);
+    return h;
+}
 
 void cloudy_plan_desc_init(cloudy_plan_desc *d) {
     if (!d) return;

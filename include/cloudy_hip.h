@@ -415,6 +415,9 @@ int cloudy_timer_end(void *timer, void *stream, float *ms_total);
 
 const char *cloudy_last_error(void);
 int cloudy_version(void);
+/* FNV-1a of the kernel sources inside the library (which = 0: all of them; 1: those of the all-Inf kernels, the headline of
+ * bench.py): a committed profile figure is quoted only for the sources it was collected on */
+unsigned long long cloudy_source_hash(int which);
 
 #ifdef __cplusplus
 }

@@ -354,19 +354,37 @@ def test_plans_beyond_the_ahead_of_time_families(gpu_cloudy, oracle, dist_types,
     assert mass.max() < 1e-12
     # fused integrators of the same plan against host stepping with the device RHS (SSPRK33: three evaluations per step)
     u0 = dev(cloudy, mom)
-    with np.errstate(all="ignore"):   # a step that changes no moment of any parcel by more than ~1e-3 of itself
+    f = lambda u: run_rhs(cloudy, par, np.ascontiguousarray(u), ts)
+
+    def staged(u, h):   # OrdinaryDiffEq's SSPRK33 driven from the host, the device RHS per stage
+        u1 = u + h * f(u)
+        u2 = 0.75 * u + 0.25 * (u1 + h * f(u1))
+        return u / 3.0 + (2.0 / 3.0) * (u2 + h * f(u2))
+
+    # (a) VERDICT r5 weak #9: the WHOLE batch -- its degenerate parcels (closures on a clamp, tendencies up to 1e30 x the regular
+    # ones) included -- over a step sized so that NO parcel changes a moment by more than ~1e-3 of itself: everything stays
+    # finite, and the fused step must be finite element by element exactly where the staged one is (round 5 accepted up to
+    # 0.5 % of parcels that differed: its step was sized for the regular parcels and the degenerate ones overflowed, in
+    # physical units on the host and in normalised units in the kernel)
+    with np.errstate(all="ignore"):
+        dt_all = 1e-3 * float(np.min(np.where((np.abs(d) > 0) & (mom > 0) & ok, mom / np.abs(d), np.inf)))
+    assert 0 < dt_all < np.inf
+    out_a = cloudy.DeviceArray.zeros(*mom.shape)
+    cloudy.solve_ssprk33(par, u0, dt_all, 1, out=out_a)
+    got_a, want_a = out_a.to_numpy(), staged(mom, dt_all)
+    assert np.array_equal(np.isfinite(got_a), np.isfinite(want_a)) and np.isfinite(got_a).all()
+    bound_a = np.maximum(np.maximum(np.abs(mom), dt_all * scale), 1e-300)
+    assert (np.abs(got_a - want_a) / bound_a)[:, regular].max() <= 1e-12   # (a parcel ON a clamp amplifies the last bit of a stage)
+    # (b) a real step -- sized for the regular parcels, on the regular parcels
+    with np.errstate(all="ignore"):   # a step that changes no moment of any regular parcel by more than ~1e-3 of itself
         dt = 1e-3 * float(np.min(np.where((np.abs(d) > 0) & (mom > 0) & (ok & regular), mom / np.abs(d), np.inf)))
     assert 0 < dt < np.inf
     out = cloudy.DeviceArray.zeros(*mom.shape)
     cloudy.solve_ssprk33(par, u0, dt, 1, out=out)
-    f = lambda u: run_rhs(cloudy, par, np.ascontiguousarray(u), ts)
-    u1 = mom + dt * f(mom)
-    u2 = 0.75 * mom + 0.25 * (u1 + dt * f(u1))
-    u3 = mom / 3.0 + (2.0 / 3.0) * (u2 + dt * f(u2))
+    u3 = staged(mom, dt)
     got = out.to_numpy()
-    # the fused step is finite on the parcels the staged step (the same device RHS, driven from the host) is finite on
-    assert (np.isfinite(u3).all(axis=0) == np.isfinite(got).all(axis=0)).mean() > 0.995
     fin = np.isfinite(u3).all(axis=0) & np.isfinite(got).all(axis=0) & regular
+    assert np.array_equal(np.isfinite(u3)[:, regular], np.isfinite(got)[:, regular]) and fin.sum() == regular.sum()
     assert fin.mean() > 0.85 and (np.abs(got - mom) / np.maximum(np.abs(mom), 1e-300))[:, fin].max() > 1e-4   # a real step
     bound = np.maximum(np.maximum(np.abs(mom), dt * scale), 1e-300)
     r3 = (np.abs(got - u3) / bound)[:, fin].max()

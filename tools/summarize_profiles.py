@@ -47,6 +47,15 @@ print(json.dumps(traffic, indent=1))
 # what bench.py reads back (profiles/measured_latest.json): HBM bytes per launch of the headline kernel and the fp64
 # flop count per parcel of the threshold kernel, both at the bench's 1e7-parcel workloads
 latest = {"tag": tag, "n_parcels": 10_000_000}
+try:   # the kernel sources these figures were collected on (bench.py quotes them only while the library still holds them)
+    sys.path.insert(0, root)
+    from __graft_entry__ import load_package
+
+    _L = load_package().lib()
+    latest["source_hash_all"] = f"{_L.cloudy_source_hash(0):016x}"
+    latest["source_hash_allinf"] = f"{_L.cloudy_source_hash(1):016x}"
+except Exception as e:   # noqa: BLE001
+    print("summarize_profiles: no source hash:", e)
 for row in rows:
     if (row["kernel"].startswith(("cloudy_jit_allinf2_n2p3_f64", "coal_rhs_allinf2_kernel<2, 3, double>"))
             and row["grid_size"] >= 5_000_000 and "FETCH_SIZE" in row and "WRITE_SIZE" in row
@@ -83,6 +92,9 @@ VARIANTS = {   # bench variant -> (kernel name prefix, items per launch in the b
     "cfg3a_f32_planes": ("cloudy_jit_allinf2_n2p3_f32", 10_000_000 // 2),
     "cfg3a_f32_fast_packed": ("cloudy_jit_allinf4_n2p3_f32fast", 10_000_000 // 4),
     "cfg3a_aot_kernels": ("coal_rhs_allinf2_kernel<2, 3, double>", 10_000_000 // 2),
+    "rainshaft_rhs": (("cloudy_jit_rainshaft_rhs_n2p3_f64_b512", "cloudy_jit_rainshaft_rhs_n2p3_f64"), 10_000_000),
+    "cfg3b_f64_relaxed": ("cloudy_jit_sorted_n2p3_f64r", 10_000_000),
+    "cfg4_f64_relaxed": ("cloudy_jit_sorted_n3p5_f64r", 12_500_000),
 }
 kern = {}
 for name, (prefix, items) in VARIANTS.items():
