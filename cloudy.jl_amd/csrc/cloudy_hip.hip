@@ -243,7 +243,7 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
         double dt = r.dt;
         int n_steps = r.n_steps;
         if (h.coal_style == CLOUDY_NUMERICAL_COAL) {
-            const unsigned qb = h.q.mode == QUAD_CONVERGED ? (unsigned)kBlock : (unsigned)quad_block(h.q.nq);
+            const unsigned qb = h.q.mode == QUAD_CONVERGED ? (unsigned)jit_conv_block_size(h) : (unsigned)quad_block(h.q.nq);
             ConvHints hints = h.q.mode == QUAD_CONVERGED ? conv_hints(plan, n, r.stream) : ConvHints{};
             void *args[] = {&n, &ld, &in, &out, &dt, &n_steps, &hints.p1, &hints.p2};
             return hipModuleLaunchKernel(plan->int_tsit5, (unsigned)((n + qb - 1) / qb), 1, 1, qb, 1, 1, 0, r.stream, args, nullptr);
@@ -253,7 +253,7 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
         return hipModuleLaunchKernel(plan->int_tsit5, g1, 1, 1, kBlock, 1, 1, 0, r.stream, args, nullptr);
     }
     if (h.coal_style == CLOUDY_NUMERICAL_COAL) {
-        const unsigned qb = h.q.mode == QUAD_CONVERGED ? (unsigned)kBlock : (unsigned)quad_block(h.q.nq);
+        const unsigned qb = h.q.mode == QUAD_CONVERGED ? (unsigned)jit_conv_block_size(h) : (unsigned)quad_block(h.q.nq);
         if (r.op == OP_SSPRK33) {
             double dt = r.dt;
             int n_steps = r.n_steps;
@@ -264,7 +264,8 @@ hipError_t launch_jit(const cloudy_plan *plan, const LaunchReq &r) {
         }
         ConvHints hints = h.q.mode == QUAD_CONVERGED ? conv_hints(plan, n, r.stream) : ConvHints{};
         void *args[] = {&n, &ld, &in, &out, &hints.p1, &hints.p2};
-        return hipModuleLaunchKernel(plan->jit.quad, (unsigned)((n + qb - 1) / qb), 1, 1, qb, 1, 1, 0, r.stream, args,
+        const size_t per_wg = (size_t)qb * (size_t)(h.q.mode == QUAD_CONVERGED ? h.jit_conv_rounds : 1);
+        return hipModuleLaunchKernel(plan->jit.quad, (unsigned)((n + per_wg - 1) / per_wg), 1, 1, qb, 1, 1, 0, r.stream, args,
                                      nullptr);
     }
     if (r.op == OP_SSPRK33) {
@@ -589,6 +590,8 @@ int build_host_plan(const cloudy_plan_desc *d, cloudy_plan **out, std::vector<do
             h.vel_n[v][1] = d->vel[v][1];
         }
         nodes.clear();
+        h.jit_conv_bs = jit_conv_block_size_resolve(h);
+        h.jit_conv_rounds = jit_conv_rounds_resolve(h);
         *out = p;
         return CLOUDY_OK;
     }
@@ -828,7 +831,7 @@ int cloudy_jit_selfcheck(const cloudy_plan_desc *d, const char *arch) {
         delete p;
         return bytes > 0 ? CLOUDY_OK : fail(CLOUDY_EUNSUPPORTED, "no source generated");
     }
-    bool ok = jit_compile(jit_source(p->h, 0), a, !numerical && p->h.mode == MODE_ALLINF, code, log);
+    bool ok = jit_compile(jit_source(p->h, 0), a, numerical ? jit_quad_licm_off(p->h) : p->h.mode == MODE_ALLINF, code, log);
     if (ok && numerical) ok = jit_compile(jit_source(p->h, 1), a, true, code, log);  // fused SSPRK33 of the quadrature plan
     if (ok && !numerical && p->h.mode != MODE_ALLINF) ok = jit_compile(jit_source(p->h, 1), a, true, code, log);
     if (ok && !numerical) ok = jit_compile(jit_source(p->h, 2), a, false, code, log);  // rainshaft cell body

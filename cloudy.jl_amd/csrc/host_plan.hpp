@@ -31,6 +31,8 @@ struct HostPlan {
     double inv_map[2] = {0.0, 0.0}, inv_klo = 0.0;
     double inv_tab[CLOUDY_MAX_MODES][16] = {{0}};
     int device = 0;
+    int jit_conv_rounds = 1;  // parcels per lane of the plan-time compiled converged-mode RHS kernel (quad_kernels.hpp: ROUNDS)
+    int jit_conv_bs = 0;    // ... of the plan-time compiled converged-mode kernels (NumericalCoalStyle), likewise
     int jit_sorted_bs = 0;  // workgroup size of the plan-time compiled threshold kernels, fixed at plan creation (jit.hpp)
     int force_ppl1 = 0;  // CLOUDY_HIP_PPL1=1: always the one-parcel-per-lane ALLINF kernel (A/B timing)
     double *nodes_dev = nullptr;                        // [n_nodes][kNodeStride]

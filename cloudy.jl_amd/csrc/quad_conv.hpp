@@ -34,6 +34,14 @@
 
 namespace cloudy {
 
+// Workgroup size of the converged-mode kernels: 256 ahead of time; a kernel compiled for its plan gets the size the plan was
+// created with (jit.hpp: jit_conv_block_size, HostPlan::jit_conv_bs) as a macro in front of this header -- the LDS rows of this
+// file are one slot per lane wide, and the rankings order that many parcels.
+#ifndef CLOUDY_CONV_BLOCK
+#define CLOUDY_CONV_BLOCK 256
+#endif
+constexpr int kConvBlock = CLOUDY_CONV_BLOCK;
+
 // continued fraction of the incomplete beta function (DLMF 8.17.22), converging for x < (a+1)/(a+b+2):
 //   h = 1 / (1 + e_1 / (1 + e_2 / (1 + ...))),   e_1 = -(a+b) x / (a+1),
 //   e_2m = m (b-m) x / ((a+2m-1)(a+2m)),   e_2m+1 = -(a+m)(a+b+m) x / ((a+2m)(a+2m+1))
@@ -677,7 +685,7 @@ __device__ static const double kLongDct[kLongNT][kLongNT] = {
 // the Chebyshev coefficients of g for shape k, left in the lane's own LDS slots sh[row0 + r][lane] (conflict-free, no barrier:
 // a lane reads what it wrote)
 template <int NROW>
-__device__ __forceinline__ void conv_long_tab_build(double k, double (&sh)[NROW][kBlock], int row0) {
+__device__ __forceinline__ void conv_long_tab_build(double k, double (&sh)[NROW][kConvBlock], int row0) {
     double c[kLongNT];
 #pragma unroll
     for (int r = 0; r < kLongNT; ++r) c[r] = 0.0;
@@ -695,7 +703,7 @@ __device__ __forceinline__ void conv_long_tab_build(double k, double (&sh)[NROW]
 // c0 = 1 / (k B(k, k)), rB = B(k+1, k+1) / B(k, k)
 template <int NROW>
 __device__ __forceinline__ double conv_long_G_mid_tab(const QArgs &Q, double k, double c0, double rB, double s, double lx,
-                                                      const double (&sh)[NROW][kBlock], int row0) {
+                                                      const double (&sh)[NROW][kConvBlock], int row0) {
     const double xt = Q.kf[0], cb = Q.kf[1], ca = Q.kf[2];
     const double x = xt * recip_fast(s), y = 1.0 - x;   // y in (0, 1/2)
     const double z2 = fma(8.0, y, -2.0);                // 2 z, z = 4 y - 1 in [-1, 1]
@@ -848,7 +856,7 @@ __device__ __forceinline__ void conv_T_lognormal_poly(const QArgs &Q, double n, 
                                                       const double (&totals)[3], double &T0, double &T1, double &T2, int &cost) {
     static_assert(KIND == KF_CONSTANT || KIND == KF_LINEAR, "polynomial kernels only");
     constexpr double gtop = KIND == KF_LINEAR ? 1.0 : 0.0, ln2 = 0.6931471805599453;
-    __shared__ double sh_q[kLnQTab][kBlock];
+    __shared__ double sh_q[kLnQTab][kConvBlock];
     const int lane = threadIdx.x;
     const double L0 = fma(-8.5, sg, mu), L1 = mu + 8.5 * sg + (gtop + 2.0) * (sg * sg) + ln2;
     const double c1 = 1.0 / (sg * sg), h = fmin(sg, 0.5), rh = 1.0 / h, pref = 0.5 * (n * n);
@@ -1053,7 +1061,7 @@ template <int N, int KIND, bool LTAB, int PHASE, int NROW>
 __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensity (&lg)[N],
                                               const ConvRule<(N > 1 ? N - 1 : 1)> (&rb)[(N > 1 ? N - 1 : 1)],
                                               double (&Traw)[(N > 1 ? N - 1 : 1)][3], bool (&midneed)[(N > 1 ? N - 1 : 1)],
-                                              const double (&gtab)[NROW][kBlock], int &cost) {
+                                              const double (&gtab)[NROW][kConvBlock], int &cost) {
     constexpr int NM = N > 1 ? N - 1 : 1, NR = NM;
     static_assert((KIND == KF_LONG) == (PHASE != 0), "the Long kernel's rules are walked in two phases, the others in one");
     // The Long kernel's G(s) behaves like (s - x_t)^k just above x_t (the Beta(k, k) law of tau ends like tau^(k-1)), so K15
@@ -1385,7 +1393,7 @@ __device__ __forceinline__ void conv_long_phase2_split(const KArgs<N, 1> &A, con
                                                        const double (&th)[N], const double (&kk)[N],
                                                        const ConvRule<(N > 1 ? N - 1 : 1)> (&rb)[(N > 1 ? N - 1 : 1)],
                                                        double (&Traw)[(N > 1 ? N - 1 : 1)][3],
-                                                       const bool (&midneed)[(N > 1 ? N - 1 : 1)], double (&xt)[NROW][kBlock],
+                                                       const bool (&midneed)[(N > 1 ? N - 1 : 1)], double (&xt)[NROW][kConvBlock],
                                                        ConvSplit &sp) {
     constexpr int NM = N > 1 ? N - 1 : 1;
     static_assert(NROW >= 3 * N + 6 * NM + 1 && NROW >= NM * kLongNT, "exchange rows");
@@ -1410,7 +1418,7 @@ __device__ __forceinline__ void conv_long_phase2_split(const KArgs<N, 1> &A, con
     xt[3 * N + 6 * NM][t] = double(flags);
     // ---- the second ranking: by the trips phase 2 took the last time (regime_rank brackets itself with barriers: the rows
     // above are visible once it returns)
-    regime_rank<kBlock>(sp.valid, sp.p2_hint > kBlock - 2 ? kBlock - 2 : sp.p2_hint, sp.sh_cnt, sp.sh_perm);
+    regime_rank<kConvBlock>(sp.valid, sp.p2_hint > kConvBlock - 2 ? kConvBlock - 2 : sp.p2_hint, sp.sh_cnt, sp.sh_perm);
     const int src = sp.sh_perm[t];
     double n2[N], th2[N], k2[N], sc2[NM][3], T2[NM][3];
 #pragma unroll
@@ -1567,7 +1575,7 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
             // wrote): the 3N partial tendencies of phase 1 and the prefactors -- registers the allocator would otherwise
             // spill around (and, at three waves per SIMD, inside) the loop: 11 x the algorithmic HBM traffic in scratch
 #ifndef CLOUDY_CONV_NO_PARK
-            __shared__ double sh_park[3 * N + (N > 1 ? N - 1 : 1)][kBlock];
+            __shared__ double sh_park[3 * N + (N > 1 ? N - 1 : 1)][kConvBlock];
             const int t = threadIdx.x;
 #pragma unroll
             for (int k = 0; k < N; ++k)
@@ -1579,7 +1587,7 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
             constexpr bool kTabFits = KIND == KF_LONG && N <= 3;
             constexpr int kXRows = 3 * N + 6 * NM + 1;   // SPLIT: what crosses between the two lanes of a parcel
             constexpr int kTabRows = kTabFits ? (SPLIT && kXRows > NM * kLongNT ? kXRows : NM * kLongNT) : 1;
-            __shared__ double sh_gtab[kTabRows][kBlock];
+            __shared__ double sh_gtab[kTabRows][kConvBlock];
             bool midneed[NM];
 #pragma unroll
             for (int j = 0; j < NM; ++j) midneed[j] = false;

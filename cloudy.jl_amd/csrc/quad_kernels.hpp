@@ -249,13 +249,101 @@ __device__ __forceinline__ void quad_store_hints(unsigned char *__restrict__ hin
     }
 }
 
-template <int N, int KIND, int NQ, typename TIO, bool CONV = false, bool SPLIT = false>
+// ROUNDS (round 6, an experiment switch: CLOUDY_HIP_CONV_ROUNDS): a workgroup of QB threads takes ROUNDS x QB parcels, ranks ALL of
+// them by their hints, and wave w walks the groups of 64 in the order w, 2W - 1 - w, 2W + w, ... (W waves): the cheapest group
+// with the dearest one, so that the waves of a workgroup finish together.  A workgroup keeps its LDS and its wave slots until its
+// LAST wave ends, and the ranking makes the waves of a workgroup as different as it can: with one group per wave the slots of the
+// cheap waves idle (VALU busy 0.93 at 256 threads, 0.78 at 512, 28 ms at 1024 where ranking alone predicts the opposite order).
+// No barrier but the ranking's; results do not depend on which lane or round computes a parcel.
+template <int QB, int ROUNDS>
+__device__ __forceinline__ void quad_rank_rounds(size_t n, size_t base, const unsigned char *__restrict__ hint,
+                                                 const unsigned char *__restrict__ hint2, bool key44, unsigned int *sh_cnt /*[QB]*/,
+                                                 unsigned short *sh_perm /*[ROUNDS * QB]*/) {
+    static_assert(QB >= 256, "one counter per hint value");
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    sh_cnt[t] = 0u;
+    __syncthreads();
+    unsigned int pos[ROUNDS];
+    int bucket[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const size_t i = base + (size_t)r * QB + t;
+        const bool valid = i < n;
+        int hb = (valid && hint != nullptr) ? (int)hint[i] : 0;
+        if (key44 && hint2 != nullptr) {
+            const int p2 = valid ? (int)hint2[i] : 0, p1 = hb >> 2;
+            hb = ((p2 > 15 ? 15 : p2) << 4) | (p1 > 15 ? 15 : p1);
+        }
+        bucket[r] = valid ? (hb > QB - 2 ? QB - 2 : hb) : QB - 1;
+        pos[r] = atomicAdd(&sh_cnt[bucket[r]], 1u);
+    }
+    __syncthreads();
+    const unsigned int c = sh_cnt[t];
+    unsigned int incl = c;
+    const int lane = t & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned int up = (unsigned int)__builtin_amdgcn_ds_bpermute(((lane - d) & 63) << 2, (int)incl);
+        if (lane >= d) incl += up;
+    }
+    __shared__ unsigned int sh_wave_tot[QB / 64];
+    if (lane == 63) sh_wave_tot[t >> 6] = incl;
+    __syncthreads();
+    unsigned int offs = 0;
+#pragma unroll
+    for (int w = 0; w < QB / 64; ++w)
+        if (w < (t >> 6)) offs += sh_wave_tot[w];
+    sh_cnt[t] = offs + incl - c;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) sh_perm[sh_cnt[bucket[r]] + pos[r]] = (unsigned short)(r * QB + t);
+    __syncthreads();
+}
+
+template <int N, int KIND, typename TIO, int ROUNDS>
+__device__ __forceinline__ void coal_rhs_quad_rounds(const KArgs<N, 1> &A, const QArgs &Q, const double *__restrict__ tab, size_t n,
+                                                     size_t ld, const TIO *__restrict__ in, TIO *__restrict__ out,
+                                                     unsigned char *__restrict__ hint, unsigned char *__restrict__ hint2) {
+    constexpr int QB = kConvBlock, W = QB / 64;
+    __shared__ unsigned int sh_cnt[QB];
+    __shared__ unsigned short sh_perm[ROUNDS * QB];
+    const size_t base = (size_t)blockIdx.x * (QB * ROUNDS);
+    quad_rank_rounds<QB, ROUNDS>(n, base, hint, hint2, true, sh_cnt, sh_perm);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+#pragma unroll 1
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int group = (r & 1) ? (r + 1) * W - 1 - w : r * W + w;   // w, 2W - 1 - w, 2W + w, 4W - 1 - w, ...
+        const size_t i = base + sh_perm[group * 64 + l];
+        if (i < n) {
+            double nn[N], th[N], kk[N], acc[N][3];
+            load_parcel<N, 1, TIO>(A, i, ld, in, nn, th, kk);
+            int cost = 0;
+            conv_coal_ints<N, KIND>(A, Q, tab, nn, th, kk, acc, cost);
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const int off = A.off[k];
+                out[(size_t)(off + 0) * ld + i] = (TIO)(acc[k][0] * A.out_scale[3 * k + 0]);
+                out[(size_t)(off + 1) * ld + i] = (TIO)(acc[k][1] * A.out_scale[3 * k + 1]);
+                if (A.np[k] == 3) out[(size_t)(off + 2) * ld + i] = (TIO)(acc[k][2] * A.out_scale[3 * k + 2]);
+            }
+            if (hint != nullptr) quad_store_hints<KIND>(hint, hint2, i, cost);
+        }
+    }
+}
+
+template <int N, int KIND, int NQ, typename TIO, bool CONV = false, bool SPLIT = false, int ROUNDS = 1>
 __device__ __forceinline__ void coal_rhs_quad_body(const KArgs<N, 1> &A, const QArgs &Q, const double *__restrict__ tab,
                                                    size_t n, size_t ld, const TIO *__restrict__ in,
                                                    TIO *__restrict__ out, unsigned char *__restrict__ hint = nullptr,
                                                    unsigned char *__restrict__ hint2 = nullptr) {
-    constexpr int QB = NQ ? quad_block(NQ) : kBlock;
+    constexpr int QB = NQ ? quad_block(NQ) : (CONV ? kConvBlock : kBlock);
     static_assert(!SPLIT || (CONV && KIND == KF_LONG), "SPLIT: the Long kernel's converged mode");
+    static_assert(ROUNDS == 1 || (CONV && !SPLIT), "ROUNDS: the barrier-free converged kernels");
+    if constexpr (ROUNDS > 1) {
+        coal_rhs_quad_rounds<N, KIND, TIO, ROUNDS>(A, Q, tab, n, ld, in, out, hint, hint2);
+        return;
+    }
     __shared__ unsigned int sh_cnt[CONV ? QB : 1];
     __shared__ unsigned short sh_perm[CONV ? QB : 1];
     const size_t i = quad_ranked_parcel<QB>(n, CONV ? hint : nullptr, sh_cnt, sh_perm, hint2, !SPLIT);
@@ -316,7 +404,7 @@ __device__ __forceinline__ void quad_ssprk33_body(const KArgs<N, 1> &A, const QA
                                                   unsigned char *__restrict__ hint2 = nullptr) {
     // (converged mode: the lane keeps, for the whole call, the parcel its hint ranks it to -- the cost of a parcel moves little
     // over a few stages -- and leaves the cost of its last evaluation behind; coal_rhs_quad_body shares the bytes)
-    constexpr int QB = NQ ? quad_block(NQ) : kBlock;
+    constexpr int QB = NQ ? quad_block(NQ) : (CONV ? kConvBlock : kBlock);
     const size_t i = quad_ranked_parcel<QB>(n, CONV ? hint : nullptr, hint2, true);
     if (i >= n) return;
     int cost = 0;
@@ -420,7 +508,7 @@ __device__ __forceinline__ void quad_tsit5_body(const KArgs<N, 1> &A, const QArg
                                                 size_t n, size_t ld, const TIO *u_in, TIO *u_out, double dt, int n_steps,
                                                 unsigned char *__restrict__ hint = nullptr,
                                                 unsigned char *__restrict__ hint2 = nullptr) {
-    constexpr int QB = NQ ? quad_block(NQ) : kBlock;
+    constexpr int QB = NQ ? quad_block(NQ) : (CONV ? kConvBlock : kBlock);
     const size_t i = quad_ranked_parcel<QB>(n, CONV ? hint : nullptr, hint2, true);   // (as quad_ssprk33_body)
     if (i >= n) return;
     int cost = 0;

@@ -75,11 +75,24 @@ struct ClosureStatsArgs {
 };
 // the reference's check on one mode's (normalised) moments; NaN comparisons are false there as here
 __device__ __forceinline__ bool moments_inconsistent(int np, double m0, double m1, double m2) {
+    // (every product and sum rounded on its own, as Julia rounds them: the library is built with -ffp-contract=fast, and a parcel of
+    // zero variance -- M2 = M1^2 / M0 to the last bit -- has a central moment of rounding size whose SIGN a fused multiply-add
+    // changes: 29 of 2 500 such parcels of the bench batch, first GPU run of the test.  Neither __dmul_rn (a plain product in HIP)
+    // nor `#pragma clang fp contract(off)` stops the fusion under that option -- it happens in the instruction selector -- so the
+    // products pass through opaque copies before they are added.)
     if (m0 < 0.0 || m1 < 0.0 || (np == 3 && m2 < 0.0)) return true;
     if (np < 3) return false;
     // order 2: sum_i binomial(2, i) (-1)^i (m[2]/m[1])^i (m[3-i]/m[1]), i = 0, 1, 2, left to right
     const double r = m1 / m0;
-    const double cm = (m2 / m0 + (-2.0 * r) * (m1 / m0)) + (r * r) * (m0 / m0);
+    const double t0 = m2 / m0;
+    double t1 = (-2.0 * r) * (m1 / m0);
+    double rr = r * r;
+    asm volatile("" : "+v"(t1));
+    asm volatile("" : "+v"(rr));
+    double t2 = rr * (m0 / m0);
+    asm volatile("" : "+v"(t2));
+    const double s01 = t0 + t1;
+    const double cm = s01 + t2;
     return cm < 0.0;
 }
 template <typename TIO>

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""TEST INFRASTRUCTURE (round 5): an independent check of the R matrix of the golden case narrow_lognormal_gamma_hydro (a Lognormal mode
+"""TEST INFRASTRUCTURE (round 5; superseded in round 6 by oracle/gl_check.py, which checks EVERY entry of EVERY golden case the same way
+and stores the figure in the golden file -- this script stays as the record of how the case was first settled): an independent check of the R matrix of the golden case narrow_lognormal_gamma_hydro (a Lognormal mode
 of sigma = 0.005 under the hydrodynamic kernel, whose |x^(2/3) - y^(2/3)| has its kink on the diagonal INSIDE the 0.5 % wide peak).
 
 mpmath's tanh-sinh recomputation of this case (oracle/numerical_adaptive.py --mpmath-case=narrow_lognormal_gamma_hydro, 11 682 s) agrees

@@ -154,6 +154,7 @@ int co_get_coal_ints_numerical_fixed(const co_dist *pdists, int N, const co_kern
                                      double *scale, double *noise);
 /* cloudy_oracle_adaptive.c: the same operator by NESTED ADAPTIVE Gauss-Kronrod quadrature, as the reference evaluates it
  * (Coalescence.jl:503-708) -- slow; generates tests/golden/numerical_adaptive.json.  Q, R: [orders][N][N]; S: [orders][2][N] */
+void co_adaptive_set_endpoint_map(int q); /* cloudy_oracle_adaptive.c: 0 (default) = the reference's formulation; q >= 2: end-point map + half-range inner integrals */
 int co_get_coal_ints_numerical_adaptive(const co_dist *pdists, int N, const co_kernel_func *kf, double eps_outer,
                                         double eps_inner, double *out, double *Q, double *R, double *S);
 /* cloudy_oracle_quad.c, converged mode (CLOUDY_QUAD_CONVERGED): closed forms for Q and R, adaptive Gauss-Kronrod (7, 15)

@@ -42,7 +42,10 @@ CASES = [
     dict(name="1gamma_long_at_threshold", kf=(3, LONG), pdists=[(1, 30.0, 0.2, 2.0)], mp=True),
     dict(name="2exp_hydrodynamic", kf=(2, [E_HYDRO]), pdists=[(0, 80.0, 0.1, 1.0), (0, 2.0, 6.0, 1.0)]),
     dict(name="exp_gamma_hydro_overlapping", kf=(2, [E_HYDRO]), pdists=[(0, 40.0, 1.0, 1.0), (1, 10.0, 1.5, 2.0)]),
-    dict(name="2gamma_linear_shapes_far_apart", kf=(1, [5e-3]), pdists=[(1, 60.0, 0.4, 0.6), (1, 4.0, 1.2, 9.0)]),
+    # (round 6, endpoint_map: oracle/gl_check.py -- and the closed form c (M1 M0' + M0 M1') of this Q -- showed the recorded Q entries
+    # 1.2e-9 low: pdists[j](x - y) evaluated next to y = x loses x - y below 1e-16 x, and a shape of 0.6 keeps 1e-9 of its mass
+    # there.  The inner integrals of this case are taken over (0, x / 2] and doubled, cloudy_oracle_adaptive.c)
+    dict(name="2gamma_linear_shapes_far_apart", kf=(1, [5e-3]), pdists=[(1, 60.0, 0.4, 0.6), (1, 4.0, 1.2, 9.0)], endpoint_map=True),
     dict(name="2gamma_hydro_small_shapes", kf=(2, [E_HYDRO]), pdists=[(1, 90.0, 0.5, 0.75), (1, 5.0, 20.0, 0.9)]),
     dict(name="exp_2gamma_long", kf=(3, LONG), pdists=[(0, 200.0, 0.04, 1.0), (1, 8.0, 0.3, 2.5), (1, 0.2, 6.0, 4.0)], mp=True),
     dict(name="2gamma_constant", kf=(0, [1e-4]), pdists=[(1, 100.0, 0.1, 2.0), (1, 3.0, 3.0, 3.5)]),
@@ -267,9 +270,13 @@ def main():
             continue
         pd = [O.make_dist(int(d[0]), d[1], d[2], d[3]) for d in c["pdists"]]
         kf = O.kernel_func(c["kf"][0], *c["kf"][1])
+        O.lib().co_adaptive_set_endpoint_map(6 if c.get("endpoint_map") else 0)
         ci, Q, R, S = O.get_coal_ints_numerical_adaptive(pd, kf, 1e-10, 1e-12)
+        O.lib().co_adaptive_set_endpoint_map(0)
         rec = dict(name=c["name"], kf=[c["kf"][0], list(c["kf"][1])], pdists=[list(d) for d in c["pdists"]],
                    coal_ints=ci.tolist(), Q=Q.tolist(), R=R.tolist(), S=S.tolist())
+        if c.get("endpoint_map"):
+            rec["endpoint_map"] = True
         msg = ""
         if with_mp and c.get("mp"):
             Qm, Rm, Sm = mp_matrices(c)
