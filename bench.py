@@ -449,7 +449,7 @@ TIMED_MS = 40.0          # ... and at least this much GPU time inside the timed 
 
 def _sustained_ms(pkg, launch, min_reps=5, max_reps=400):
     """Milliseconds per call of launch() at the clock the GPU SUSTAINS: >= WARM_SECONDS of back-to-back calls first, then
-    HIP events (on the launch stream) around enough calls to cover >= TIMED_MS.  Round 4 finding (tools/time_warm.py): the
+    HIP events (on the launch stream) around enough calls to cover >= TIMED_MS.  Round 4 finding (profiles/r04_time_warm.txt): the
     variants used to be timed over 3-5 launches right after their input had been generated and copied by the host -- the
     GPU idle for 0.1-1 s -- and a 1-ms kernel then runs at a clock it leaves within tens of ms: the fused SSPRK33
     integrator measured 1.14 ms that way and 0.89 ms sustained, moving4 1.63 / 1.37, cfg3b 2.35 / 2.04 (the headline,
@@ -512,7 +512,7 @@ def _run_workload(pkg, name, n_parcels, steps, warmup, rank, dist, torch):
     rhs = pkg.make_box_model_rhs(pkg.AnalyticalCoalStyle(), pkg.MovingThreshold() if wl["spec"].get("moving") else None)
     # W untimed warm-up steps through the operator boundary -- and at least ~80 ms of back-to-back launches: after
     # idling the GPU needs tens of ms of continuous work to reach its sustained clocks (a 0.17 ms launch measured
-    # 0.24 / 0.19 / 0.17 ms per step over the first 10 / 50 / 200 launches, tools/launch_ramp_timing.py).
+    # 0.24 / 0.19 / 0.17 ms per step over the first 10 / 50 / 200 launches, round 1).
     t_w = time.perf_counter()
     done = 0
     while done < max(warmup, 1) or (time.perf_counter() - t_w) < 0.08:

@@ -1191,7 +1191,7 @@ int cloudy_rainshaft_ssprk33_steps(const cloudy_plan *plan, size_t nz, size_t n_
         // of this call (the caller's stream may be the legacy NULL stream, which cannot capture) ordered after the caller's
         // stream by an event and before it by another.  Same bits (test_tall_columns_replay_a_captured_step); per step of
         // 3 x 1500 / 64 x 1500 / 256 x 4000 cells: eager 0.143 / 0.128 / 0.52 ms, replayed 0.158 / 0.162 / 0.84 ms, plus 3-5 ms
-        // of capture and instantiation per call (tools/time_tall_columns.py, profiles/r05_tall_columns_graph_experiment.txt):
+        // of capture and instantiation per call (profiles/r05_tall_columns_graph_experiment.txt):
         // the eager launches already queue back to back on the stream, and the graph's kernel nodes do not run closer together.
         DeviceGuard guard(plan->h.device);
         if (guard.err != hipSuccess) return fail_hip(guard.err, "selecting the plan's device");

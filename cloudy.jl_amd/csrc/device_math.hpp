@@ -19,14 +19,10 @@ constexpr double kSqrtEps = 1.4901161193847656e-08;     // 2^-26: x >= 2^-26 && 
 // (11-12 instructions) whose only purpose is denormal and overflow ranges these operands never reach
 // (z = (x_t - x)/theta, D' in [1, 1e17], |B| <= 1e150 by the rescaling in the loop).
 __device__ __forceinline__ double recip_fast(double x) {
-#ifdef CLOUDY_IEEE_DIV
-    return 1.0 / x;
-#else
     double r = __builtin_amdgcn_rcp(x);
     r = fma(fma(-x, r, 1.0), r, r);
     r = fma(fma(-x, r, 1.0), r, r);
     return r;
-#endif
 }
 
 // Regularised lower incomplete gamma P(a, z) for a > 0, z > 0, given
@@ -36,7 +32,7 @@ __device__ __forceinline__ double recip_fast(double x) {
 // Wallis forward recurrence (no division per term).  *q_out gets Q on the same branch's accuracy.
 // Stopping tolerances (relative size of the last term / of the last change of the continued fraction), tested every four
 // terms.  Rounds 1-3 used 1e-17 / 1e-16 -- BELOW the rounding unit, so both loops ran one or two groups of four past the
-// point where double precision stops changing.  Measured in round 4 (tools/time_kernels.py --error; cfg3b / cfg4 / moving4,
+// point where double precision stops changing.  Measured in round 4 (tools/timeit.py kernels --error; cfg3b / cfg4 / moving4,
 // error against the oracle in units of the term scale):
 //   1e-17 / 1e-16   2.05 / 6.56 / 1.375 ms   1.8e-14 / 1.9e-14 / 7.5e-15
 //   1e-15           1.85 / 6.05 / 1.291 ms   the same errors to both printed digits
@@ -51,135 +47,6 @@ __device__ __forceinline__ double recip_fast(double x) {
 #define CLOUDY_CF_TOL 1e-14
 #endif
 __device__ __forceinline__ double inc_gamma_p_from_E(double a, double z, double E, double *q_out) {
-#ifdef CLOUDY_ABLATE_PTOP  // timing experiment only: skips the series / continued fraction
-    if (q_out) *q_out = 1.0 - E;
-    return E;
-#endif
-#ifdef CLOUDY_FIXED_LATE
-    // (experiment, VERDICT r4 item 4 -- measured, not shipped: ONE algorithm of FIXED length for every node, so that no lane of a
-    // wave waits for another algorithm or another term count: the power series, which converges for every z, for exactly
-    // CLOUDY_FIXED_LATE groups of four terms; a lane that has converged keeps its sums (three selects per group).  The P = 1
-    // shortcut stays (a predicate).  profiles/r05_fixed_late_experiment.txt)
-    {
-        if (z > a + 1.0 && a * E < 1e-18) {
-            if (q_out) *q_out = a * E * (1.0 / (z + 1.0 - a));
-            return 1.0;
-        }
-        const double invz = recip_fast(z);
-        double q = a * invz, Nn = 1.0, Dn = 1.0;
-#pragma unroll 1
-        for (int it = 0; it < CLOUDY_FIXED_LATE; ++it) {
-            double q2 = q, N2 = Nn, D2 = Dn;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                q2 += invz;
-                N2 = fma(N2, q2, 1.0);
-                D2 *= q2;
-            }
-            const bool live = Nn < 1.0 / CLOUDY_SERIES_TOL;
-            q = live ? q2 : q;
-            Nn = live ? N2 : Nn;
-            Dn = live ? D2 : Dn;
-        }
-        double p = E * (Nn * recip_fast(Dn));
-        p = p > 1.0 ? 1.0 : p;
-        if (q_out) *q_out = 1.0 - p;
-        return p;
-    }
-#endif
-#ifdef CLOUDY_F32_TAIL
-    // (experiment, VERDICT r5 item 6 -- measured, profiles/r06_f32_tail_experiment.txt: the terms of the series / the steps of the
-    // continued fraction below 2^-24 of the running value in SINGLE precision -- 2-cycle instead of 4-cycle instructions.  Series:
-    // S D'_m = N'_m + R, R = sum_{j>=1} prod_{i<=j} 1 / q_{m+i} by the same N / D recurrence started at (0, 1), in floats, until the
-    // last term is below CLOUDY_SERIES_TOL of the sum.  Continued fraction: from the Wallis state at step m the increments by
-    // Steed's recurrence, D_n = 1 / (b_n + a_n D_{n-1}), df_n = -a_n D_{n-1} D_n df_{n-1}, in floats.)
-    if (z <= a + 1.0) {
-        const double invz = recip_fast(z);
-        double q = a * invz, Nn = 1.0, Dn = 1.0;
-#pragma unroll 1
-        for (int it = 0; it < 100; ++it) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                q += invz;
-                Nn = fma(Nn, q, 1.0);
-                Dn *= q;
-            }
-            if (!(Nn < 16777216.0)) break;
-        }
-        float qf = (float)q, Nt = 0.0f, Dt = 1.0f;
-        const float invzf = (float)invz, stop = (float)(1.0 / (CLOUDY_SERIES_TOL * Nn));
-#pragma unroll 1
-        for (int it = 0; it < 100; ++it) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                qf += invzf;
-                Nt = fmaf(Nt, qf, 1.0f);
-                Dt *= qf;
-            }
-            if (!(Dt < stop)) break;
-        }
-        double p = E * ((Nn + (double)(Nt / Dt)) * recip_fast(Dn));
-        p = p > 1.0 ? 1.0 : p;
-        if (q_out) *q_out = 1.0 - p;
-        return p;
-    } else {
-        if (a * E < 1e-18) {
-            if (q_out) *q_out = a * E * (1.0 / (z + 1.0 - a));
-            return 1.0;
-        }
-        double b = z + 1.0 - a;
-        double Ap = 0.0, Bp = 1.0, Ac = 1.0, Bc = b;
-        double an = a - 1.0, c = a - 1.0;
-        double lhs = 1.0, den = 1.0;
-#pragma unroll 1
-        for (int it = 0; it < 100; ++it) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                b += 2.0;
-                const double An = fma(b, Ac, an * Ap);
-                const double Bn = fma(b, Bc, an * Bp);
-                Ap = Ac;
-                Bp = Bc;
-                Ac = An;
-                Bc = Bn;
-                c -= 2.0;
-                an += c;
-            }
-            lhs = fma(Ac, Bp, -(Ap * Bc));
-            den = Ac * Bp;
-            if (!(fabs(lhs) > 5.96e-8 * fabs(den))) break;
-            if (fabs(Bc) > 1e150) {
-                Ap *= 1e-150;
-                Bp *= 1e-150;
-                Ac *= 1e-150;
-                Bc *= 1e-150;
-            }
-        }
-        const double rBc = recip_fast(Bc);
-        const double f = Ac * rBc;
-        // the increments in floats: df = f_n - f_{n-1} = lhs / (Bc Bp), D = B_{n-1} / B_n
-        float D = (float)(Bp * rBc), df = (float)(f - Ap * recip_fast(Bp)), tail = 0.0f;   // (f_n - f_{n-1}: 6e-8 of f, good to 2e-9 of itself)
-        float bf = (float)b, anf = (float)an, cf = (float)c;
-        const float ftol = (float)(CLOUDY_CF_TOL * fabs(f));
-        if (fabsf(df) > ftol) {
-#pragma unroll 1
-            for (int it = 0; it < 400; ++it) {
-                bf += 2.0f;
-                const float Dn = __builtin_amdgcn_rcpf(fmaf(anf, D, bf));
-                df *= -anf * D * Dn;
-                D = Dn;
-                tail += df;
-                cf -= 2.0f;
-                anf += cf;
-                if (!(fabsf(df) > ftol)) break;
-            }
-        }
-        double qv = a * E * (f + (double)tail);
-        qv = qv < 0.0 ? 0.0 : qv;
-        if (q_out) *q_out = qv;
-        return 1.0 - qv;
-    }
-#endif
     if (z <= a + 1.0) {
         // S = sum_n z^n/(a+1)_n = N_n/D_n with both scaled by z^-n:  q_n = (a+n)/z,
         //   N'_n = N'_{n-1} q_n + 1,  D'_n = D'_{n-1} q_n;   term_n / S_n = 1 / N'_n   (3 VALU ops per term)

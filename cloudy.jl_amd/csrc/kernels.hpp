@@ -114,24 +114,14 @@ __device__ __forceinline__ double div_by_const(double x, double d, double r) {
 // v_div_scale / v_div_fixup range handling -- the same bits as x / d there (the final FMA rounds the same exact value),
 // 8 instead of 11 instructions.  A non-finite numerator gives NaN where IEEE gives Inf.
 __device__ __forceinline__ double div_normal(double x, double d) {
-#if defined(CLOUDY_IEEE_DIV) || defined(CLOUDY_IEEE_CLOSURE_DIV)
-    return x / d;
-#else
     const double r = recip_fast(d);
     const double q = x * r;
     return fma(fma(-d, q, x), r, q);
-#endif
 }
 
 // update_dist_from_moments, ParticleDistributions.jl:456-476 / :512-523 (normalised moments in)
 __device__ __forceinline__ void invert_closure(int dist_type, double m0, double m1, double m2, double kmin,
                                                double kmax, double &n, double &th, double &k) {
-#ifdef CLOUDY_ABLATE_INV  // timing experiment only: no divisions
-    n = m0;
-    th = m1;
-    k = m2 + kmin;
-    return;
-#endif
     if (dist_type == DIST_LOGNORMAL) {
         // ParticleDistributions.jl:483-505: (n, mu, sigma) kept in the (n, theta, k) slots
         if (m0 > kEps && m1 > kEps && m2 > kEps) {
@@ -321,7 +311,6 @@ __device__ __forceinline__ int early_series(const Grid &grid, int nb, double xt,
     const double x_early = fmin(kEarlyTmax * th, kEarlyUa * xt / fmax(a_top - 1.0, 3.0));
     int j = 0;
     const double xr = grid.first_x();
-#ifndef CLOUDY_NO_EARLY_NODES
     {
         const double lx0 = grid.first_lx(), dxl = grid.log_step();
         int J = 0;
@@ -399,7 +388,6 @@ __device__ __forceinline__ int early_series(const Grid &grid, int nb, double xt,
             j = J;
         }
     }
-#endif
     return j;
 }
 
@@ -417,11 +405,7 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double th,
                                          double (&msh)[(P + 2) * (P + 3) / 2]) {  // WITHOUT msh_pref(n, k) M_p2: the caller applies them
     constexpr int M = P + 2;
     constexpr int T = M * (M + 1) / 2;
-#ifdef CLOUDY_ABLATE_NODES  // timing experiment only: no Simpson nodes at all
-    const int nb = 0;
-#else
     const int nb = grid.n_bins();
-#endif
     // (log_pos / lgamma_pos of device_math.hpp: branch-free, a third of the library routines' instructions)
     const double inv_th = 1.0 / th, lnth = log_pos(th);
     const double a_top = k + double(M - 1);
@@ -434,9 +418,6 @@ __device__ __forceinline__ void msh_grid(const Grid &grid, double xt, double th,
     // ---- early nodes: closed form (early_series)
     int j = early_series<P>(grid, nb, xt, th, k, inv_th, lnth, a_top, lg_top, z0, acc);
     // ---- late nodes: one incomplete-gamma evaluation each
-#ifdef CLOUDY_ABLATE_LATE  // timing experiment only: early nodes and their conversion, no late nodes
-    j = nb;
-#endif
     // From the LAST node down: in a regime-sorted wave every lane is then at the same node index in the same iteration
     // (the lanes differ in where their early group ends, not in where the grid ends), so z = (x_t - x_j) / theta is as
     // homogeneous across the wave as theta is -- and the node table of a FixedGrid is read at wave-uniform addresses.
@@ -848,7 +829,6 @@ __device__ __forceinline__ void promoted_mode(const KArgs<N, P> &A, const double
 //      with v_s[b] = sum_a c_ab Mj_{a+s}.   Adds to acc.
 template <int N, int P, bool SPEC>
 __device__ __forceinline__ void pair_terms(const KArgs<N, P> &A, const double (&Mm)[N][P + 2], double (&acc)[N][3]) {
-#ifndef CLOUDY_ABLATE_PAIR
 #pragma unroll
     for (int k = 0; k < N; ++k) {
 #pragma unroll
@@ -905,7 +885,6 @@ __device__ __forceinline__ void pair_terms(const KArgs<N, P> &A, const double (&
         }
     }
 
-#endif
 }
 
 // get_coal_ints for one parcel: acc[k][m], normalised units.
@@ -1273,11 +1252,7 @@ __device__ __forceinline__ void ssprk33_body(const KArgs<N, P> *__restrict__ Ag,
     // a parcel stay for the barriers; the lane -> parcel map is the natural one (coalesced loads and stores).
     const bool valid = i < n;
     if (MODE == MODE_ALLINF && !valid) return;
-#ifdef CLOUDY_SSPRK33_PHYSICAL_STATE  // (A/B switch: the reference's sequence, normalising in every evaluation)
-    constexpr bool kNormalisedState = false;
-#else
     constexpr bool kNormalisedState = MODE == MODE_ALLINF;  // see rhs_normalised
-#endif
     double u[N][3], up[N][3], f[N][3];
 #pragma unroll
     for (int m = 0; m < N; ++m) {
@@ -1568,11 +1543,7 @@ __global__ void __launch_bounds__(kBlock)
     finite_2d_body<N, P, MODE>(A, nodes, n, ld, in, F, thr_out);
 }
 
-#ifdef CLOUDY_ABLATE_BARRIER
-#define CLOUDY_STAGE_BARRIER() ((void)0)
-#else
 #define CLOUDY_STAGE_BARRIER() __syncthreads()
-#endif
 
 #ifndef CLOUDY_RS_BLOCK
 #define CLOUDY_RS_BLOCK 256
@@ -1645,9 +1616,6 @@ __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__rest
     __shared__ double sh_up[NUP > 0 ? NUP : 1][BS];
     __shared__ unsigned char sh_small[kPark ? BS : 1];  // the empty-cell flag of the stage (:67-72) waits here as well
     const KArgs<N, P> &A = *Ag;
-#ifdef CLOUDY_RS_NZ_CONST   // (timing experiment only: what the divisions by a run-time column height cost)
-    nz = CLOUDY_RS_NZ_CONST;
-#endif
     const int cpb = BS / nz;       // whole columns per workgroup
     const int pos = threadIdx.x;   // cell slot of the workgroup this lane integrates: column pos / nz, level pos % nz
     // (With a finite threshold the Simpson passes of every stage run on cells re-ranked on that stage's state, per
@@ -1765,11 +1733,7 @@ __device__ __forceinline__ void rainshaft_ssprk33_body(const KArgs<N, P> *__rest
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
                         const double f_up = top ? 0.0 : fx[3 * m + q][pp + 1];
-#ifdef CLOUDY_RS_MUL_RDZ     // (timing experiment only, not the reference's bits: what the IEEE divisions by dz cost)
-                        const double fd = -(f_up - fx[3 * m + q][pp]) * (1.0 / dz);
-#else
                         const double fd = -(f_up - fx[3 * m + q][pp]) / dz;  // :83-85
-#endif
                         // coal_source .+ sedi_source (:88), empty cells skip coalescence (:67-72)
                         const double ft = ((q < Af.np[m] && !small2) ? acc[m][q] * Af.out_scale[3 * m + q] : 0.0) + fd;
                         if (RHS_ONLY) {

@@ -354,9 +354,7 @@ __device__ __forceinline__ int conv_adaptive(double tlo, double thi, ConvMarks<N
             own = fma(h0, double(io2), tlo);
         }
         double nxt = fmin(thi, own);
-#ifndef CLOUDY_CONV_PROBE_NO_MARKS  // (timing experiments only)
         nxt = fmin(nxt, mk.next(lim, need));
-#endif
         nxt = nxt > thi - gap ? thi : nxt;
         io = io2;
         a0 = go ? cur : a0;
@@ -400,9 +398,6 @@ __device__ __forceinline__ int conv_adaptive(double tlo, double thi, ConvMarks<N
             // (a NaN estimate accepts: the NaN reaches the output)
             if (fabs(K[e] - G[e]) * hw > kConvTol * fmax(fabs(fma(K[e], hw, acc_o)), kConvFloor * sc_o)) ok = false;
         }
-#ifdef CLOUDY_CONV_PROBE_ACCEPT_ALL
-        ok = true;
-#endif
         const bool accept = ok || L == kConvLMax || budget <= 0;
         if (accept) {
             if (TWO_PASS) {
@@ -711,9 +706,7 @@ __device__ __forceinline__ double conv_long_G_mid_tab(const QArgs &Q, double k, 
     // (the lane index through an opaque copy: the twelve coefficients are READ here, per node -- left alone the compiler hoists
     // the reads out of the node loop and keeps them in 24 registers the walk does not have: scratch instead of LDS)
     int tl = threadIdx.x;
-#ifndef CLOUDY_LONG_TAB_HOIST
     asm volatile("" : "+v"(tl));
-#endif
 #pragma unroll
     for (int r = kLongNT - 1; r >= 1; --r) {
         const double b0 = fma(z2, b1, sh[row0 + r][tl]) - b2;
@@ -1546,7 +1539,6 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
         }
     }
     // ---- phase 2: T_m, the self collisions weighting_fn hands to mode j + 1
-#ifndef CLOUDY_ABLATE_CONV_T  // (timing experiment only: the closed forms alone)
     if (N > 1) {
         constexpr int NM = N > 1 ? N - 1 : 1;
         // the rules of the Gamma-family modes: everything prepared here, walked in ONE loop (conv_T_merged)
@@ -1574,7 +1566,6 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
             // what the walk does not need waits in the lane's own LDS slots (conflict-free, no barrier: a lane reads what it
             // wrote): the 3N partial tendencies of phase 1 and the prefactors -- registers the allocator would otherwise
             // spill around (and, at three waves per SIMD, inside) the loop: 11 x the algorithmic HBM traffic in scratch
-#ifndef CLOUDY_CONV_NO_PARK
             __shared__ double sh_park[3 * N + (N > 1 ? N - 1 : 1)][kConvBlock];
             const int t = threadIdx.x;
 #pragma unroll
@@ -1583,7 +1574,6 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
                 for (int m = 0; m < 3; ++m) sh_park[3 * k + m][t] = acc[k][m];
 #pragma unroll
             for (int j = 0; j < N - 1; ++j) sh_park[3 * N + j][t] = prefj[j];
-#endif
             constexpr bool kTabFits = KIND == KF_LONG && N <= 3;
             constexpr int kXRows = 3 * N + 6 * NM + 1;   // SPLIT: what crosses between the two lanes of a parcel
             constexpr int kTabRows = kTabFits ? (SPLIT && kXRows > NM * kLongNT ? kXRows : NM * kLongNT) : 1;
@@ -1608,14 +1598,12 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
                     conv_T_merged<N, KIND, false, (KIND == KF_LONG ? 2 : 0)>(Q, lg, rb, Traw, midneed, sh_gtab, cost);
                 }
             }
-#ifndef CLOUDY_CONV_NO_PARK
 #pragma unroll
             for (int k = 0; k < N; ++k)
 #pragma unroll
                 for (int m = 0; m < 3; ++m) acc[k][m] = sh_park[3 * k + m][t];
 #pragma unroll
             for (int j = 0; j < N - 1; ++j) prefj[j] = sh_park[3 * N + j][t];
-#endif
         }
 #pragma unroll
         for (int j = 0; j < N - 1; ++j) {
@@ -1649,7 +1637,6 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
             acc[j + 1][2] += T2;
         }
     }
-#endif
 }
 
 // The byte a parcel leaves in the plan's hint scratch from the `cost` of conv_coal_ints (quad_kernels.hpp ranks the parcels of a

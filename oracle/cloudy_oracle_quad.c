@@ -533,11 +533,17 @@ void co_conv_rule_node_counts(long *out) {
     for (int i = 0; i < CO_MAX_MODES; ++i) out[i] = co_conv_rule_nodes_[i];
 }
 static _Thread_local long co_conv_phase_evals_[3]; /* panel evaluations of the descending walk by phase (0: homogeneous kernels) */
+static _Thread_local long co_conv_rejects_;        /* ... of which were rejected (bisected): evaluations - rejects = accepted panels */
 void co_conv_phase_evals(long *out, int reset) { /* tools/long_lane_sim.py: the per-parcel cost the device's hint bytes record */
     for (int i = 0; i < 3; ++i) {
         out[i] = co_conv_phase_evals_[i];
         if (reset) co_conv_phase_evals_[i] = 0;
     }
+}
+long co_conv_rejects(int reset) {
+    const long n = co_conv_rejects_;
+    if (reset) co_conv_rejects_ = 0;
+    return n;
 }
 long co_conv_node_count(int reset) {
     const long n = co_conv_nodes_;
@@ -702,6 +708,7 @@ static int co_conv_descending(double tlo, double thi, const double *marks, int n
                 }
                 if (L == 0) break;
             } else {
+                ++co_conv_rejects_;
                 ++L;
                 i <<= 1;
             }

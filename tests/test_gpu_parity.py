@@ -1868,12 +1868,83 @@ def test_closure_stats_vs_oracle(gpu_cloudy, oracle):
     g3 = cloudy.closure_stats(plan3, dev(cloudy, mom3))
     w3 = O.closure_stats(op3, mom3)
     assert np.array_equal(g3, w3), (g3, w3)
-    assert w3[0, 3] >= 500 and w3[2, 1] >= 900 and w3[2, 0] >= 500 and w3[1, 1] >= 900 and w3[0, 1] == 0 and w3[0, 2] == 0
+    # (a few of the doctored parcels coincide with the batch's own degenerate ones)
+    assert w3[0, 3] >= 450 and w3[2, 1] >= 800 and w3[2, 0] >= 450 and w3[1, 1] >= 800 and w3[0, 1] == 0 and w3[0, 2] == 0, w3
     # float planes: the counts of the ROUNDED moments (the oracle sees the same float values)
     pf = wl["coal_data"].plan(wl["dist_types"], dtype=1)
     mf = wl["mom"].astype(np.float32)
     gf = cloudy.closure_stats(pf, cloudy.DeviceArray.from_numpy(mf))
     assert np.array_equal(gf, O.closure_stats(bench.oracle_params("cfg3b"), mf.astype(np.float64)))
+
+
+def test_first_calls_from_two_host_threads_on_one_plan(gpu_cloudy):
+    """VERDICT r5 item 5 / ADVICE r5 (medium): a plan is shared by host threads.  (i) The FIRST calls of two entry points that each
+    build something on first use -- cloudy_tsit5_steps compiles its kernel, a diagnostic its own -- from two threads at once on one
+    thresholded plan (ctypes releases the GIL: the calls overlap in the library); (ii) a converged-mode plan whose hint bytes are
+    GROWN by one thread (a larger batch) while the other keeps launching on the smaller one -- round 5 freed the superseded buffer
+    under the first thread's launch.  Results equal the single-threaded ones bit for bit, on every repetition."""
+    import ctypes as C
+    import threading
+
+    cloudy = gpu_cloudy
+    L = cloudy.lib()
+    # ---- (i)
+    wl = bench.make_workload("cfg3b", 60_000, seed=21)
+    plan = wl["coal_data"].plan(wl["dist_types"], k_range=(EPS, 9.5))     # (a plan no other test has warmed up)
+    m = dev(cloudy, wl["mom"])
+    o5, prm = cloudy.DeviceArray.zeros(6, 60_000), cloudy.DeviceArray.zeros(6, 60_000)
+    errs = []
+
+    def run(fn):
+        try:
+            fn()
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    t1 = threading.Thread(target=run, args=(lambda: cloudy._lib.check(
+        L.cloudy_tsit5_steps(plan.handle, 60_000, 60_000, m.ptr, o5.ptr, C.c_double(1e-4), 1, None)),))
+    t2 = threading.Thread(target=run, args=(lambda: [cloudy.closure_stats(plan, m),
+                                                     cloudy._lib.check(L.cloudy_update_dist_from_moments(plan.handle, 60_000, 60_000, m.ptr, prm.ptr, None))],))
+    t1.start(); t2.start(); t1.join(); t2.join()
+    assert not errs, errs
+    cloudy._lib.check(L.cloudy_stream_synchronize(None))
+    ref5, refp = cloudy.DeviceArray.zeros(6, 60_000), cloudy.DeviceArray.zeros(6, 60_000)
+    cloudy._lib.check(L.cloudy_tsit5_steps(plan.handle, 60_000, 60_000, m.ptr, ref5.ptr, C.c_double(1e-4), 1, None))
+    cloudy._lib.check(L.cloudy_update_dist_from_moments(plan.handle, 60_000, 60_000, m.ptr, refp.ptr, None))
+    cloudy._lib.check(L.cloudy_stream_synchronize(None))
+    assert np.array_equal(o5.to_numpy(), ref5.to_numpy(), equal_nan=True) and np.array_equal(prm.to_numpy(), refp.to_numpy(), equal_nan=True)
+    # ---- (ii)
+    kfn = cloudy.get_normalized_kernel_func(cloudy.HydrodynamicKernelFunction(1e2 * np.pi), bench.NORMS)
+    cplan = cloudy.NumericalPlan([1, 1], kfn, bench.NORMS, 8, specialize=1, quad_mode=cloudy.QUAD_CONVERGED)
+    small, sizes = 20_000, (30_000, 70_000, 150_000, 320_000)
+    ms = dev(cloudy, bench.synth_moments(2, small, seed=5))
+    ds = cloudy.DeviceArray.zeros(6, small)
+    cloudy._lib.check(L.cloudy_coal_rhs(cplan.handle, small, small, ms.ptr, ds.ptr, None))
+    cloudy._lib.check(L.cloudy_stream_synchronize(None))
+    want_small = ds.to_numpy().copy()
+    bigs = [(n, dev(cloudy, bench.synth_moments(2, n, seed=6)), cloudy.DeviceArray.zeros(6, n)) for n in sizes]
+    outs = [cloudy.DeviceArray.zeros(6, small) for _ in range(24)]
+
+    def hammer():
+        for o in outs:
+            cloudy._lib.check(L.cloudy_coal_rhs(cplan.handle, small, small, ms.ptr, o.ptr, None))
+
+    def grow():
+        for n, mb, db in bigs:
+            cloudy._lib.check(L.cloudy_coal_rhs(cplan.handle, n, n, mb.ptr, db.ptr, None))
+
+    ta, tb = threading.Thread(target=run, args=(hammer,)), threading.Thread(target=run, args=(grow,))
+    ta.start(); tb.start(); ta.join(); tb.join()
+    cloudy._lib.check(L.cloudy_stream_synchronize(None))
+    assert not errs, errs
+    for o in outs:
+        assert np.array_equal(o.to_numpy(), want_small, equal_nan=True)
+    fresh = cloudy.NumericalPlan([1, 1], kfn, bench.NORMS, 8, specialize=1, quad_mode=cloudy.QUAD_CONVERGED)
+    n, mb, db = bigs[-1]
+    chk = cloudy.DeviceArray.zeros(6, n)
+    cloudy._lib.check(L.cloudy_coal_rhs(fresh.handle, n, n, mb.ptr, chk.ptr, None))
+    cloudy._lib.check(L.cloudy_stream_synchronize(None))
+    assert np.array_equal(db.to_numpy(), chk.to_numpy(), equal_nan=True)
 
 
 def test_error_returns_of_the_column_and_integrator_entry_points(gpu_cloudy):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # VALU / wait / LDS / scratch counters of one python command on the GPU box (separate passes, kernel trace only):
-#   tools/pmc_one.sh <tag> <script.py args...>  ->  gpurun_out/<tag>_pmc.txt
+#   tools/pmc.sh <tag> <script.py args...>  ->  gpurun_out/<tag>_pmc.txt
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
