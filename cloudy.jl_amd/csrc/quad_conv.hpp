@@ -737,6 +737,7 @@ __device__ __forceinline__ double conv_long_G_mid_tab(const QArgs &Q, double k, 
 // the rule with panels of sigma / 2 at s ~ 2 e^mu: 2e-10 of scale at sigma = 0.02, 6e-7 at 0.01, 1e-4 ... 1e-1 below 0.005; now
 // <= 1.5e-12 down to sigma = 0.003, 6.5e-11 at 0.002, 1e-9 ... 2e-6 at 0.001 (the cap), tests/test_numerical_oracle.py.
 constexpr int kLnPanels2 = 12, kLnPanels2Max = 256;
+constexpr double kLnCut = 42.0;   // the density of the sum of two Lognormal variates is followed down to e^-42 of its peak
 constexpr double kLnPanelSigmas = 3.0;
 template <int N, int KIND>
 __device__ __forceinline__ void conv_T_lognormal(const QArgs &Q, const double *__restrict__ tab, double n, double mu, double sg,
@@ -764,7 +765,16 @@ __device__ __forceinline__ void conv_T_lognormal(const QArgs &Q, const double *_
     }
     const auto node = [&](double ls, double (&vals)[3]) {
         const double s = exp_fin(ls);
-        const double Tm = fmax(ls - mu, 0.0) + 12.0 * sg;
+        // Round 6: the Gaussian factor of the inner integrand is that of the polynomial kernels (conv_T_lognormal_poly) whatever
+        // the kernel function, so its two bounds hold here too: nothing where min(d^2, 2 d - 1) > 42 sigma^2, nothing beyond
+        // T = 2 sqrt(d^2 + 42 sigma^2).  (Without them a shape clamped to sigma = eps ran 256 panels x nq points at EVERY node while
+        // the 63 other parcels of its wave waited: 2e5 parcel-RHS/s against 3.5e7 for the polynomial kernels.)
+        const double md = ls - mu, dd = md - 0.6931471805599453;
+        if ((dd <= 1.0 ? dd * dd : fma(2.0, dd, -1.0)) > kLnCut * (sg * sg)) {
+            vals[0] = vals[1] = vals[2] = 0.0;
+            return;
+        }
+        const double Tm = fmin(fmax(md, 0.0) + 12.0 * sg, 2.0 * sqrt(fma(dd, dd, kLnCut * (sg * sg))));
         // the Long kernel jumps where the larger particle x = s / (1 + e^-t) crosses x_t: at t_b = ln(x_t / (s - x_t)) for
         // x_t < s < 2 x_t (below, both stay under x_t; above, x >= s / 2 >= x_t) -- the inner panels are split there
         double tb = 0.0;
@@ -842,7 +852,6 @@ __device__ __forceinline__ void conv_T_lognormal(const QArgs &Q, const double *_
 // computed.  Per inner point: one LDS read, one exponential, four FMAs.  The outer rule is the adaptive walk over ln s of
 // conv_T_lognormal (same range, marks and tolerance).
 constexpr int kLnQTab = 24;
-constexpr double kLnCut = 42.0;
 template <int N, int KIND>
 __device__ __forceinline__ void conv_T_lognormal_poly(const QArgs &Q, double n, double mu, double sg, const double (&cm)[N],
                                                       const double (&wm)[N], const ConvLogDensity (&lg)[N], int j,

@@ -1012,7 +1012,18 @@ static void co_TL_node(double ls, double *vals, void *v) {
         return;
     }
     const double mu = c->pdists[c->j].theta, sg = c->pdists[c->j].k, c2 = 1.0 / (2.0 * sg * sg), nrm = c2 / M_PI;
-    const double s = exp(ls), Tm = fmax(ls - mu, 0.0) + 12.0 * sg;
+    const double s = exp(ls);
+    /* Round 6: the Gaussian factor of the inner integrand is the polynomial kernels' (co_TL_node_poly) whatever the kernel
+     * function -- exp(-[(m - q(t))^2 + t^2 / 4] / sigma^2) -- so the same two bounds hold: nothing where
+     * min(d^2, 2 d - 1) > 42 sigma^2 (d = m - ln 2: the density of the sum is below e^-42 of its peak), and nothing beyond
+     * T = 2 sqrt(d^2 + 42 sigma^2).  Without them a shape clamped to sigma = eps ran the full 256 panels at every node -- and the
+     * 63 other parcels of its wave waited: 2e5 parcel-RHS/s where the polynomial kernels make 3.5e7. */
+    const double md = ls - mu, dd = md - 0.6931471805599453;
+    if ((dd <= 1.0 ? dd * dd : 2.0 * dd - 1.0) > CO_LN_CUT * (sg * sg)) {
+        vals[0] = vals[1] = vals[2] = 0.0;
+        return;
+    }
+    const double Tm = fmin(fmax(md, 0.0) + 12.0 * sg, 2.0 * sqrt(dd * dd + CO_LN_CUT * (sg * sg)));
     /* the Long kernel jumps where the larger particle x = s / (1 + e^-t) crosses x_t: at t_b = ln(x_t / (s - x_t)) for
      * x_t < s < 2 x_t (below, both stay under x_t; above, x >= s / 2 >= x_t) -- the inner panels are split there */
     double tb = 0.0;
