@@ -736,7 +736,7 @@ __device__ __forceinline__ double conv_long_G_mid_tab(const QArgs &Q, double k, 
 // minimum) for sigma >= 0.03, up to kLnPanels2Max = 256 below 0.001.  Rounds 2-3 used 12 panels whatever sigma: measured against
 // the rule with panels of sigma / 2 at s ~ 2 e^mu: 2e-10 of scale at sigma = 0.02, 6e-7 at 0.01, 1e-4 ... 1e-1 below 0.005; now
 // <= 1.5e-12 down to sigma = 0.003, 6.5e-11 at 0.002, 1e-9 ... 2e-6 at 0.001 (the cap), tests/test_numerical_oracle.py.
-constexpr int kLnPanels2 = 12, kLnPanels2Max = 256;
+constexpr int kLnPanels2 = 6, kLnPanels2Max = 256;   // (round 6: six panels of <= 3 sigma cover the bounded range 2 sqrt(84) sigma; 12 before the bound)
 constexpr double kLnCut = 42.0;   // the density of the sum of two Lognormal variates is followed down to e^-42 of its peak
 constexpr double kLnPanelSigmas = 3.0;
 template <int N, int KIND>

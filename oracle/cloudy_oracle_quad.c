@@ -954,7 +954,7 @@ static void co_T_bound(double b, double stop, double *B, void *v) {
  * boundary t = 0.  Outer: the adaptive rule over ln s in [mu - 8.5 sigma, mu + 8.5 sigma + (gamma + 2) sigma^2 + ln 2]
  * (budget CO_CONV_BUDGET_LN), marks at the other modes' cores (and ln x_t, ln 2 x_t for Long); inner: CO_LN_PAN2
  * panels of q Gauss-Legendre points over t in [0, max(ln s - mu, 0) + 12 sigma], split at the Long kernel's jump (co_TL_node). */
-#define CO_LN_PAN2 12
+#define CO_LN_PAN2 6   /* (round 6: the range is at most 2 sqrt(84) sigma = 18.3 sigma wide now -- six panels of <= 3 sigma cover it; 12 before the bound) */
 /* ... at least; as many as make a panel no wider than CO_LN_PAN2_SIGMAS sigma (the integrand in t is a Gaussian sqrt(2) sigma
  * to 2 sigma wide around its peak), up to CO_LN_PAN2_MAX: 12 for sigma >= 0.03, 256 below 0.001 (round 4; the fixed 12 were
  * off by 2e-10 at sigma = 0.02, 6e-7 at 0.01 and 1e-4 ... 1e-1 below 0.005) */

@@ -282,7 +282,8 @@ def test_converged_mode_narrow_lognormal_modes(oracle):
     try:
         for kind, prm in ((0, (1.0,)), (1, (0.7,)), (2, (3.14,)), (3, (0.5, 2.0, 1.0))):
             kf = O.kernel_func(kind, *prm)
-            for sg, bound in ((0.05, 2e-12), (0.02, 2e-12), (0.01, 2e-12), (0.005, 2e-12), (0.003, 2e-12), (0.002, 1e-10)):
+            # (round 6: wide shapes too -- the inner range is bounded by 2 sqrt(d^2 + 42 sigma^2) now and the minimum is six panels)
+            for sg, bound in ((1.0, 2e-12), (0.5, 2e-12), (0.2, 2e-12), (0.05, 2e-12), (0.02, 2e-12), (0.01, 2e-12), (0.005, 2e-12), (0.003, 2e-12), (0.002, 1e-10)):
                 pd = [O.make_dist(O.LOGNORMAL, 2.0, -1.0, sg), O.make_dist(O.GAMMA, 1.0, 0.9, 2.0)]
                 O.conv_set_ln_inner(0.5, 8192)
                 ref, sc = O.get_coal_ints_numerical_converged(pd, kf, q=8, tol=1e-12, with_scale=True)
