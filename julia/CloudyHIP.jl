@@ -190,6 +190,11 @@ mutable struct PlanCache
     key::Any
     plan::Union{Nothing,Plan}
 end
+# (The key is CONTENT-based although it is spelled objectid: CoalescenceData, CoalescenceTensor (an SMatrix inside) and the
+# kernel-function structs are immutable isbits structs (src/Sources/Coalescence.jl:45-53, src/Kernels/KernelTensors.jl:44-52,
+# KernelFunctions.jl:39-87), for which `===` compares bits and objectid hashes them.  A driver that rebuilds an EQUAL
+# CoalescenceData in every step therefore hits this cache and pays neither cloudy_plan_create nor hiprtc again; a changed
+# tensor, threshold, norm or velocity builds a new plan.)
 function cached_plan!(c::PlanCache, coal_type, ts, par)
     key = (objectid(coal_type isa NumericalCoalStyle ? par.kernel_func : par.coal_data), map(typeof, par.pdists),
            par.NProgMoms, par.norms, haskey(par, :vel) ? par.vel : ())
@@ -210,6 +215,9 @@ function batch_shape(m::AbstractVector, nmom)
     stride(m, 1) == 1 || error("state vector must be contiguous")
     return 1, 1
 end
+# (views: `stride` of a SubArray is the parent's stride times the step of the range, so `@view big[1:2:end, :]` is refused by the
+# unit-stride test below, `@view big[1001:2000, :]` passes with ld = the PARENT's leading dimension and the view's own pointer --
+# the slice-of-batch case tests/test_gpu_numerical.py runs through the same (n, ld) pair)
 function batch_shape(m::AbstractMatrix, nmom)
     size(m, 2) == nmom || error("state has $(size(m, 2)) moment columns, the plan has $nmom")
     stride(m, 1) == 1 || error("state must have unit stride along parcels (m[parcel, moment])")
