@@ -175,17 +175,17 @@ def test_launcher_ends_the_run_when_a_rank_dies(tmp_path, fault, expect):
 
 def test_launcher_wall_clock_limit_ends_a_hung_rank(tmp_path):
     """a rank that neither dies nor arrives: the parent's wall-clock limit (CLOUDY_BENCH_LAUNCH_TIMEOUT) ends the run"""
-    p, dt = _bench_dry(tmp_path, 2, "hang@before_barrier:1", {"CLOUDY_BENCH_LAUNCH_TIMEOUT": "12"})
+    p, dt = _bench_dry(tmp_path, 2, "hang@before_barrier:1", {"CLOUDY_BENCH_LAUNCH_TIMEOUT": "8"})
     assert p.returncode == 6 and dt < 60, (p.returncode, dt, p.stderr[-2000:])
-    assert "still running after 12 s" in p.stderr
+    assert "still running after 8 s" in p.stderr
 
 
 @pytest.mark.parametrize("fault", ["raise@before_barrier:1", "exit0@before_barrier:1", "hang@before_barrier:1"])
 def test_driver_launch_line_survives_a_dead_or_hung_rank(tmp_path, fault):
     """the same three failures under the DRIVER's launcher (`python -m torch.distributed.run ... bench.py --gpus 2`): the
     surviving rank's control-plane collective fails -- at once when the peer's sockets close, after
-    CLOUDY_BENCH_DIST_TIMEOUT (default 300 s, 15 s here) when the peer hangs -- with a one-line reason, non-zero exit"""
-    p, dt = _bench_dry(tmp_path, 2, fault, {"CLOUDY_BENCH_DIST_TIMEOUT": "15"}, launcher="torchrun",
+    CLOUDY_BENCH_DIST_TIMEOUT (default 300 s, 8 s here) when the peer hangs -- with a one-line reason, non-zero exit"""
+    p, dt = _bench_dry(tmp_path, 2, fault, {"CLOUDY_BENCH_DIST_TIMEOUT": "8"}, launcher="torchrun",
                        port=29643 + len(fault) % 7)
     assert p.returncode != 0 and dt < 60, (p.returncode, dt, p.stderr[-2000:])
     assert "bench.py rank" in p.stderr and "FAILED" in p.stderr or "injected failure" in p.stderr
