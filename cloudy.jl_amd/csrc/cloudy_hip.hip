@@ -88,7 +88,14 @@ ConvHints conv_hints(const cloudy_plan *plan, size_t n, hipStream_t stream) {
             (void)hipFree(p);
             return r;
         }
-        if (plan->hint_dev) plan->hint_old.push_back(plan->hint_dev);   // kernels of earlier calls may still use it
+        if (plan->hint_dev) {
+            // the costs the plan has learnt so far move over (stream-ordered after the memset): a batch that grew keeps the ranking
+            // of the parcels it already had
+            (void)hipMemcpyAsync(p, plan->hint_dev, plan->hint_cap, hipMemcpyDeviceToDevice, stream);
+            if (two) (void)hipMemcpyAsync(p + cap, plan->hint_dev + plan->hint_cap, plan->hint_cap, hipMemcpyDeviceToDevice, stream);
+            (void)hipGetLastError();
+            plan->hint_old.push_back(plan->hint_dev);   // kernels of earlier calls may still use it
+        }
         plan->hint_dev = p;
         plan->hint_cap = cap;
     }

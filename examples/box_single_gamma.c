@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <stdint.h>
 #include "cloudy_hip.h"
 
 #define CHECK(call)                                                              \
@@ -95,7 +96,19 @@ int main(void) {
     const double m0_exact = 1e8 * exp(-5.0 * 1e-2 * 120.0);
     printf("M(t=120) = [%.10e, %.10e, %.10e]  (exact M0 %.6e)\n", out[0], out[n], out[2 * n], m0_exact);
     printf("fused vs staged SSPRK33: max rel diff %.2e\n", worst);
-    const int ok = worst < 1e-13 && fabs(out[n] - 1e-2) < 1e-15 && fabs(out[0] / m0_exact - 1.0) < 6e-2;
+    int ok = worst < 1e-13 && fabs(out[n] - 1e-2) < 1e-15 && fabs(out[0] / m0_exact - 1.0) < 6e-2;
+
+    /* (iii) the batch form of the reference's silent clamps (cloudy_closure_stats): every box of the final state inverts to a
+     * regular Gamma closure -- no fallback, no clamp, consistent moments; one box with M2 below M1^2 / M0 is counted */
+    uint64_t counts[4];
+    CHECK(cloudy_closure_stats(plan, n, n, u, counts, NULL));
+    printf("closure stats of the final state: fallback %llu, k_min %llu, k_max %llu, inconsistent %llu\n",
+           (unsigned long long)counts[0], (unsigned long long)counts[1], (unsigned long long)counts[2], (unsigned long long)counts[3]);
+    ok = ok && counts[0] == 0 && counts[1] == 0 && counts[2] == 0 && counts[3] == 0;
+    out[2 * n] = 0.5 * out[n] * out[n] / out[0];   /* parcel 0: negative variance */
+    CHECK(cloudy_memcpy_h2d(u, out, bytes, NULL));
+    CHECK(cloudy_closure_stats(plan, n, n, u, counts, NULL));
+    ok = ok && counts[0] == 0 && counts[1] == 1 && counts[2] == 0 && counts[3] == 1;
 
     CHECK(cloudy_free(u));
     CHECK(cloudy_free(up));
