@@ -5,6 +5,7 @@
 #include "quad_kernels.hpp"
 
 namespace cloudy {
+static_assert(kConvUnrolledModes == CLOUDY_AOT_MAX_MODES, "quad_conv.hpp: the rolled form serves the plans beyond the ahead-of-time families");
 
 template <int N, int KIND, typename TIO, bool CONV>
 hipError_t launch_quad_io2(const HostPlan &h, const LaunchReq &r, const KArgs<N, 1> &A) {

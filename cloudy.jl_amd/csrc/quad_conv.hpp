@@ -41,6 +41,7 @@ namespace cloudy {
 #define CLOUDY_CONV_BLOCK 256
 #endif
 constexpr int kConvBlock = CLOUDY_CONV_BLOCK;
+constexpr int kConvUnrolledModes = 4;   // = CLOUDY_AOT_MAX_MODES (include/cloudy_hip.h): plans of more modes take conv_coal_ints_rolled
 
 // continued fraction of the incomplete beta function (DLMF 8.17.22), converging for x < (a+1)/(a+b+2):
 //   h = 1 / (1 + e_1 / (1 + e_2 / (1 + ...))),   e_1 = -(a+b) x / (a+1),
@@ -1059,12 +1060,19 @@ __device__ __forceinline__ void conv_rule_prepare(const QArgs &Q, int j, bool ln
 // together, walks the holes of the parcel's rules from 2 x_t down to x_t with the table code unconditional.  The accumulated
 // sums of a rule carry over (the acceptance test of a hole's panels compares with everything outside the hole); the bound
 // that ends a rule early covers the hole while the walk is above it (midneed[r] = false then: the hole is negligible too).
-template <int N, int KIND, bool LTAB, int PHASE, int NROW>
+// NRULES (round 6): the number of rules in `rb`.  N - 1 (the default): the merged walk of every rule of the parcel, rule r = mode r.
+// 1 with N > 2 (plans of more than CLOUDY_AOT_MAX_MODES modes, conv_coal_ints_rolled): ONE rule, that of mode `jsingle` (a run-time
+// index) -- the prepared rules of seven modes do not fit a lane's registers (2 303 spilled for N = 8), so such plans walk their rules
+// one after the other and prepare each just before its walk; nothing but the rule in hand is live in the loop.
+template <int N, int KIND, bool LTAB, int PHASE, int NROW, int NRULES = (N > 1 ? N - 1 : 1)>
 __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensity (&lg)[N],
-                                              const ConvRule<(N > 1 ? N - 1 : 1)> (&rb)[(N > 1 ? N - 1 : 1)],
-                                              double (&Traw)[(N > 1 ? N - 1 : 1)][3], bool (&midneed)[(N > 1 ? N - 1 : 1)],
-                                              const double (&gtab)[NROW][kConvBlock], int &cost) {
-    constexpr int NM = N > 1 ? N - 1 : 1, NR = NM;
+                                              const ConvRule<(N > 1 ? N - 1 : 1)> (&rb)[NRULES],
+                                              double (&Traw)[NRULES][3], bool (&midneed)[NRULES],
+                                              const double (&gtab)[NROW][kConvBlock], int &cost, int jsingle = 0) {
+    constexpr int NM = N > 1 ? N - 1 : 1, NR = NRULES;
+    constexpr bool kSingle = NRULES == 1 && NM > 1;
+    static_assert(NRULES == NM || NRULES == 1, "all the rules of the parcel, or one");
+    static_assert(!(kSingle && LTAB), "the per-rule tables belong to the merged walk");
     static_assert((KIND == KF_LONG) == (PHASE != 0), "the Long kernel's rules are walked in two phases, the others in one");
     // The Long kernel's G(s) behaves like (s - x_t)^k just above x_t (the Beta(k, k) law of tau ends like tau^(k-1)), so K15
     // converges only algebraically in the panel whose lower edge is x_t; rounds 3-4 ran the Long rules at a hundredth of the
@@ -1079,7 +1087,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
     double hlo = 0.0, hhi = 0.0;   // the hole [x_t, 2 x_t] in the rule's variable, clamped to [t_lo, t_hi]
     bool mid_flag = false;         // PHASE 1, set by next_panel when a rule ends: its hole has to be walked
     // ---- the state of the rule in hand
-    int j = -1;
+    int j = -1, jm = -1;   // the rule in hand and its mode (the same number in the merged walk)
     double A = 1.0, lgA = 0.0, thj = 1.0, lnthj = 0.0, tlo = 0.0, thi = 0.0, kj = 1.0, lgB = 0.0, rB = 0.0, gl = 0.0, c0 = 0.0;
     double scaleS[3] = {1.0, 1.0, 1.0}, out[3] = {0.0, 0.0, 0.0};
     double tmode = 0.0, lwmode = 0.0, lnup = 0.0, ltlo[NM];
@@ -1138,7 +1146,13 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
             tmode = sel ? rb[r].tmode : tmode;
             lwmode = sel ? rb[r].lwmode : lwmode;
             convex = sel ? rb[r].convex : convex;
-            lnup = sel ? (N - 1 - r == 1 ? 0.0 : N - 1 - r == 2 ? 0.6931471805599453 : 1.0986122886681098) : lnup;
+            const int rm = kSingle ? jsingle : r;   // the mode of rule r
+            {   // ln of the number of modes above (round 6: to ln 7; ln 3 stood in for every count >= 3 -- plans of up to 4 modes)
+                const int nup = N - 1 - rm;
+                const double l = nup <= 1 ? 0.0 : nup == 2 ? 0.6931471805599453 : nup == 3 ? 1.0986122886681098 : nup == 4 ? 1.3862943611198906
+                                 : nup == 5 ? 1.6094379124341003 : nup == 6 ? 1.791759469228055 : 1.9459101090932196;
+                lnup = sel ? l : lnup;
+            }
 #pragma unroll
             for (int sl = 0; sl < NM; ++sl) ltlo[sl] = sel ? rb[r].ltlo[sl] : ltlo[sl];
             if (KIND == KF_LONG) {
@@ -1159,33 +1173,41 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
                 mk.w[sl] = sel ? rb[r].mw[sl] : mk.w[sl];
                 mk.I[sl] = sel ? rb[r].mI[sl] : mk.I[sl];
             }
-            // the densities of the rule's own mode (r) and of the others, ascending (slot sl is mode sl < r ? sl : sl + 1)
+            // the densities of the rule's own mode (rm) and of the others, ascending (slot sl is mode sl < rm ? sl : sl + 1)
+            double ra = 0.0, rbb = 0.0, rc = 0.0;   // the own mode's coefficients
 #pragma unroll
-            for (int m = 0; m < N; ++m)
-                if (m == r) {
-                    own.a = sel ? lg[m].a : own.a;
-                    own.b = sel ? lg[m].b : own.b;
-                    own.c = sel ? lg[m].c : own.c;
-                    own.lognormal = sel ? lg[m].lognormal : own.lognormal;
-                } else {
-                    const int sl = m < r ? m : m - 1;
+            for (int m = 0; m < N; ++m) {
+                const bool is_own = m == rm;
+                ra = is_own ? lg[m].a : ra;
+                rbb = is_own ? lg[m].b : rbb;
+                rc = is_own ? lg[m].c : rc;
+            }
 #pragma unroll
-                    for (int s2 = 0; s2 < NM; ++s2)
-                        if (s2 == sl) {
-                            oth[s2].a = sel ? lg[m].a : oth[s2].a;
-                            oth[s2].b = sel ? lg[m].b : oth[s2].b;
-                            oth[s2].c = sel ? lg[m].c : oth[s2].c;
-                            oth[s2].lognormal = sel ? lg[m].lognormal : oth[s2].lognormal;
-                            da[s2] = sel ? lg[m].a - lg[r].a : da[s2];
-                            nb[s2] = sel ? lg[r].b - lg[m].b : nb[s2];
-                            nc[s2] = sel ? lg[r].c - lg[m].c : nc[s2];
-                        }
+            for (int m = 0; m < N; ++m) {
+                const bool is_own = m == rm;
+                own.a = (sel && is_own) ? lg[m].a : own.a;
+                own.b = (sel && is_own) ? lg[m].b : own.b;
+                own.c = (sel && is_own) ? lg[m].c : own.c;
+                own.lognormal = (sel && is_own) ? lg[m].lognormal : own.lognormal;
+                const int sl = m < rm ? m : m - 1;
+#pragma unroll
+                for (int s2 = 0; s2 < NM; ++s2) {
+                    const bool hit = sel && !is_own && s2 == sl;
+                    oth[s2].a = hit ? lg[m].a : oth[s2].a;
+                    oth[s2].b = hit ? lg[m].b : oth[s2].b;
+                    oth[s2].c = hit ? lg[m].c : oth[s2].c;
+                    oth[s2].lognormal = hit ? lg[m].lognormal : oth[s2].lognormal;
+                    da[s2] = hit ? lg[m].a - ra : da[s2];
+                    nb[s2] = hit ? rbb - lg[m].b : nb[s2];
+                    nc[s2] = hit ? rc - lg[m].c : nc[s2];
                 }
+            }
         }
 #pragma unroll
-        for (int sl = 0; sl < NM; ++sl) upw[sl] = go ? (sl >= jn ? 1.0 : 0.0) : upw[sl];
+        for (int sl = 0; sl < NM; ++sl) upw[sl] = go ? (sl >= (kSingle ? jsingle : jn) ? 1.0 : 0.0) : upw[sl];
         if (go) {
             j = jn;
+            jm = kSingle ? jsingle : jn;
             mk.shift = lnthj;
             h0 = (thi - tlo) * (1.0 / double(kConvNInit));
             gap = 1e-7 * (thi - tlo);
@@ -1237,7 +1259,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
         for (int sl = 0; sl < NM; ++sl) {
             const double lr = oth[sl].lognormal ? oth[sl](sb, lsb) - ow : fma(da[sl], lsb, fma(nb[sl], sb, nc[sl]));
             const double l = fmax(lr, ltlo[sl]);
-            lmax = sl >= j ? fmax(lmax, l) : lmax;
+            lmax = sl >= jm ? fmax(lmax, l) : lmax;
         }
         const double lsig = convex ? fmin(0.0, lmax + lnup) : 0.0;
         double Bv = exp_fin(lw + lsig) * (cur - stop);
@@ -1374,7 +1396,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
                 Traw[r][2] = st ? out[2] : Traw[r][2];
                 if (PHASE == 1) midneed[r] = st ? mid_flag : midneed[r];
             }
-            next_rule(done, ConvInt<(NR > 1 ? 1 : 0)>{});
+            next_rule(done, ConvInt<1>{});
             (void)next_panel(done && busy);
         }
     }
@@ -1488,6 +1510,127 @@ __device__ __forceinline__ void conv_long_phase2_split(const KArgs<N, 1> &A, con
     sp.cost2 = (int)xt[3 * NM][tl];
 }
 
+// ---- plans of more than CLOUDY_AOT_MAX_MODES modes (round 6; VERDICT r5 missing #3) ----
+// conv_coal_ints below keeps, per lane, the closed-form tables of EVERY mode across the unrolled pair loops (25 doubles each) and
+// the prepared rules of every mode across the merged walk (~38 each): fine for the 2-4 modes of the reference's examples, 2 303
+// spilled registers and 15-40 s of hiprtc per kernel for eight.  The reference is generic in N (Coalescence.jl:470-489), so such
+// plans run -- here with loops over the modes that STAY loops: (n, theta, k) of the modes and the 3N partial tendencies wait in the
+// lane's LDS column (indexed at run time), a pair's two mode tables are built when the pair is taken, and the rules are walked one
+// after the other, each prepared just before its walk (conv_T_merged with NRULES = 1) -- the same functions, the same order of
+// every accumulation, so the same bits as the unrolled form would give; one wave per workgroup (jit.hpp: 64 threads for such plans)
+// keeps the LDS of eight workgroups on a CU.
+template <int N, int KIND>
+__device__ __forceinline__ void conv_coal_ints_rolled(const KArgs<N, 1> &A, const QArgs &Q, const double *__restrict__ tab,
+                                                      const double (&nn)[N], const double (&th)[N], const double (&kk)[N],
+                                                      double (&acc)[N][3], int &cost) {
+    constexpr int NM = N - 1;
+    __shared__ double sh_ntk[3 * N][kConvBlock];
+    __shared__ double sh_acc[3 * N][kConvBlock];
+    __shared__ double sh_none[1][kConvBlock];   // (the walk's table argument: plans of this size have no incomplete-beta tables)
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+        sh_ntk[3 * m + 0][t] = nn[m];
+        sh_ntk[3 * m + 1][t] = th[m];
+        sh_ntk[3 * m + 2][t] = kk[m];
+        sh_acc[3 * m + 0][t] = sh_acc[3 * m + 1][t] = sh_acc[3 * m + 2][t] = 0.0;
+    }
+    // ---- every closed form (pairs j <= k), in the order of conv_coal_ints
+#pragma unroll 1
+    for (int j = 0; j < N; ++j) {
+        ConvMode mj;
+        conv_mode<KIND>(Q, A.dist_type[j] == DIST_LOGNORMAL, sh_ntk[3 * j][t], sh_ntk[3 * j + 1][t], sh_ntk[3 * j + 2][t], mj);
+        double pr[4];
+        conv_pair<KIND>(Q, tab, mj, mj, true, pr);
+        sh_acc[3 * j + 0][t] -= 0.5 * pr[0];
+        sh_acc[3 * j + 2][t] += pr[3];
+#pragma unroll 1
+        for (int k = j + 1; k < N; ++k) {
+            ConvMode mk;
+            conv_mode<KIND>(Q, A.dist_type[k] == DIST_LOGNORMAL, sh_ntk[3 * k][t], sh_ntk[3 * k + 1][t], sh_ntk[3 * k + 2][t], mk);
+            conv_pair<KIND>(Q, tab, mj, mk, false, pr);
+            sh_acc[3 * j + 0][t] -= pr[0];
+            sh_acc[3 * j + 1][t] -= pr[1];
+            sh_acc[3 * j + 2][t] -= pr[2];
+            sh_acc[3 * k + 1][t] += pr[1];
+            sh_acc[3 * k + 2][t] += fma(2.0, pr[3], pr[2]);
+        }
+    }
+    // ---- T_m of every mode but the last, one rule at a time
+    cost = 0;
+#pragma unroll 1
+    for (int j = 0; j < N - 1; ++j) {
+        const double nj = sh_ntk[3 * j][t], thj = sh_ntk[3 * j + 1][t], kj = sh_ntk[3 * j + 2][t];
+        const bool lnj = A.dist_type[j] == DIST_LOGNORMAL;   // wave-uniform
+        double T0 = 0.0, T1 = 0.0, T2 = 0.0;
+        if (nj > 0.0) {
+            // the log densities and cores of all modes: built per rule, nothing of them is live across a walk
+            ConvLogDensity lg[N];
+            double cm[N], wm[N];
+#pragma unroll
+            for (int m = 0; m < N; ++m) {
+                ConvMode md;
+                md.lognormal = A.dist_type[m] == DIST_LOGNORMAL;
+                md.n = sh_ntk[3 * m + 0][t];
+                md.th = sh_ntk[3 * m + 1][t];
+                md.k = sh_ntk[3 * m + 2][t];
+                md.lnth = md.lognormal ? md.th : log_pos(md.th);
+                md.lgk = md.lognormal ? 0.0 : lgamma_pos(md.k);
+                lg[m] = conv_log_density(md);
+                cm[m] = conv_ln_mean(md);
+                wm[m] = conv_core_width(md);
+            }
+            ConvMode mj;
+            conv_mode<KIND>(Q, lnj, nj, thj, kj, mj);
+            double pr[4];
+            conv_pair<KIND>(Q, tab, mj, mj, true, pr);
+            if (lnj) {
+                const double totals[3] = {0.5 * pr[0], pr[1], pr[2] + pr[3]};
+                if (KIND == KF_CONSTANT || KIND == KF_LINEAR)
+                    conv_T_lognormal_poly<N, (KIND == KF_LINEAR ? KF_LINEAR : KF_CONSTANT)>(Q, nj, thj, kj, cm, wm, lg, j, totals, T0, T1, T2, cost);
+                else
+                    conv_T_lognormal<N, KIND>(Q, tab, nj, thj, kj, cm, wm, lg, j, totals, T0, T1, T2);
+            } else {
+                const double prefj = KIND == KF_LONG ? 0.5 * (nj * nj) : 0.5 * pr[0];
+                double sc[3] = {1.0, 1.0, 1.0};
+                if (KIND == KF_LONG) {
+                    const double rp = 1.0 / prefj;
+                    sc[0] = (0.5 * pr[0]) * rp;
+                    sc[1] = pr[1] * rp;
+                    sc[2] = (pr[2] + pr[3]) * rp;
+                }
+                ConvRule<NM> rb[1];
+                conv_rule_prepare<N, KIND>(Q, j, false, nj, kj, thj, mj.lnth, mj.lgk, cm, wm, lg, sc, rb[0]);
+                double Traw[1][3] = {{0.0, 0.0, 0.0}};
+                bool midneed[1] = {false};
+                conv_T_merged<N, KIND, false, (KIND == KF_LONG ? 1 : 0), 1, 1>(Q, lg, rb, Traw, midneed, sh_none, cost, j);
+                if (KIND == KF_LONG)
+                    conv_T_merged<N, KIND, false, (KIND == KF_LONG ? 2 : 0), 1, 1>(Q, lg, rb, Traw, midneed, sh_none, cost, j);
+                double T[3] = {Traw[0][0], Traw[0][1], Traw[0][2]};
+                if (KIND != KF_LONG) {   // the mass below t_lo, as conv_coal_ints
+                    const double Ash = rb[0].A, tlo = rb[0].tlo;
+                    const double u_lo = exp_fin(tlo);
+                    T[0] = fma(conv_one_minus_w<N>(lg, j, u_lo * thj, tlo + mj.lnth), exp_fin(fma(Ash, tlo, -lgamma_pos(Ash + 1.0))), T[0]);
+                }
+                T0 = T[0] * prefj;
+                T1 = T[1] * prefj;
+                T2 = T[2] * prefj;
+            }
+        }
+        sh_acc[3 * j + 0][t] -= T0;
+        sh_acc[3 * j + 1][t] -= T1;
+        sh_acc[3 * j + 2][t] -= T2;
+        sh_acc[3 * j + 3][t] += T0;
+        sh_acc[3 * j + 4][t] += T1;
+        sh_acc[3 * j + 5][t] += T2;
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) acc[k][m] = sh_acc[3 * k + m][t];
+}
+
 // get_coal_ints(::NumericalCoalStyle, ...) for the parcel of this lane in converged mode: acc[k][m], normalised units,
 // kernel constants INCLUDED.  tab: nq Gauss-Legendre nodes on [-1, 1], then nq weights.
 // SPLIT (round 6; the Long kernel's table plans, the kernel behind cloudy_coal_rhs only): the holes of a parcel's rules (phase 2)
@@ -1507,6 +1650,10 @@ __device__ __forceinline__ void conv_coal_ints(const KArgs<N, 1> &A, const QArgs
                                                const double (&nn)[N], const double (&th)[N], const double (&kk)[N],
                                                double (&acc)[N][3], int &cost, ConvSplit *sp = nullptr) {
     static_assert(!SPLIT || (KIND == KF_LONG && N > 1 && N <= 3), "the split walk serves the Long kernel's table plans");
+    if constexpr (N > kConvUnrolledModes) {   // (plans that exist only as kernels compiled for them)
+        conv_coal_ints_rolled<N, KIND>(A, Q, tab, nn, th, kk, acc, cost);
+        return;
+    }
     cost = 0;   // panel evaluations of the parcel's Gamma-weight rules (the only part whose length differs between parcels)
     ConvMode md[N];
     ConvLogDensity lg[N];

@@ -60,7 +60,15 @@ def cmd_conv(a, pkg, L):
     dists = [int(x) for x in a.dists.split(",")]
     N = len(dists)
     n = a.n
-    mom = bench.lognorm_example_moments(n) if a.lognorm_example else bench.synth_moments(N, n, bench.SEED)
+    if a.lognorm_example:
+        mom = bench.lognorm_example_moments(n)
+    elif N <= 4:
+        mom = bench.synth_moments(N, n, bench.SEED)
+    else:   # N size classes between 1e-12 and 1e-4 kg, number densities falling with size (as tests/test_gpu_parity.py::many_mode_moments)
+        rng = np.random.Generator(np.random.Philox(key=bench.SEED))
+        edges = np.logspace(-12, -4, N + 1)
+        mom = np.ascontiguousarray(np.concatenate([bench._gamma_mode(rng, n, 1e6 * 10.0 ** (-1.5 * i * 8 / N), 1e9 * 10.0 ** (-1.5 * i * 8 / N),
+                                                                      0.5 if i == 0 else 1.0, 7.0, edges[i], edges[i + 1]) for i in range(N)]))
     m, dm = pkg.DeviceArray.from_numpy(mom), pkg.DeviceArray.zeros(3 * N, n)
     kfn = pkg.get_normalized_kernel_func(kernel_functions(pkg)[a.kernel], bench.NORMS)
     plan = pkg.NumericalPlan(dists, kfn, bench.NORMS, a.fixed or 8, specialize=1,
