@@ -12,6 +12,8 @@ every experiment switch of the library is an environment variable, so an A/B run
         cloudy_rainshaft_ssprk33_steps and cloudy_rainshaft_rhs (ms per 1e7 cells)
   python tools/timeit.py integrators [--parcels P]
         cloudy_ssprk33_steps / cloudy_tsit5_steps of the tensor plans cfg3a, cfg3b, cfg2
+  python tools/timeit.py host [--parcels P]
+        cloudy_coal_rhs_host on cfg3a: the PCIe-inclusive rate (host arrays staged through the device)
 
 switches read by the library: CLOUDY_HIP_LIB, CLOUDY_HIP_JIT, CLOUDY_HIP_JIT_DEFS, CLOUDY_HIP_CONV_HINTS, CLOUDY_HIP_CONV_BLOCK,
 CLOUDY_HIP_CONV_ROUNDS, CLOUDY_HIP_LONG_SPLIT, CLOUDY_HIP_JIT_QUAD_WAVES, CLOUDY_HIP_RS_BLOCK, CLOUDY_HIP_RS_FUSED_RHS, ..."""
@@ -99,6 +101,25 @@ def cmd_columns(a, pkg, L):
           f"{os.environ.get('CLOUDY_HIP_RS_BLOCK', 'auto')})", flush=True)
 
 
+def cmd_host(a, pkg, L):
+    """the PCIe-inclusive rate: cloudy_coal_rhs_host stages host arrays through the device (never the bench's `value`)"""
+    import time
+
+    n = a.parcels or 10_000_000
+    wl = bench.make_workload("cfg3a", n)
+    plan = wl["coal_data"].plan(wl["dist_types"])
+    mom, out = np.ascontiguousarray(wl["mom"]), np.zeros_like(wl["mom"])
+    pin, pout = mom.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)
+    best = 1e9
+    for _ in range(4):
+        t0 = time.perf_counter()
+        pkg._lib.check(L.cloudy_coal_rhs_host(plan.handle, n, n, pin, pout))
+        best = min(best, time.perf_counter() - t0)
+    gb = 2 * plan.nmom * 8 * n / 1e9
+    print(f"cloudy_coal_rhs_host, cfg3a, {n} parcels (pageable host arrays, {gb:.2f} GB over PCIe): {best * 1e3:.1f} ms = {n / best:.3e} parcel-RHS/s "
+          f"= {gb / best:.1f} GB/s of host traffic", flush=True)
+
+
 def cmd_integrators(a, pkg, L):
     for name in ("cfg3a", "cfg3b", "cfg2"):
         n = a.parcels or 4_000_000
@@ -134,9 +155,11 @@ def main():
     r.add_argument("--steps", type=int, default=2)
     i = sub.add_parser("integrators")
     i.add_argument("--parcels", type=int, default=0)
+    hh = sub.add_parser("host")
+    hh.add_argument("--parcels", type=int, default=0)
     a = ap.parse_args()
     pkg = load_package()
-    {"kernels": cmd_kernels, "conv": cmd_conv, "columns": cmd_columns, "integrators": cmd_integrators}[a.cmd](a, pkg, pkg.lib())
+    {"kernels": cmd_kernels, "conv": cmd_conv, "columns": cmd_columns, "integrators": cmd_integrators, "host": cmd_host}[a.cmd](a, pkg, pkg.lib())
 
 
 if __name__ == "__main__":
