@@ -853,13 +853,41 @@ __device__ __forceinline__ void conv_T_lognormal(const QArgs &Q, const double *_
 // computed.  Per inner point: one LDS read, one exponential, four FMAs.  The outer rule is the adaptive walk over ln s of
 // conv_T_lognormal (same range, marks and tolerance).
 constexpr int kLnQTab = 24;
+// exp_fin (device_math.hpp: the same reduction, the same polynomial, the same bits) with its constants HELD in registers: the
+// trapezoidal loop below is one exponential and five other operations per point, and the compiler rebuilt the ten coefficients
+// with two v_mov_b32 each in every trip (16 of the 48 VALU instructions per point; round 6, tools/isa_loops.py) -- constants
+// are "free to rematerialise" in its books, and a v_fmac overwrites its addend.  An empty asm makes each an opaque register
+// value defined once, before the walk; v_fma_f64 then reads it in place.
+struct ExpKept {
+    double l2e, nh, nl, c[11];
+    __device__ __forceinline__ ExpKept() {
+        l2e = 1.4426950408889634, nh = -0.69314718055989033, nl = -5.497923018708371e-14;
+        c[0] = 0x1.adeb8db5d7212p-26, c[1] = 0x1.28afdbfa89bf0p-22, c[2] = 0x1.71dedfc117959p-19, c[3] = 0x1.a019970598987p-16;
+        c[4] = 0x1.a01a014a32d85p-13, c[5] = 0x1.6c16c18581530p-10, c[6] = 0x1.1111111121b01p-7, c[7] = 0x1.55555555500b2p-5;
+        c[8] = 0x1.5555555555513p-3, c[9] = 0x1.000000000000bp-1, c[10] = 1.0;
+        asm volatile("" : "+v"(l2e), "+v"(nh), "+v"(nl));
+#pragma unroll
+        for (int i = 0; i < 10; ++i) asm volatile("" : "+v"(c[i]));
+    }
+    __device__ __forceinline__ double operator()(double x) const {
+        const double n = __builtin_rint(x * l2e);
+        double r = fma(n, nh, x);
+        r = fma(n, nl, r);
+        double p = c[0];
+#pragma unroll
+        for (int i = 1; i < 10; ++i) p = fma(p, r, c[i]);
+        p = fma(p, r, 1.0);
+        p = fma(p, r, 1.0);
+        return ldexp(p, (int)n);
+    }
+};
 template <int N, int KIND>
 __device__ __forceinline__ void conv_T_lognormal_poly(const QArgs &Q, double n, double mu, double sg, const double (&cm)[N],
                                                       const double (&wm)[N], const ConvLogDensity (&lg)[N], int j,
                                                       const double (&totals)[3], double &T0, double &T1, double &T2, int &cost) {
     static_assert(KIND == KF_CONSTANT || KIND == KF_LINEAR, "polynomial kernels only");
     constexpr double gtop = KIND == KF_LINEAR ? 1.0 : 0.0, ln2 = 0.6931471805599453;
-    __shared__ double sh_q[kLnQTab][kConvBlock];
+    __shared__ double sh_q[kLnQTab + 1][kConvBlock];
     const int lane = threadIdx.x;
     const double L0 = fma(-8.5, sg, mu), L1 = mu + 8.5 * sg + (gtop + 2.0) * (sg * sg) + ln2;
     const double c1 = 1.0 / (sg * sg), h = fmin(sg, 0.5), rh = 1.0 / h, pref = 0.5 * (n * n);
@@ -887,6 +915,7 @@ __device__ __forceinline__ void conv_T_lognormal_poly(const QArgs &Q, double n, 
             }
     }
     const double kc = Q.kf[0] * (0.3183098861837907 * c1);   // c / (pi sigma^2)
+    const ExpKept ek;
     const auto node = [&](double ls, double (&vals)[3]) {
         const double m = ls - mu, d = m - ln2;
         const double lb = (d <= 1.0 ? d * d : fma(2.0, d, -1.0)) * c1;   // a lower bound of the exponent over t
@@ -896,18 +925,26 @@ __device__ __forceinline__ void conv_T_lognormal_poly(const QArgs &Q, double n, 
             const int npt = (int)ceil(Tm * rh);
             sum = 0.5 * exp_fin(-(d * d) * c1);   // t = 0
             const double hq = 0.25 * (h * h);
-            double vv = exp_fin(-h * double(kLnQTab));   // e^(-t) beyond the table
+            // the points served by the table, then (sigma > 1/2 only) the ones beyond it: two loops, so that the first carries
+            // neither the second's e^(-t) nor its select (round 6: 48 -> 27 VALU instructions per point together with ek)
+            const int ntab = npt < kLnQTab ? npt : kLnQTab;
+            double fi = 0.0, qn = sh_q[0][lane];
 #pragma unroll 1
-            for (int i = 1; i <= npt; ++i) {
-                double qd;   // q(i h) - ln 2
-                if (i <= kLnQTab) {
-                    qd = sh_q[i - 1][lane];
-                } else {
+            for (int i = 0; i < ntab; ++i) {
+                const double dq = d - qn;
+                qn = sh_q[i + 1][lane];   // (the next trip's value, asked for before this trip's arithmetic; row kLnQTab is padding)
+                fi += 1.0;
+                sum += ek(-fma(dq, dq, hq * (fi * fi)) * c1);
+            }
+            if (npt > kLnQTab) {
+                double vv = exp_fin(-h * double(kLnQTab));   // e^(-t) at the end of the table
+#pragma unroll 1
+                for (int i = kLnQTab + 1; i <= npt; ++i) {
                     vv *= eh;
-                    qd = fma(0.5 * h, double(i), log1p(vv) - ln2);
+                    fi += 1.0;
+                    const double dq = d - fma(0.5 * h, fi, log1p(vv) - ln2);
+                    sum += ek(-fma(dq, dq, hq * (fi * fi)) * c1);
                 }
-                const double dq = d - qd, fi = double(i);
-                sum += exp_fin(-fma(dq, dq, hq * (fi * fi)) * c1);
             }
         }
         const double s = exp_fin(ls);
