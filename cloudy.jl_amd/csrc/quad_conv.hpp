@@ -738,7 +738,19 @@ __device__ __forceinline__ double conv_long_G_mid_tab(const QArgs &Q, double k, 
 // the rule with panels of sigma / 2 at s ~ 2 e^mu: 2e-10 of scale at sigma = 0.02, 6e-7 at 0.01, 1e-4 ... 1e-1 below 0.005; now
 // <= 1.5e-12 down to sigma = 0.003, 6.5e-11 at 0.002, 1e-9 ... 2e-6 at 0.001 (the cap), tests/test_numerical_oracle.py.
 constexpr int kLnPanels2 = 6, kLnPanels2Max = 256;   // (round 6: six panels of <= 3 sigma cover the bounded range 2 sqrt(84) sigma; 12 before the bound)
-constexpr double kLnCut = 42.0;   // the density of the sum of two Lognormal variates is followed down to e^-42 of its peak
+constexpr double kLnCut = 32.0;   // the density of the sum of two Lognormal variates is followed down to e^-32 of its peak (42 until late in round 6)
+// The end of the inner range in t (round 6): sigma^2 E(t) = (d - qd(t))^2 + t^2 / 4 with qd = ln cosh(t / 2) >= sqrt(1 + t^2 / 4) - 1 =
+// w - 1 (equal at 0; the derivative of the difference is tanh x - x / sqrt(1 + x^2) >= 0), and E_min <= E(0) = d^2 / sigma^2:
+// wherever w - 1 >= d, sigma^2 E >= (w - 1 - d)^2 + w^2 - 1 > d^2 + kLnCut sigma^2 for every
+// w > max(1 + max(d, 0), [(1 + d) + sqrt((d - 1)^2 + 2 kLnCut sigma^2)] / 2).  The older bounds (t^2 / 4 alone; m + 12 sigma) stay as
+// well.  At d = 0, sigma = ln 2: 6.3 against 7.8 (the true end: 4.9), about half for d < 0; a few per cent for sigma << 1.
+__device__ __forceinline__ double conv_ln_inner_top(double m, double d, double sg) {
+    const double cs = kLnCut * (sg * sg), dm = d - 1.0;
+    const double wr = 0.5 * ((1.0 + d) + sqrt(fma(dm, dm, 2.0 * cs)));
+    const double w = fmax(wr, 1.0 + fmax(d, 0.0));
+    const double T = fmin(fmax(m, 0.0) + 12.0 * sg, 2.0 * sqrt(fma(d, d, cs)));
+    return fmin(T, 2.0 * sqrt(fma(w, w, -1.0)));
+}
 constexpr double kLnPanelSigmas = 3.0;
 template <int N, int KIND>
 __device__ __forceinline__ void conv_T_lognormal(const QArgs &Q, const double *__restrict__ tab, double n, double mu, double sg,
@@ -767,15 +779,15 @@ __device__ __forceinline__ void conv_T_lognormal(const QArgs &Q, const double *_
     const auto node = [&](double ls, double (&vals)[3]) {
         const double s = exp_fin(ls);
         // Round 6: the Gaussian factor of the inner integrand is that of the polynomial kernels (conv_T_lognormal_poly) whatever
-        // the kernel function, so its two bounds hold here too: nothing where min(d^2, 2 d - 1) > 42 sigma^2, nothing beyond
-        // T = 2 sqrt(d^2 + 42 sigma^2).  (Without them a shape clamped to sigma = eps ran 256 panels x nq points at EVERY node while
+        // the kernel function, so its two bounds hold here too: nothing where min(d^2, 2 d - 1) > kLnCut sigma^2, nothing beyond
+        // T = 2 sqrt(d^2 + kLnCut sigma^2).  (Without them a shape clamped to sigma = eps ran 256 panels x nq points at EVERY node while
         // the 63 other parcels of its wave waited: 2e5 parcel-RHS/s against 3.5e7 for the polynomial kernels.)
         const double md = ls - mu, dd = md - 0.6931471805599453;
         if ((dd <= 1.0 ? dd * dd : fma(2.0, dd, -1.0)) > kLnCut * (sg * sg)) {
             vals[0] = vals[1] = vals[2] = 0.0;
             return;
         }
-        const double Tm = fmin(fmax(md, 0.0) + 12.0 * sg, 2.0 * sqrt(fma(dd, dd, kLnCut * (sg * sg))));
+        const double Tm = conv_ln_inner_top(md, dd, sg);
         // the Long kernel jumps where the larger particle x = s / (1 + e^-t) crosses x_t: at t_b = ln(x_t / (s - x_t)) for
         // x_t < s < 2 x_t (below, both stay under x_t; above, x >= s / 2 >= x_t) -- the inner panels are split there
         double tb = 0.0;
@@ -844,10 +856,11 @@ __device__ __forceinline__ void conv_T_lognormal(const QArgs &Q, const double *_
 //     G2(ln s) = 2 c s^gamma int_0^inf g(ln x) g(ln y) dt = c s^gamma / (pi sigma^2) int_0^inf exp(-[(m - q(t))^2 + t^2 / 4] / sigma^2) dt,
 //     m = ln s - mu,   q(t) = ln(2 cosh(t / 2))   (ln x - mu = m + t/2 - q, ln y - mu = m - t/2 - q),
 // an EVEN, analytic integrand (poles of q at t = +- i pi) that decays like a Gaussian: the trapezoidal rule converges
-// geometrically.  Step h = min(sigma, 1/2): <= 2e-13 of the density's peak against 30-digit mpmath for sigma from 0.002 to 2
-// (1.2 sigma: 3e-12; 1.4 sigma: 4e-9).  Range: the integrand is below e^-42 of its maximum beyond
-// T = min(max(m, 0) + 12 sigma, 2 sqrt((m - ln 2)^2 + 42 sigma^2)) (E(t) >= t^2 / (4 sigma^2), E_min <= E(0)); and the whole
-// density is below e^-42 of its peak where min(d^2, 2 d - 1) > 42 sigma^2, d = m - ln 2 (q <= ln 2 + t^2 / 8): zero there --
+// geometrically.  Step h = min(sigma, 1/2): <= 4e-13 of the density's peak against 30-digit mpmath for sigma <= 0.3 and sigma >= ln 2,
+// rising to 3e-10 at sigma = 1/2, where the step is at both of its limits (0.4: 1.4e-11, 0.45: 7e-11, 0.55: 3e-11, 0.6: 4e-12; round 6
+// re-measured -- round 5's "2e-13 from 0.002 to 2" had not sampled that neighbourhood; 1.2 sigma: 3e-12 ... 5e-8; 1.4 sigma: 4e-9).  Range: the integrand is below e^-kLnCut of its maximum beyond
+// T = min(max(m, 0) + 12 sigma, 2 sqrt((m - ln 2)^2 + kLnCut sigma^2)) (E(t) >= t^2 / (4 sigma^2), E_min <= E(0)); and the whole
+// density is below e^-kLnCut of its peak where min(d^2, 2 d - 1) > kLnCut sigma^2, d = m - ln 2 (q <= ln 2 + t^2 / 8): zero there --
 // which also bounds the number of points by ~20 for every sigma <= 1/2, clamped shapes included.  q(i h) does not depend on s:
 // the first kLnQTab values wait in the lane's own LDS slots (conflict-free, no barrier), further ones (sigma > 1/2 only) are
 // computed.  Per inner point: one LDS read, one exponential, four FMAs.  The outer rule is the adaptive walk over ln s of
@@ -921,7 +934,7 @@ __device__ __forceinline__ void conv_T_lognormal_poly(const QArgs &Q, double n, 
         const double lb = (d <= 1.0 ? d * d : fma(2.0, d, -1.0)) * c1;   // a lower bound of the exponent over t
         double sum = 0.0;
         if (lb <= kLnCut) {
-            const double Tm = fmin(fmax(m, 0.0) + 12.0 * sg, 2.0 * sqrt(fma(d, d, kLnCut * (sg * sg))));
+            const double Tm = conv_ln_inner_top(m, d, sg);
             const int npt = (int)ceil(Tm * rh);
             sum = 0.5 * exp_fin(-(d * d) * c1);   // t = 0
             const double hq = 0.25 * (h * h);

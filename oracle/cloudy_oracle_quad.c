@@ -981,9 +981,23 @@ typedef struct {
 /* Round 5 -- polynomial kernels (constant, linear: K = c s^gamma leaves the inner integral): the inner integral is the density
  * of S = X + Y in ln s,  G2 = c s^gamma / (pi sigma^2) int_0^inf exp(-[(m - q(t))^2 + t^2 / 4] / sigma^2) dt,  m = ln s - mu,
  * q(t) = ln(2 cosh(t / 2)) -- even, analytic, Gaussian decay -- by the TRAPEZOIDAL rule with step h = min(sigma, 1/2) over
- * [0, T], T = min(max(m, 0) + 12 sigma, 2 sqrt(d^2 + 42 sigma^2)), d = m - ln 2; zero where min(d^2, 2 d - 1) > 42 sigma^2
- * (csrc/quad_conv.hpp, conv_T_lognormal_poly: the same rule, <= 2e-13 of the density's peak against mpmath). */
-#define CO_LN_CUT 42.0
+ * [0, T], T = min(max(m, 0) + 12 sigma, 2 sqrt(d^2 + CUT sigma^2)), d = m - ln 2; zero where min(d^2, 2 d - 1) > CUT sigma^2
+ * (csrc/quad_conv.hpp, conv_T_lognormal_poly: the same rule, <= 4e-13 of the density's peak against mpmath except around
+ * sigma = 1/2, where it reaches 3e-10). */
+#define CO_LN_CUT 32.0   /* (round 6, late: 42 before -- e^-32 = 1.3e-14 of the peak, still below the trapezoidal rule's own error) */
+/* The end of the inner range (round 6): E(t) = [(d - qd(t))^2 + t^2 / 4] / sigma^2, qd = q - ln 2 = ln cosh(t / 2), d = m - ln 2.
+ * E(0) = d^2 / sigma^2 bounds the minimum from above.  ln cosh x >= sqrt(1 + x^2) - 1 for every x (equal at 0; the derivative of
+ * the difference is tanh x - x / sqrt(1 + x^2) >= 0, which is sinh^2 x >= x^2), so with w = sqrt(1 + t^2 / 4): wherever
+ * w - 1 >= d, sigma^2 E >= (w - 1 - d)^2 + w^2 - 1, and that exceeds d^2 + CUT sigma^2 for every
+ * w > max(1 + max(d, 0), [(1 + d) + sqrt((d - 1)^2 + 2 CUT sigma^2)] / 2) -- there the integrand is below e^-CUT of its maximum.
+ * At d = 0, sigma = ln 2: T = 6.3 against 2 sqrt(d^2 + CUT sigma^2) = 7.8 (the bound that ignores the first square; the true
+ * end is 4.9), for d < 0 about half of it; sigma << 1: the same to a few per cent. */
+static double co_ln_inner_top(double m, double d, double sg) {
+    const double wr = 0.5 * ((1.0 + d) + sqrt((d - 1.0) * (d - 1.0) + 2.0 * CO_LN_CUT * (sg * sg)));
+    const double w = fmax(wr, 1.0 + fmax(d, 0.0));
+    const double T = fmin(fmax(m, 0.0) + 12.0 * sg, 2.0 * sqrt(d * d + CO_LN_CUT * (sg * sg)));
+    return fmin(T, 2.0 * sqrt(w * w - 1.0));
+}
 static void co_TL_node_poly(double ls, double *vals, void *v) {
     const co_TL_ctx *c = (const co_TL_ctx *)v;
     const double mu = c->pdists[c->j].theta, sg = c->pdists[c->j].k, c1 = 1.0 / (sg * sg), h = fmin(sg, 0.5);
@@ -991,7 +1005,7 @@ static void co_TL_node_poly(double ls, double *vals, void *v) {
     const double lb = (d <= 1.0 ? d * d : 2.0 * d - 1.0) * c1;
     double sum = 0.0;
     if (lb <= CO_LN_CUT) {
-        const double Tm = fmin(fmax(m, 0.0) + 12.0 * sg, 2.0 * sqrt(d * d + CO_LN_CUT * sg * sg));
+        const double Tm = co_ln_inner_top(m, d, sg);
         const int npt = (int)ceil(Tm / h);
         sum = 0.5 * exp(-(d * d) * c1);
         for (int i = 1; i <= npt; ++i) {
@@ -1015,15 +1029,15 @@ static void co_TL_node(double ls, double *vals, void *v) {
     const double s = exp(ls);
     /* Round 6: the Gaussian factor of the inner integrand is the polynomial kernels' (co_TL_node_poly) whatever the kernel
      * function -- exp(-[(m - q(t))^2 + t^2 / 4] / sigma^2) -- so the same two bounds hold: nothing where
-     * min(d^2, 2 d - 1) > 42 sigma^2 (d = m - ln 2: the density of the sum is below e^-42 of its peak), and nothing beyond
-     * T = 2 sqrt(d^2 + 42 sigma^2).  Without them a shape clamped to sigma = eps ran the full 256 panels at every node -- and the
+     * min(d^2, 2 d - 1) > CUT sigma^2 (d = m - ln 2: the density of the sum is below e^-CUT of its peak), and nothing beyond
+     * T = 2 sqrt(d^2 + CUT sigma^2).  Without them a shape clamped to sigma = eps ran the full 256 panels at every node -- and the
      * 63 other parcels of its wave waited: 2e5 parcel-RHS/s where the polynomial kernels make 3.5e7. */
     const double md = ls - mu, dd = md - 0.6931471805599453;
     if ((dd <= 1.0 ? dd * dd : 2.0 * dd - 1.0) > CO_LN_CUT * (sg * sg)) {
         vals[0] = vals[1] = vals[2] = 0.0;
         return;
     }
-    const double Tm = fmin(fmax(md, 0.0) + 12.0 * sg, 2.0 * sqrt(dd * dd + CO_LN_CUT * (sg * sg)));
+    const double Tm = co_ln_inner_top(md, dd, sg);
     /* the Long kernel jumps where the larger particle x = s / (1 + e^-t) crosses x_t: at t_b = ln(x_t / (s - x_t)) for
      * x_t < s < 2 x_t (below, both stay under x_t; above, x >= s / 2 >= x_t) -- the inner panels are split there */
     double tb = 0.0;
