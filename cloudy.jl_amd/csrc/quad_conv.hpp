@@ -724,6 +724,34 @@ __device__ __forceinline__ double conv_long_G_mid_tab(const QArgs &Q, double k, 
     return fma(ca, s, fma(fma(cb, s2, -(ca * s)), P0, -2.0 * cb * s2 * P1));
 }
 
+// exp_fin (device_math.hpp: the same reduction, the same polynomial, the same bits) with its constants HELD in registers: the
+// trapezoidal loop below is one exponential and five other operations per point, and the compiler rebuilt the ten coefficients
+// with two v_mov_b32 each in every trip (16 of the 48 VALU instructions per point; round 6, tools/isa_loops.py) -- constants
+// are "free to rematerialise" in its books, and a v_fmac overwrites its addend.  An empty asm makes each an opaque register
+// value defined once, before the walk; v_fma_f64 then reads it in place.
+struct ExpKept {
+    double l2e, nh, nl, c[11];
+    __device__ __forceinline__ ExpKept() {
+        l2e = 1.4426950408889634, nh = -0.69314718055989033, nl = -5.497923018708371e-14;
+        c[0] = 0x1.adeb8db5d7212p-26, c[1] = 0x1.28afdbfa89bf0p-22, c[2] = 0x1.71dedfc117959p-19, c[3] = 0x1.a019970598987p-16;
+        c[4] = 0x1.a01a014a32d85p-13, c[5] = 0x1.6c16c18581530p-10, c[6] = 0x1.1111111121b01p-7, c[7] = 0x1.55555555500b2p-5;
+        c[8] = 0x1.5555555555513p-3, c[9] = 0x1.000000000000bp-1, c[10] = 1.0;
+        asm volatile("" : "+v"(l2e), "+v"(nh), "+v"(nl));
+#pragma unroll
+        for (int i = 0; i < 10; ++i) asm volatile("" : "+v"(c[i]));
+    }
+    __device__ __forceinline__ double operator()(double x) const {
+        const double n = __builtin_rint(x * l2e);
+        double r = fma(n, nh, x);
+        r = fma(n, nl, r);
+        double p = c[0];
+#pragma unroll
+        for (int i = 1; i < 10; ++i) p = fma(p, r, c[i]);
+        p = fma(p, r, 1.0);
+        p = fma(p, r, 1.0);
+        return ldexp(p, (int)n);
+    }
+};
 // T_m of a LOGNORMAL mode j: the sum of two Lognormal variates has no closed law, so two variables remain,
 //   s = x + y,  t = ln(x / y):   f(x) f(y) dx dy = n^2 g(ln x) g(ln y) d(ln s) dt   (g: the normal density of ln x),
 //   T_m = 1/2 n^2 int d(ln s) s^m (1 - w(s)) G2(ln s),   G2 = 2 int_0^inf dt K(x, y) g(ln x) g(ln y),
@@ -788,6 +816,7 @@ __device__ __forceinline__ void conv_T_lognormal(const QArgs &Q, const double *_
             return;
         }
         const double Tm = conv_ln_inner_top(md, dd, sg);
+        const ExpKept ek;   // (its 13 constants live for the point loops of this node only)
         // the Long kernel jumps where the larger particle x = s / (1 + e^-t) crosses x_t: at t_b = ln(x_t / (s - x_t)) for
         // x_t < s < 2 x_t (below, both stay under x_t; above, x >= s / 2 >= x_t) -- the inner panels are split there
         double tb = 0.0;
@@ -813,23 +842,28 @@ __device__ __forceinline__ void conv_T_lognormal(const QArgs &Q, const double *_
 #pragma unroll 1
             for (int g2 = 0; g2 < nq; ++g2) {
                 const double t = fma(0.5 * h2, tab[g2], tc);
-                const double spm = log1p(exp_fin(-t));  // ln(1 + e^-t); ln(1 + e^t) = t + ln(1 + e^-t)
-                const double lx = ls - spm, ly = ls - t - spm, dx = lx - mu, dy = ly - mu;
+                // Round 6 (late): ~300 -> ~130 instructions per point.  ln(1 + e^-t) through log_pos(1 + v) -- its ABSOLUTE error
+                // (1e-16) is what ln x and ln y carry, the library log1p's relative accuracy (120 instructions) bought nothing;
+                // x = s / (1 + v), y = x v instead of two exponentials (Long); the kernel's power of x y joins the Gaussian's
+                // exponent (hydrodynamic: one exponential instead of two), 1 / e^(t/3) by a Newton reciprocal instead of a division.
+                const double v1 = ek(-t), opv = 1.0 + v1, spm = log_pos(opv);   // ln(1 + e^-t); ln(1 + e^t) = t + ln(1 + e^-t)
+                const double lx = ls - spm, ly = lx - t, dx = lx - mu, dy = ly - mu;
+                const double ge = -fma(dx, dx, dy * dy) * c2;
                 double Kv;
                 if (KIND == KF_CONSTANT) {
-                    Kv = Q.kf[0];
+                    Kv = Q.kf[0] * ek(ge);
                 } else if (KIND == KF_LINEAR) {
-                    Kv = Q.kf[0] * s;
+                    Kv = (Q.kf[0] * s) * ek(ge);
                 } else if (KIND == KF_HYDRODYNAMIC) {
                     // K = C (xy)^(2/3) (e^(2t/3) + 2 e^(t/3) - 2 e^(-t/3) - e^(-2t/3)),  x / y = e^t
-                    const double e1 = exp_fin(t * (1.0 / 3.0)), r1 = 1.0 / e1;
-                    Kv = (Q.kf[0] * 0.46526286817455001) * exp_fin((2.0 / 3.0) * (lx + ly)) *
+                    const double e1 = ek(t * (1.0 / 3.0)), r1 = recip_fast(e1);
+                    Kv = (Q.kf[0] * 0.46526286817455001) * ek(fma(2.0 / 3.0, lx + ly, ge)) *
                          (fma(e1, e1, 2.0 * e1) - fma(r1, r1, 2.0 * r1));
                 } else {
-                    const double x = exp_fin(lx), y = exp_fin(ly);
-                    Kv = (x < Q.kf[0] && y < Q.kf[0]) ? Q.kf[1] * fma(x, x, y * y) : Q.kf[2] * (x + y);
+                    const double x = s * recip_fast(opv), y = x * v1;
+                    Kv = ((x < Q.kf[0] && y < Q.kf[0]) ? Q.kf[1] * fma(x, x, y * y) : Q.kf[2] * (x + y)) * ek(ge);
                 }
-                G2 = fma((0.5 * h2 * tab[nq + g2]) * Kv, exp_fin(-fma(dx, dx, dy * dy) * c2), G2);
+                G2 = fma(0.5 * h2 * tab[nq + g2], Kv, G2);
             }
         }
         const double v = conv_one_minus_w<N>(lg, j, s, ls) * (2.0 * nrm * G2);
@@ -866,34 +900,6 @@ __device__ __forceinline__ void conv_T_lognormal(const QArgs &Q, const double *_
 // computed.  Per inner point: one LDS read, one exponential, four FMAs.  The outer rule is the adaptive walk over ln s of
 // conv_T_lognormal (same range, marks and tolerance).
 constexpr int kLnQTab = 24;
-// exp_fin (device_math.hpp: the same reduction, the same polynomial, the same bits) with its constants HELD in registers: the
-// trapezoidal loop below is one exponential and five other operations per point, and the compiler rebuilt the ten coefficients
-// with two v_mov_b32 each in every trip (16 of the 48 VALU instructions per point; round 6, tools/isa_loops.py) -- constants
-// are "free to rematerialise" in its books, and a v_fmac overwrites its addend.  An empty asm makes each an opaque register
-// value defined once, before the walk; v_fma_f64 then reads it in place.
-struct ExpKept {
-    double l2e, nh, nl, c[11];
-    __device__ __forceinline__ ExpKept() {
-        l2e = 1.4426950408889634, nh = -0.69314718055989033, nl = -5.497923018708371e-14;
-        c[0] = 0x1.adeb8db5d7212p-26, c[1] = 0x1.28afdbfa89bf0p-22, c[2] = 0x1.71dedfc117959p-19, c[3] = 0x1.a019970598987p-16;
-        c[4] = 0x1.a01a014a32d85p-13, c[5] = 0x1.6c16c18581530p-10, c[6] = 0x1.1111111121b01p-7, c[7] = 0x1.55555555500b2p-5;
-        c[8] = 0x1.5555555555513p-3, c[9] = 0x1.000000000000bp-1, c[10] = 1.0;
-        asm volatile("" : "+v"(l2e), "+v"(nh), "+v"(nl));
-#pragma unroll
-        for (int i = 0; i < 10; ++i) asm volatile("" : "+v"(c[i]));
-    }
-    __device__ __forceinline__ double operator()(double x) const {
-        const double n = __builtin_rint(x * l2e);
-        double r = fma(n, nh, x);
-        r = fma(n, nl, r);
-        double p = c[0];
-#pragma unroll
-        for (int i = 1; i < 10; ++i) p = fma(p, r, c[i]);
-        p = fma(p, r, 1.0);
-        p = fma(p, r, 1.0);
-        return ldexp(p, (int)n);
-    }
-};
 template <int N, int KIND>
 __device__ __forceinline__ void conv_T_lognormal_poly(const QArgs &Q, double n, double mu, double sg, const double (&cm)[N],
                                                       const double (&wm)[N], const ConvLogDensity (&lg)[N], int j,
