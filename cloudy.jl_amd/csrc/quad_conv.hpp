@@ -950,8 +950,10 @@ __device__ __forceinline__ void conv_T_lognormal_poly(const QArgs &Q, double n, 
             double fi = 0.0, qn = sh_q[0][lane];
 #pragma unroll 1
             for (int i = 0; i < ntab; ++i) {
-                const double dq = d - qn;
+                double dq = d - qn;
                 qn = sh_q[i + 1][lane];   // (the next trip's value, asked for before this trip's arithmetic; row kLnQTab is padding)
+                asm volatile("" : "+v"(dq) : : "memory");   // (the read is issued HERE, before the arithmetic on dq: without the fence
+                                                            // the compiler moves it to the end of the trip, four instructions before its use)
                 fi += 1.0;
                 sum += ek(-fma(dq, dq, hq * (fi * fi)) * c1);
             }
