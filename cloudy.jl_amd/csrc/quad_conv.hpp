@@ -1016,6 +1016,35 @@ __device__ __forceinline__ double exp_node(double x) {
     p = fma(p, r, 1.0);
     return ldexp(p, (int)n);
 }
+// 1 / x for the walk (tools/rcp_probe on gfx950: v_rcp_f64 is good to 4.6e-8; one Newton step leaves 2.2e-15, two -- recip_fast --
+// 1.1e-16, and so does the cubic single pass r (1 + e + e^2) in three instructions instead of four).  A node's 1 / (1 + sum rho)
+// is a factor of its value: one step; the reciprocal of a pair's e^d goes on into an exponent (u = e^c / e^d): the cubic pass.
+__device__ __forceinline__ double recip_node(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+__device__ __forceinline__ double recip_cubic(double x) {
+    const double r = __builtin_amdgcn_rcp(x), e = fma(-x, r, 1.0);
+    return fma(fma(e, e, e), r, r);
+}
+// exp_fin with one reduction step, for the half widths of panels (0 <= x <= a few: n <= 3 loses 7e-17)
+__device__ __forceinline__ double exp_small(double x) {
+    const double n = __builtin_rint(x * 1.4426950408889634);
+    const double r = fma(n, -0.6931471805599453, x);
+    double p = 0x1.adeb8db5d7212p-26;
+    p = fma(p, r, 0x1.28afdbfa89bf0p-22);
+    p = fma(p, r, 0x1.71dedfc117959p-19);
+    p = fma(p, r, 0x1.a019970598987p-16);
+    p = fma(p, r, 0x1.a01a014a32d85p-13);
+    p = fma(p, r, 0x1.6c16c18581530p-10);
+    p = fma(p, r, 0x1.1111111121b01p-7);
+    p = fma(p, r, 0x1.55555555500b2p-5);
+    p = fma(p, r, 0x1.5555555555513p-3);
+    p = fma(p, r, 0x1.000000000000bp-1);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
 template <int V>
 struct ConvInt {
     static constexpr int value = V;
@@ -1399,7 +1428,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
                 den += rho;
                 up = fma(upw[sl], rho, up);
             }
-            double hh = wt * (up * recip_fast(den));
+            double hh = wt * (up * recip_node(den));
             if (PHASE == 1)   // outside [x_t, 2 x_t]: both particles below x_t, or the larger one above
                 hh *= s <= Q.kf[0] ? (Q.kf[1] * gl) * (s * s) : Q.kf[2] * s;
             if (PHASE == 2)   // inside: this rule's table (rows j * kLongNT + r of the lane's LDS column); ln(x_t / s) = ex1 - t
@@ -1441,7 +1470,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
 #pragma unroll
             for (int g = 0; g < 7; ++g) {
                 const double d = hw * kGKX[14 - g];   // > 0
-                const double e = exp_fin(d), re = recip_fast(e);
+                const double e = exp_small(d), re = recip_cubic(e);
                 eval_node(c - d, uc * re, kGKWK[g], kGKWG[g], (g & 1) != 0);
                 eval_node(c + d, uc * e, kGKWK[14 - g], kGKWG[14 - g], (g & 1) != 0);
             }
