@@ -900,6 +900,29 @@ __device__ __forceinline__ void conv_T_lognormal(const QArgs &Q, const double *_
 // computed.  Per inner point: one LDS read, one exponential, four FMAs.  The outer rule is the adaptive walk over ln s of
 // conv_T_lognormal (same range, marks and tolerance).
 constexpr int kLnQTab = 24;
+// exp_node (below: degree 9, one reduction step, 4e-14) with its constants held the same way: the trapezoidal rule's terms are
+// summed as they come, so that is their relative error and the sum's (round 6, late: 28 -> 25 VALU instructions per point).
+struct ExpKept9 {
+    double l2e, nl2, c[8];
+    __device__ __forceinline__ ExpKept9() {
+        l2e = 1.4426950408889634, nl2 = -0.6931471805599453;
+        c[0] = 0x1.710182df3d7acp-19, c[1] = 0x1.a16e32bc8180fp-16, c[2] = 0x1.a01b7383bafc4p-13, c[3] = 0x1.6c163be91fb17p-10;
+        c[4] = 0x1.1111108e2cc07p-7, c[5] = 0x1.5555557deef18p-5, c[6] = 0x1.5555555589f00p-3, c[7] = 0x1.fffffffff13f6p-2;
+        asm volatile("" : "+v"(l2e), "+v"(nl2));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(c[i]));
+    }
+    __device__ __forceinline__ double operator()(double x) const {
+        const double n = __builtin_rint(x * l2e);
+        const double r = fma(n, nl2, x);
+        double p = c[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) p = fma(p, r, c[i]);
+        p = fma(p, r, 1.0);
+        p = fma(p, r, 1.0);
+        return ldexp(p, (int)n);
+    }
+};
 template <int N, int KIND>
 __device__ __forceinline__ void conv_T_lognormal_poly(const QArgs &Q, double n, double mu, double sg, const double (&cm)[N],
                                                       const double (&wm)[N], const ConvLogDensity (&lg)[N], int j,
@@ -934,7 +957,7 @@ __device__ __forceinline__ void conv_T_lognormal_poly(const QArgs &Q, double n, 
             }
     }
     const double kc = Q.kf[0] * (0.3183098861837907 * c1);   // c / (pi sigma^2)
-    const ExpKept ek;
+    const ExpKept9 ek;
     const auto node = [&](double ls, double (&vals)[3]) {
         const double m = ls - mu, d = m - ln2;
         const double lb = (d <= 1.0 ? d * d : fma(2.0, d, -1.0)) * c1;   // a lower bound of the exponent over t
@@ -947,24 +970,30 @@ __device__ __forceinline__ void conv_T_lognormal_poly(const QArgs &Q, double n, 
             // the points served by the table, then (sigma > 1/2 only) the ones beyond it: two loops, so that the first carries
             // neither the second's e^(-t) nor its select (round 6: 48 -> 27 VALU instructions per point together with ek)
             const int ntab = npt < kLnQTab ? npt : kLnQTab;
-            double fi = 0.0, qn = sh_q[0][lane];
+            // the exponent of point i: -c1 [(d - qd_i)^2 + (h i / 2)^2]; its second term by differences (e2 = c1 hq i^2: two additions
+            // a point instead of an addition and two products), the first as (-c1 dq) dq
+            const double nc1 = -c1, g2 = 2.0 * (c1 * hq);
+            double e2 = 0.0, st = c1 * hq, qn = sh_q[0][lane];
 #pragma unroll 1
             for (int i = 0; i < ntab; ++i) {
                 double dq = d - qn;
                 qn = sh_q[i + 1][lane];   // (the next trip's value, asked for before this trip's arithmetic; row kLnQTab is padding)
                 asm volatile("" : "+v"(dq) : : "memory");   // (the read is issued HERE, before the arithmetic on dq: without the fence
                                                             // the compiler moves it to the end of the trip, four instructions before its use)
-                fi += 1.0;
-                sum += ek(-fma(dq, dq, hq * (fi * fi)) * c1);
+                e2 += st;
+                st += g2;
+                sum += ek(fma(nc1 * dq, dq, -e2));
             }
             if (npt > kLnQTab) {
-                double vv = exp_fin(-h * double(kLnQTab));   // e^(-t) at the end of the table
+                double vv = exp_fin(-h * double(kLnQTab)), fi = double(kLnQTab);   // e^(-t) at the end of the table
 #pragma unroll 1
                 for (int i = kLnQTab + 1; i <= npt; ++i) {
                     vv *= eh;
                     fi += 1.0;
                     const double dq = d - fma(0.5 * h, fi, log1p(vv) - ln2);
-                    sum += ek(-fma(dq, dq, hq * (fi * fi)) * c1);
+                    e2 += st;
+                    st += g2;
+                    sum += ek(fma(nc1 * dq, dq, -e2));
                 }
             }
         }
