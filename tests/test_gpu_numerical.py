@@ -420,6 +420,50 @@ def test_converged_mode_extreme_parcels(gpu_cloudy, oracle, kname):
     print(f"narrow Lognormal below a Gamma mode, {kname}: max |hip - oracle| / scale = {worst:.2e}")
 
 
+@pytest.mark.parametrize("kname", ["linear", "constant", "hydro", "long"])
+def test_converged_mode_four_modes_ahead_of_time_kernel_repeats_itself(gpu_cloudy, oracle, kname):
+    """Round 6: the ahead-of-time kernel of a FOUR-mode converged-mode plan (what runs when hiprtc is not available; 1 000+ spilled
+    registers) built with 512 registers and the accumulation registers as spill space returned, for the linear kernel, different
+    bits from run to run on identical input -- 1e-12 ... 1e-11 of scale on ~7 % of the parcels of a multi-scale batch
+    (tools/jit_aot_diff.py; found by tools/fuzz_parity.py --converged).  The kernels are built for two waves per SIMD now, as the
+    plan-time compiled ones; here: three calls and a fresh plan give the same bits, and they agree with the plan-time compiled
+    kernel to 1e-13 of scale and with the same-rule oracle."""
+    cloudy = gpu_cloudy
+    par, op, okf = converged_case(cloudy, oracle, [1, 1, 1, 1], kname, 6)
+    rng = np.random.Generator(np.random.Philox(key=4056))
+    n = 1200
+    rows = []
+    for i in range(4):   # size classes 2.5 decades apart, shapes 1 ... 8, numbers falling with size
+        k = rng.uniform(1.0, 8.0, n)
+        th = 10.0 ** (-11.0 + 2.5 * i + rng.uniform(-0.8, 0.8, n)) / k
+        nn = 10.0 ** (8.0 - 2.5 * i + rng.uniform(-1.0, 1.0, n))
+        rows += [nn, nn * k * th, nn * k * (k + 1.0) * th * th]
+    mom = np.ascontiguousarray(np.stack(rows))
+    want, scale = oracle.rhs_coal_numerical_converged_batch(op, okf, 6, mom, with_scale=True)
+    kf = par.kernel_func
+    jit = cloudy.NumericalPlan([1, 1, 1, 1], kf, NORMS, 6, specialize=1, quad_mode=1)
+    aot = cloudy.NumericalPlan([1, 1, 1, 1], kf, NORMS, 6, specialize=-1, quad_mode=1)
+    assert jit.specialized and not aot.specialized
+    L, m = cloudy.lib(), dev(cloudy, mom)
+
+    def run_plan(plan):
+        dm = cloudy.DeviceArray.zeros(*mom.shape)
+        cloudy._lib.check(L.cloudy_coal_rhs(plan.handle, n, n, m.ptr, dm.ptr, None))
+        return dm.to_numpy()
+
+    a = run_plan(jit)
+    b = [run_plan(aot) for _ in range(3)]
+    b.append(run_plan(cloudy.NumericalPlan([1, 1, 1, 1], kf, NORMS, 6, specialize=-1, quad_mode=1)))
+    for other in b[1:]:
+        assert np.array_equal(b[0], other, equal_nan=True), "the ahead-of-time kernel does not repeat itself"
+    assert np.array_equal(a, run_plan(jit), equal_nan=True)
+    ok = np.isfinite(want) & (scale > 0)
+    dj = float(np.max(np.abs(a - b[0])[ok] / scale[ok]))
+    assert dj <= 1e-13, dj
+    assert_same_rule(b[0], want, scale, np.zeros_like(scale), f"ahead of time, four modes, {kname}", tol=TOL_CONVERGED)
+    print(f"four modes, {kname}: |plan-time compiled - ahead of time| / scale = {dj:.1e}")
+
+
 def test_converged_mode_jit_aot_params_and_float_planes(gpu_cloudy, oracle):
     cloudy = gpu_cloudy
     L = cloudy.lib()

@@ -336,6 +336,8 @@ def check_converged_config(pkg, cfg, n, seed):
     # round 5: the second call of the plan ranks the parcels of a workgroup by the cost hints the first call left -- not a bit may change
     a2 = run(pkg, jit, mom, np.float64)
     assert np.array_equal(a, a2, equal_nan=True), "the cost hints of the first call changed the result of the second"
+    # round 6: so does the ahead-of-time kernel (its 512-register build of a four-mode linear plan did not, tools/jit_aot_diff.py)
+    assert aot is jit or np.array_equal(b, run(pkg, aot, mom, np.float64), equal_nan=True), "the ahead-of-time kernel does not repeat itself"
     want, scale = O.rhs_coal_numerical_converged_batch(op, okf, q, mom, with_scale=True)
     keep = np.ones(mom.shape[1], dtype=bool)
     if 3 in cfg["dist"]:
