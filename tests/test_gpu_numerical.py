@@ -457,6 +457,14 @@ def test_converged_mode_four_modes_ahead_of_time_kernel_repeats_itself(gpu_cloud
     for other in b[1:]:
         assert np.array_equal(b[0], other, equal_nan=True), "the ahead-of-time kernel does not repeat itself"
     assert np.array_equal(a, run_plan(jit), equal_nan=True)
+
+    def step_plan(plan):   # cloudy_ssprk33_steps of the plan: the fused integrator's ahead-of-time kernel (512 registers)
+        u, o = dev(cloudy, mom), cloudy.DeviceArray.zeros(*mom.shape)
+        cloudy._lib.check(L.cloudy_ssprk33_steps(plan.handle, n, n, u.ptr, o.ptr, 1e-3, 1, None))
+        return o.to_numpy()
+
+    s0 = step_plan(aot)
+    assert np.array_equal(s0, step_plan(aot), equal_nan=True) and np.array_equal(s0, step_plan(aot), equal_nan=True)
     ok = np.isfinite(want) & (scale > 0)
     dj = float(np.max(np.abs(a - b[0])[ok] / scale[ok]))
     assert dj <= 1e-13, dj
