@@ -678,6 +678,55 @@ __device__ static const double kLongDct[kLongNT][kLongNT] = {
     {0.08333333333333333333, -0.1539799220852144594, 0.1178511301977579207, -0.06378057206084829529, 3.585325260436553952e-42, 0.06378057206084829529, -0.1178511301977579207, 0.1539799220852144594, -0.1666666666666666667, 0.1539799220852144594, -0.1178511301977579207, 0.06378057206084829529},
     {0.08333333333333333333, -0.1652408102289684019, 0.1609876377148447145, -0.1539799220852144594, 0.1443375672974064411, -0.1322255567152058608, 0.1178511301977579207, -0.1014602381681201066, 0.08333333333333333333, -0.06378057206084829529, 0.04313650751708679372, -0.02175436537000859859}};
 
+// e^x for the walk's nodes: the weight and the density ratios of a node enter its value as FACTORS, so 4e-14 of relative error
+// each is far inside the walk's budget (acceptance at 1e-7 of scale, results <= 1e-9; exp_fin is good to an ulp, which nothing
+// downstream can use).  Degree 9 instead of 11 (Remez fit of 1 + r + r^2 p(r) on [-ln 2 / 2, ln 2 / 2]: 1.6e-14) and ONE reduction
+// step -- the product n ln 2 is exact inside the FMA, what is lost is n (ln 2 - its double) = 2.3e-17 n: 14 instructions instead
+// of 17, and three of every five instructions of the walk are these exponentials (round 6, late: 1 731 -> 1 596 per trip).
+__device__ __forceinline__ double exp_node(double x) {
+    const double n = __builtin_rint(x * 1.4426950408889634);
+    const double r = fma(n, -0.6931471805599453, x);
+    double p = 0x1.710182df3d7acp-19;
+    p = fma(p, r, 0x1.a16e32bc8180fp-16);
+    p = fma(p, r, 0x1.a01b7383bafc4p-13);
+    p = fma(p, r, 0x1.6c163be91fb17p-10);
+    p = fma(p, r, 0x1.1111108e2cc07p-7);
+    p = fma(p, r, 0x1.5555557deef18p-5);
+    p = fma(p, r, 0x1.5555555589f00p-3);
+    p = fma(p, r, 0x1.fffffffff13f6p-2);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+// 1 / x for the walk (tools/rcp_probe on gfx950: v_rcp_f64 is good to 4.6e-8; one Newton step leaves 2.2e-15, two -- recip_fast --
+// 1.1e-16, and so does the cubic single pass r (1 + e + e^2) in three instructions instead of four).  A node's 1 / (1 + sum rho)
+// is a factor of its value: one step; the reciprocal of a pair's e^d goes on into an exponent (u = e^c / e^d): the cubic pass.
+__device__ __forceinline__ double recip_node(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+__device__ __forceinline__ double recip_cubic(double x) {
+    const double r = __builtin_amdgcn_rcp(x), e = fma(-x, r, 1.0);
+    return fma(fma(e, e, e), r, r);
+}
+// exp_fin with one reduction step, for the half widths of panels (0 <= x <= a few: n <= 3 loses 7e-17)
+__device__ __forceinline__ double exp_small(double x) {
+    const double n = __builtin_rint(x * 1.4426950408889634);
+    const double r = fma(n, -0.6931471805599453, x);
+    double p = 0x1.adeb8db5d7212p-26;
+    p = fma(p, r, 0x1.28afdbfa89bf0p-22);
+    p = fma(p, r, 0x1.71dedfc117959p-19);
+    p = fma(p, r, 0x1.a019970598987p-16);
+    p = fma(p, r, 0x1.a01a014a32d85p-13);
+    p = fma(p, r, 0x1.6c16c18581530p-10);
+    p = fma(p, r, 0x1.1111111121b01p-7);
+    p = fma(p, r, 0x1.55555555500b2p-5);
+    p = fma(p, r, 0x1.5555555555513p-3);
+    p = fma(p, r, 0x1.000000000000bp-1);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
 // the Chebyshev coefficients of g for shape k, left in the lane's own LDS slots sh[row0 + r][lane] (conflict-free, no barrier:
 // a lane reads what it wrote)
 template <int NROW>
@@ -701,7 +750,7 @@ template <int NROW>
 __device__ __forceinline__ double conv_long_G_mid_tab(const QArgs &Q, double k, double c0, double rB, double s, double lx,
                                                       const double (&sh)[NROW][kConvBlock], int row0) {
     const double xt = Q.kf[0], cb = Q.kf[1], ca = Q.kf[2];
-    const double x = xt * recip_fast(s), y = 1.0 - x;   // y in (0, 1/2)
+    const double x = xt * recip_cubic(s), y = 1.0 - x;   // y in (0, 1/2)
     const double z2 = fma(8.0, y, -2.0);                // 2 z, z = 4 y - 1 in [-1, 1]
     double b1 = 0.0, b2 = 0.0;                           // Clenshaw: b_r = c_r + 2 z b_{r+1} - b_{r+2}
     // (the lane index through an opaque copy: the twelve coefficients are READ here, per node -- left alone the compiler hoists
@@ -715,8 +764,8 @@ __device__ __forceinline__ double conv_long_G_mid_tab(const QArgs &Q, double k, 
         b1 = b0;
     }
     const double g = fma(0.5 * z2, b1, sh[row0][tl]) - b2;
-    const double yk = exp_fin(k * log_pos(y)) * c0;      // y^k / (k B(k, k))
-    const double Dk = yk * exp_fin(k * lx);              // x^k y^k / (k B(k, k)) = D(k, k) / k
+    const double yk = exp_node(k * log_pos(y)) * c0;     // y^k / (k B(k, k))   (factors of I_y and D: exp_node's 4e-14 is theirs)
+    const double Dk = yk * exp_node(k * lx);             // x^k y^k / (k B(k, k)) = D(k, k) / k
     const double Ikk = fma(-yk, g, 1.0);                 // I_x(k, k) = 1 - I_y(k, k)
     const double Ik1k1 = fma(Dk, fma(2.0, x, -1.0), Ikk);  // I_x(k+1, k+1) = I_x(k, k) - D/k + 2 x D/k
     const double P0 = fma(2.0, Ikk, -1.0), P1 = rB * fma(2.0, Ik1k1, -1.0);
@@ -1025,55 +1074,6 @@ __device__ __forceinline__ void conv_T_lognormal_poly(const QArgs &Q, double n, 
 // -- inside the loop: 328 registers and the set-up executed, masked, in almost every trip: slower.)  The arithmetic of
 // every rule is that of conv_adaptive<3, 3, false> with the node function below: results are bit-identical to running
 // the rules one after the other.
-// e^x for the walk's nodes: the weight and the density ratios of a node enter its value as FACTORS, so 4e-14 of relative error
-// each is far inside the walk's budget (acceptance at 1e-7 of scale, results <= 1e-9; exp_fin is good to an ulp, which nothing
-// downstream can use).  Degree 9 instead of 11 (Remez fit of 1 + r + r^2 p(r) on [-ln 2 / 2, ln 2 / 2]: 1.6e-14) and ONE reduction
-// step -- the product n ln 2 is exact inside the FMA, what is lost is n (ln 2 - its double) = 2.3e-17 n: 14 instructions instead
-// of 17, and three of every five instructions of the walk are these exponentials (round 6, late: 1 731 -> 1 596 per trip).
-__device__ __forceinline__ double exp_node(double x) {
-    const double n = __builtin_rint(x * 1.4426950408889634);
-    const double r = fma(n, -0.6931471805599453, x);
-    double p = 0x1.710182df3d7acp-19;
-    p = fma(p, r, 0x1.a16e32bc8180fp-16);
-    p = fma(p, r, 0x1.a01b7383bafc4p-13);
-    p = fma(p, r, 0x1.6c163be91fb17p-10);
-    p = fma(p, r, 0x1.1111108e2cc07p-7);
-    p = fma(p, r, 0x1.5555557deef18p-5);
-    p = fma(p, r, 0x1.5555555589f00p-3);
-    p = fma(p, r, 0x1.fffffffff13f6p-2);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return ldexp(p, (int)n);
-}
-// 1 / x for the walk (tools/rcp_probe on gfx950: v_rcp_f64 is good to 4.6e-8; one Newton step leaves 2.2e-15, two -- recip_fast --
-// 1.1e-16, and so does the cubic single pass r (1 + e + e^2) in three instructions instead of four).  A node's 1 / (1 + sum rho)
-// is a factor of its value: one step; the reciprocal of a pair's e^d goes on into an exponent (u = e^c / e^d): the cubic pass.
-__device__ __forceinline__ double recip_node(double x) {
-    const double r = __builtin_amdgcn_rcp(x);
-    return fma(fma(-x, r, 1.0), r, r);
-}
-__device__ __forceinline__ double recip_cubic(double x) {
-    const double r = __builtin_amdgcn_rcp(x), e = fma(-x, r, 1.0);
-    return fma(fma(e, e, e), r, r);
-}
-// exp_fin with one reduction step, for the half widths of panels (0 <= x <= a few: n <= 3 loses 7e-17)
-__device__ __forceinline__ double exp_small(double x) {
-    const double n = __builtin_rint(x * 1.4426950408889634);
-    const double r = fma(n, -0.6931471805599453, x);
-    double p = 0x1.adeb8db5d7212p-26;
-    p = fma(p, r, 0x1.28afdbfa89bf0p-22);
-    p = fma(p, r, 0x1.71dedfc117959p-19);
-    p = fma(p, r, 0x1.a019970598987p-16);
-    p = fma(p, r, 0x1.a01a014a32d85p-13);
-    p = fma(p, r, 0x1.6c16c18581530p-10);
-    p = fma(p, r, 0x1.1111111121b01p-7);
-    p = fma(p, r, 0x1.55555555500b2p-5);
-    p = fma(p, r, 0x1.5555555555513p-3);
-    p = fma(p, r, 0x1.000000000000bp-1);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return ldexp(p, (int)n);
-}
 template <int V>
 struct ConvInt {
     static constexpr int value = V;
