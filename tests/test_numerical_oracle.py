@@ -297,6 +297,29 @@ def test_converged_mode_narrow_lognormal_modes(oracle):
     print("narrow Lognormal modes, default inner rule against panels of sigma / 2:", {k: f"{v:.1e}" for k, v in worst.items()})
 
 
+def test_lognormal_inner_range_bound_holds():
+    """Round 6: the end of the inner integral of a Lognormal mode's T_m (co_ln_inner_top in oracle/cloudy_oracle_quad.c,
+    conv_ln_inner_top in csrc/quad_conv.hpp): beyond T the integrand exp(-E(t)), sigma^2 E = (d - ln cosh(t/2))^2 + t^2/4, is
+    below e^-32 of its maximum.  Checked by brute force on random (d, sigma): min over a fine grid of [0, T + 40 sigma + 10] against
+    every grid point beyond T."""
+    rng = np.random.Generator(np.random.Philox(key=632))
+    C_ = 32.0
+    for _ in range(400):
+        sg = float(10.0 ** rng.uniform(-2.3, 0.5))
+        d = float(rng.uniform(-7.0, 7.0) * sg + (rng.uniform(0.0, 12.0) if rng.uniform() < 0.3 else 0.0))
+        if (d * d if d <= 1.0 else 2.0 * d - 1.0) > C_ * sg * sg:
+            continue   # (the node is zero there)
+        m = d + np.log(2.0)
+        wr = 0.5 * ((1.0 + d) + np.sqrt((d - 1.0) ** 2 + 2.0 * C_ * sg * sg))
+        w = max(wr, 1.0 + max(d, 0.0))
+        T = min(max(m, 0.0) + 12.0 * sg, 2.0 * np.sqrt(d * d + C_ * sg * sg), 2.0 * np.sqrt(w * w - 1.0))
+        t = np.linspace(0.0, T + 40.0 * sg + 10.0, 400001)
+        E = ((d - (np.logaddexp(0.5 * t, -0.5 * t) - np.log(2.0))) ** 2 + 0.25 * t * t) / (sg * sg)
+        beyond = t > T
+        # (m + 12 sigma is round 5's bound, kept: it was derived for the cut 42 and is never the binding one at 32 -- asserted with the others)
+        assert E[beyond].min() >= E.min() + C_ - 1e-9, (sg, d, T, float(E[beyond].min() - E.min()))
+
+
 def test_converged_mode_building_blocks(oracle):
     """incomplete beta against scipy; the hydrodynamic and Long pair integrals against direct 2-D quadrature of
     K(x, y) x^p y^q f_j f_k; polynomial kernels reproduce the analytic closure; mass conservation"""
