@@ -683,9 +683,31 @@ __device__ static const double kLongDct[kLongNT][kLongNT] = {
 // downstream can use).  Degree 9 instead of 11 (Remez fit of 1 + r + r^2 p(r) on [-ln 2 / 2, ln 2 / 2]: 1.6e-14) and ONE reduction
 // step -- the product n ln 2 is exact inside the FMA, what is lost is n (ln 2 - its double) = 2.3e-17 n: 14 instructions instead
 // of 17, and three of every five instructions of the walk are these exponentials (round 6, late: 1 731 -> 1 596 per trip).
+// The integer n is read from the LOW WORD of x / ln 2 + 1.5 2^52 instead of v_rndne + v_cvt_i32 (round 6, last day:
+// 13 instructions; |n| < 2^31 is the caller's business -- exp_arg_clamp).  An LDS table of 2^(j/64) per lane of a
+// wave (32 KB, conflict-free) with a degree-4 polynomial was measured too: 9 fp64 + 5 integer instructions + a ds_read_b64 per
+// exponential, hydrodynamic 21.9 against 20.6 ms, constant 8.2 against 7.8 -- the reads' latency is not covered at two waves per SIMD.
+#ifndef CLOUDY_EXP_ESTRIN
+#define CLOUDY_EXP_ESTRIN 0
+#endif
 __device__ __forceinline__ double exp_node(double x) {
-    const double n = __builtin_rint(x * 1.4426950408889634);
+    constexpr double kMagic = 0x1.8p52;
+    const double t = fma(x, 1.4426950408889634, kMagic);
+    const double n = t - kMagic;
     const double r = fma(n, -0.6931471805599453, x);
+#if CLOUDY_EXP_ESTRIN
+    // 1 + r + r^2 (c2 + c3 r + r^2 (c4 + c5 r + r^2 (c6 + c7 r + r^2 (c8 + c9 r)))): chains of 5 instead of 10
+    const double r2 = r * r;
+    const double q4 = fma(0x1.710182df3d7acp-19, r, 0x1.a16e32bc8180fp-16);
+    const double q3 = fma(0x1.a01b7383bafc4p-13, r, 0x1.6c163be91fb17p-10);
+    const double q2 = fma(0x1.1111108e2cc07p-7, r, 0x1.5555557deef18p-5);
+    const double q1 = fma(0x1.5555555589f00p-3, r, 0x1.fffffffff13f6p-2);
+    const double q0 = r + 1.0;
+    double p = fma(q4, r2, q3);
+    p = fma(p, r2, q2);
+    p = fma(p, r2, q1);
+    p = fma(p, r2, q0);
+#else
     double p = 0x1.710182df3d7acp-19;
     p = fma(p, r, 0x1.a16e32bc8180fp-16);
     p = fma(p, r, 0x1.a01b7383bafc4p-13);
@@ -696,7 +718,19 @@ __device__ __forceinline__ double exp_node(double x) {
     p = fma(p, r, 0x1.fffffffff13f6p-2);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-    return ldexp(p, (int)n);
+#endif
+    return ldexp(p, __double2loint(t));
+}
+// x limited to [-1e9, 700] by two INTEGER operations on its high word (2 cycles each on a SIMD with two waves; a v_min_f64 is 4 and
+// limits one side): doubles above zero order like their high words taken as signed numbers, doubles below zero like unsigned
+// ones.  As fmin(x, 700) for everything above zero: +Inf and the NaN the hardware makes (0x7FF8...) give 700 (<= 700.0002: the
+// low word stays); below zero -Inf and a NaN with the sign bit set give -1e9 (e^x = 0, as the CPU restatement's libm has it for
+// -Inf; exp_node answered NaN).
+__device__ __forceinline__ double exp_arg_clamp(double x) {
+    int hi = __double2hiint(x);
+    hi = hi < 0x4085E000 ? hi : 0x4085E000;                               // 700 = 0x4085E00000000000
+    const unsigned hu = (unsigned)hi < 0xC1CDCD65u ? (unsigned)hi : 0xC1CDCD65u;   // -1e9 = 0xC1CDCD6500000000
+    return __hiloint2double((int)hu, __double2loint(x));
 }
 // 1 / x for the walk (tools/rcp_probe on gfx950: v_rcp_f64 is good to 4.6e-8; one Newton step leaves 2.2e-15, two -- recip_fast --
 // 1.1e-16, and so does the cubic single pass r (1 + e + e^2) in three instructions instead of four).  A node's 1 / (1 + sum rho)
@@ -711,7 +745,9 @@ __device__ __forceinline__ double recip_cubic(double x) {
 }
 // exp_fin with one reduction step, for the half widths of panels (0 <= x <= a few: n <= 3 loses 7e-17)
 __device__ __forceinline__ double exp_small(double x) {
-    const double n = __builtin_rint(x * 1.4426950408889634);
+    constexpr double kMagic = 0x1.8p52;   // (n from the low word, as exp_node)
+    const double t = fma(x, 1.4426950408889634, kMagic);
+    const double n = t - kMagic;
     const double r = fma(n, -0.6931471805599453, x);
     double p = 0x1.adeb8db5d7212p-26;
     p = fma(p, r, 0x1.28afdbfa89bf0p-22);
@@ -725,7 +761,7 @@ __device__ __forceinline__ double exp_small(double x) {
     p = fma(p, r, 0x1.000000000000bp-1);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-    return ldexp(p, (int)n);
+    return ldexp(p, __double2loint(t));
 }
 // the Chebyshev coefficients of g for shape k, left in the lane's own LDS slots sh[row0 + r][lane] (conflict-free, no barrier:
 // a lane reads what it wrote)
@@ -1234,6 +1270,12 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
     // without the cancellation of that difference); Lognormal modes keep the general form.  (Round 4: -7 of ~118 instructions
     // per node for an all-Gamma plan, where `own` and `oth` then drop out of the loop.)
     double da[NM], nb[NM], nc[NM];
+#ifndef CLOUDY_WALK_TU
+#define CLOUDY_WALK_TU 1
+#endif
+    // (CLOUDY_WALK_TU: the same line in the rule's own variables, ln rho = da t + (nb th_j) u + (nc + da ln th_j) -- a node then
+    // needs s = u th_j for its moments only and ln s not at all)
+    double nbu[NM], ncu[NM];
     double upw[NM];   // 1 for the slots of the modes above the rule's own (they make up 1 - w), 0 below: one FMA instead of a select
     bool anyln = false;
     ConvMarks<NM> mk;
@@ -1252,6 +1294,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
     for (int sl = 0; sl < NM; ++sl) {
         ltlo[sl] = 0.0;
         da[sl] = nb[sl] = nc[sl] = 0.0;
+        nbu[sl] = ncu[sl] = 0.0;
         upw[sl] = 0.0;
         mk.c[sl] = 0.0;
         mk.w[sl] = 1.0;
@@ -1345,6 +1388,13 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
             j = jn;
             jm = kSingle ? jsingle : jn;
             mk.shift = lnthj;
+#if CLOUDY_WALK_TU
+#pragma unroll
+            for (int sl = 0; sl < NM; ++sl) {
+                nbu[sl] = nb[sl] * thj;
+                ncu[sl] = fma(da[sl], lnthj, nc[sl]);
+            }
+#endif
             h0 = (thi - tlo) * (1.0 / double(kConvNInit));
             gap = 1e-7 * (thi - tlo);
 #pragma unroll
@@ -1387,18 +1437,22 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
     // with theta >= theta_j is convex in t, so its supremum over [t_lo, cur] is at an end point -- any other mode above
     // j: sup (1 - w) = 1; s^m G <= s(cur)^m (c_a s + c_b s^2) for Long).  Two exponentials per initial panel.
     const auto next_panel = [&](bool need) -> bool {
-        const double ub = exp_fin(cur), sb = ub * thj, lsb = cur + lnthj;
+        const double ub = exp_node(cur), sb = ub * thj, lsb = cur + lnthj;   // (a bound's factors: exp_node's 4e-14 is plenty)
         const double lw = cur > tmode ? lwmode : fma(A, cur, -ub) - lgA;
         const double ow = anyln ? own(sb, lsb) : 0.0;
         double lmax = -INFINITY;
 #pragma unroll
         for (int sl = 0; sl < NM; ++sl) {
+#if CLOUDY_WALK_TU
+            const double lr = oth[sl].lognormal ? oth[sl](sb, lsb) - ow : fma(da[sl], cur, fma(nbu[sl], ub, ncu[sl]));
+#else
             const double lr = oth[sl].lognormal ? oth[sl](sb, lsb) - ow : fma(da[sl], lsb, fma(nb[sl], sb, nc[sl]));
+#endif
             const double l = fmax(lr, ltlo[sl]);
             lmax = sl >= jm ? fmax(lmax, l) : lmax;
         }
         const double lsig = convex ? fmin(0.0, lmax + lnup) : 0.0;
-        double Bv = exp_fin(lw + lsig) * (cur - stop);
+        double Bv = exp_node(exp_arg_clamp(lw + lsig)) * (cur - stop);
         if (KIND == KF_LONG) Bv *= fma(Q.kf[1] * sb, sb, Q.kf[2] * sb);  // G(s) <= c_a s + c_b s^2
         bool stopb = true;
 #pragma unroll
@@ -1445,18 +1499,36 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
         double K[3] = {0.0, 0.0, 0.0}, G[3] = {0.0, 0.0, 0.0};
         --budget;
         // one node: t, u = e^t, its Kronrod weight and (Gauss nodes) its Gauss weight
+#if CLOUDY_WALK_TU
+        // u is handed over as a FACTOR ef of the panel's ucw (the pairs: ucw = e^c, ef = e^(+-d); PHASE 2: ucw = 1, ef = u) and never
+        // formed: th_j ucw and the slots' nb th_j ucw once per panel, -ucw ef inside the weight's exponent
+        double ucw = 1.0, thuc = thj, nbuc[NM];
+        const auto eval_node = [&](double t, double ef, double wk, double wg, bool gauss) {
+            const double wt = exp_node(fma(-ucw, ef, fma(A, t, -lgA)));   // (the argument is inside the rule's range: > -1e3)
+            const double s = thuc * ef, ls = t + lnthj;
+            const double ow = anyln ? own(s, ls) : 0.0;
+            double up = 0.0, den = 1.0;
+#pragma unroll
+            for (int sl = 0; sl < NM; ++sl) {
+                const double lr = oth[sl].lognormal ? oth[sl](s, ls) - ow : fma(da[sl], t, fma(nbuc[sl], ef, ncu[sl]));
+                const double rho = exp_node(exp_arg_clamp(lr));   // (finite: 0 x rho below is 0)
+                den += rho;
+                up = fma(upw[sl], rho, up);
+            }
+#else
         const auto eval_node = [&](double t, double u, double wk, double wg, bool gauss) {
-            const double wt = exp_node(fma(A, t, -u) - lgA);
+            const double wt = exp_node(fma(A, t, -u) - lgA);   // (the argument is inside the rule's range: > -1e3)
             const double s = u * thj, ls = t + lnthj;
             const double ow = anyln ? own(s, ls) : 0.0;
             double up = 0.0, den = 1.0;
 #pragma unroll
             for (int sl = 0; sl < NM; ++sl) {
                 const double lr = oth[sl].lognormal ? oth[sl](s, ls) - ow : fma(da[sl], ls, fma(nb[sl], s, nc[sl]));
-                const double rho = exp_node(fmin(lr, 700.0));   // (finite: 0 x rho below is 0)
+                const double rho = exp_node(exp_arg_clamp(lr));   // (finite: 0 x rho below is 0)
                 den += rho;
                 up = fma(upw[sl], rho, up);
             }
+#endif
             double hh = wt * (up * recip_node(den));
             if (PHASE == 1)   // outside [x_t, 2 x_t]: both particles below x_t, or the larger one above
                 hh *= s <= Q.kf[0] ? (Q.kf[1] * gl) * (s * s) : Q.kf[2] * s;
@@ -1478,6 +1550,10 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
             // of the node with the table code left 220 registers in scratch, 221 scratch accesses per trip and 20 KB of HBM
             // traffic per parcel (VALU busy 0.35; round 5 PMC); rolled: 30 accesses per trip.  Node positions go through xi;
             // the panel with the singular edge maps t = a0 + h xi^4.
+#if CLOUDY_WALK_TU
+#pragma unroll
+            for (int sl = 0; sl < NM; ++sl) nbuc[sl] = nbu[sl];
+#endif
             const auto node_at = [&](double xi, double wk, double wg) {
                 const double xi2 = xi * xi;
                 const double tt = sing ? xi2 * xi2 : xi, jac = sing ? 4.0 * (xi2 * xi) : 1.0;
@@ -1496,6 +1572,20 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
             // and its reciprocal (8 exponentials + 7 reciprocals per panel for the 15 values of u instead of 15 exponentials; round
             // 4).  The pairs are taken from the outside in (g = 0 with 14, ...), the centre last.
             const double uc = exp_fin(c);
+#if CLOUDY_WALK_TU
+            ucw = uc;
+            thuc = thj * uc;
+#pragma unroll
+            for (int sl = 0; sl < NM; ++sl) nbuc[sl] = nbu[sl] * uc;
+#pragma unroll
+            for (int g = 0; g < 7; ++g) {
+                const double d = hw * kGKX[14 - g];   // > 0
+                const double e = exp_small(d), re = recip_cubic(e);
+                eval_node(c - d, re, kGKWK[g], kGKWG[g], (g & 1) != 0);
+                eval_node(c + d, e, kGKWK[14 - g], kGKWG[14 - g], (g & 1) != 0);
+            }
+            eval_node(c, 1.0, kGKWK[7], kGKWG[7], true);
+#else
 #pragma unroll
             for (int g = 0; g < 7; ++g) {
                 const double d = hw * kGKX[14 - g];   // > 0
@@ -1504,6 +1594,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
                 eval_node(c + d, uc * e, kGKWK[14 - g], kGKWG[14 - g], (g & 1) != 0);
             }
             eval_node(c, uc, kGKWK[7], kGKWG[7], true);
+#endif
         }
         bool ok = true;
 #pragma unroll
