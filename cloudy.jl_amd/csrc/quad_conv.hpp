@@ -654,7 +654,8 @@ __device__ __forceinline__ double conv_long_G_mid(const QArgs &Q, double k, doub
 // -- g is a polynomial for integer k, bounded by 1, with its only singularity at y = 1 -- so a rule tabulates g ONCE, before
 // the walk, at kLongNT Chebyshev points of [0, 1/2] (one continued fraction each: every lane the same dozen), turns the values
 // into Chebyshev coefficients (the cosine transform below: perfectly conditioned) and a node between x_t and 2 x_t costs one
-// logarithm, two exponentials and a kLongNT-term Clenshaw sum, the same for every lane.  Truncation + rounding against
+// logarithm, two exponentials and a kLongNT-term Clenshaw sum (round 6: the same polynomial in powers of 4 y - 1 by Horner,
+// kLongMono below), the same for every lane.  Truncation + rounding against
 // 30-digit mpmath over k in [1e-8, 10]: <= 7e-13 absolute in I_y (kLongNT = 12); shapes beyond kLongTabKmax (a plan whose
 // k_range allows them) keep the continued fraction per node, as do N = 4 plans (the tables of three rules would not leave
 // two workgroups per CU their LDS).
@@ -663,20 +664,25 @@ constexpr double kLongTabKmax = 10.0;
 // y_i = (1 + cos(pi (i + 1/2) / 12)) / 4 and ln(1 - y_i)
 __device__ static const double kLongY[kLongNT] = {0.4978612153434526028, 0.480969883127821689, 0.4483383350728087911, 0.4021903572521801599, 0.3456708580912724429, 0.2826315480550128979, 0.2173684519449871021, 0.1543291419087275571, 0.09780964274781984015, 0.05166166492719120886, 0.01903011687217831097, 0.002138784656547397214};
 __device__ static const double kLongL1mY[kLongNT] = {-0.6888787340401301498, -0.65579336884439617, -0.5948203464774217886, -0.5144828988712590366, -0.4241447790355740864, -0.3321656903945551713, -0.2450932581667887604, -0.1676250517077815243, -0.1029297421028883111, -0.05304394686174657753, -0.01921352006354706144, -0.002141075122909895517};
-// kLongDct[i][r] = (r == 0 ? 1 : 2) / 12 cos(r pi (i + 1/2) / 12): coefficient r of the Chebyshev series from the node values
-__device__ static const double kLongDct[kLongNT][kLongNT] = {
-    {0.08333333333333333333, 0.1652408102289684019, 0.1609876377148447145, 0.1539799220852144594, 0.1443375672974064411, 0.1322255567152058608, 0.1178511301977579207, 0.1014602381681201066, 0.08333333333333333333, 0.06378057206084829529, 0.04313650751708679372, 0.02175436537000859859},
-    {0.08333333333333333333, 0.1539799220852144594, 0.1178511301977579207, 0.06378057206084829529, 0.0, -0.06378057206084829529, -0.1178511301977579207, -0.1539799220852144594, -0.1666666666666666667, -0.1539799220852144594, -0.1178511301977579207, -0.06378057206084829529},
-    {0.08333333333333333333, 0.1322255567152058608, 0.04313650751708679372, -0.06378057206084829529, -0.1443375672974064411, -0.1652408102289684019, -0.1178511301977579207, -0.02175436537000859859, 0.08333333333333333333, 0.1539799220852144594, 0.1609876377148447145, 0.1014602381681201066},
-    {0.08333333333333333333, 0.1014602381681201066, -0.04313650751708679372, -0.1539799220852144594, -0.1443375672974064411, -0.02175436537000859859, 0.1178511301977579207, 0.1652408102289684019, 0.08333333333333333333, -0.06378057206084829529, -0.1609876377148447145, -0.1322255567152058608},
-    {0.08333333333333333333, 0.06378057206084829529, -0.1178511301977579207, -0.1539799220852144594, 3.723127401091647207e-42, 0.1539799220852144594, 0.1178511301977579207, -0.06378057206084829529, -0.1666666666666666667, -0.06378057206084829529, 0.1178511301977579207, 0.1539799220852144594},
-    {0.08333333333333333333, 0.02175436537000859859, -0.1609876377148447145, -0.06378057206084829529, 0.1443375672974064411, 0.1014602381681201066, -0.1178511301977579207, -0.1322255567152058608, 0.08333333333333333333, 0.1539799220852144594, -0.04313650751708679372, -0.1652408102289684019},
-    {0.08333333333333333333, -0.02175436537000859859, -0.1609876377148447145, 0.06378057206084829529, 0.1443375672974064411, -0.1014602381681201066, -0.1178511301977579207, 0.1322255567152058608, 0.08333333333333333333, -0.1539799220852144594, -0.04313650751708679372, 0.1652408102289684019},
-    {0.08333333333333333333, -0.06378057206084829529, -0.1178511301977579207, 0.1539799220852144594, 3.998731682401833717e-42, -0.1539799220852144594, 0.1178511301977579207, 0.06378057206084829529, -0.1666666666666666667, 0.06378057206084829529, 0.1178511301977579207, -0.1539799220852144594},
-    {0.08333333333333333333, -0.1014602381681201066, -0.04313650751708679372, 0.1539799220852144594, -0.1443375672974064411, 0.02175436537000859859, 0.1178511301977579207, -0.1652408102289684019, 0.08333333333333333333, 0.06378057206084829529, -0.1609876377148447145, 0.1322255567152058608},
-    {0.08333333333333333333, -0.1322255567152058608, 0.04313650751708679372, 0.06378057206084829529, -0.1443375672974064411, 0.1652408102289684019, -0.1178511301977579207, 0.02175436537000859859, 0.08333333333333333333, -0.1539799220852144594, 0.1609876377148447145, -0.1014602381681201066},
-    {0.08333333333333333333, -0.1539799220852144594, 0.1178511301977579207, -0.06378057206084829529, 3.585325260436553952e-42, 0.06378057206084829529, -0.1178511301977579207, 0.1539799220852144594, -0.1666666666666666667, 0.1539799220852144594, -0.1178511301977579207, 0.06378057206084829529},
-    {0.08333333333333333333, -0.1652408102289684019, 0.1609876377148447145, -0.1539799220852144594, 0.1443375672974064411, -0.1322255567152058608, 0.1178511301977579207, -0.1014602381681201066, 0.08333333333333333333, -0.06378057206084829529, 0.04313650751708679372, -0.02175436537000859859}};
+// kLongMono[i][m]: coefficient m of the interpolating polynomial IN POWERS OF z = 4 y - 1 from the node values -- the cosine
+// transform ((r == 0 ? 1 : 2) / 12 cos(r pi (i + 1/2) / 12): Chebyshev coefficient r) times the expansion of T_r in powers of
+// z, formed in 40-digit arithmetic.  Round 6, last day: a node then evaluates g by Horner, two chains of five FMAs in z^2,
+// instead of a 12-term Clenshaw sum (an FMA and a subtraction per term, one chain): 12 instead of 23 instructions per node of a
+// hole.  Entries reach 562 and g is bounded by 1: 2e-13 of rounding in g (numpy against 40-digit values over k in [1e-8, 10]),
+// beside the 12-point interpolation's own 1.4e-11 (in g; <= 7e-13 in I_y).
+__device__ static const double kLongMono[kLongNT][kLongNT] = {
+    {-0.01097104146561632112, -0.01106571014994634529, 0.7787537897977534927, 0.7854736255515628456, -8.423423384614512823, -8.496108772950288064, 30.7507912521321291, 31.01613861765528237, -44.5480629552044293, -44.93246643436705004, 22.08589184874843839, 22.27647013888880496},
+    {0.0345177968644245874, 0.03736179409733042651, -2.444841259718689435, -2.646277110472540478, 26.13063966192888182, 28.28360055872290008, -93.09783532115045802, -100.7683708157189963, 129.5161133197968052, 140.1872308695338979, -60.33977866125205542, -65.31130579030865437},
+    {-0.06394391566491336191, -0.08059954173942211059, 4.5023684289293516, 5.675111202376181658, -46.55956804149142378, -58.68705112453385624, 155.2015847409644934, 195.6273161766621412, -195.3975096083345678, -246.2931706276113185, 82.4256705100004938, 103.8952838841549891},
+    {0.108602114403433813, 0.1783984812905714895, -7.526300685504181875, -12.36330083816194929, 70.91683363139958739, 116.4936381512825583, -197.8682514076311601, -325.0341463483171081, 216.7308429416679012, 356.0193412624425403, -82.4256705100004938, -135.3989700763708014},
+    {-0.2011844635310912541, -0.5257203383164916734, 13.1115079263853561, 34.26202134059632493, -79.46397299526221516, -207.6493683150922371, 178.4311686544837914, 466.2631134871182447, -172.1827799864634719, -449.9352870395410811, 60.33977866125205542, 157.6754402152596064},
+    {0.6329795093937625367, 4.849444380685177597, -8.421488199889589884, -64.51952712825610705, 37.39949112803968255, 286.5286307056946956, -73.41745791879879577, -562.4729923556317233, 65.88139628853776263, 504.7369816585899212, -22.08589184874843839, -169.2065896744636435},
+    {0.6329795093937625367, -4.849444380685177597, -8.421488199889589884, 64.51952712825610705, 37.39949112803968255, -286.5286307056946956, -73.41745791879879577, 562.4729923556317233, 65.88139628853776263, -504.7369816585899212, -22.08589184874843839, 169.2065896744636435},
+    {-0.2011844635310912541, 0.5257203383164916734, 13.1115079263853561, -34.26202134059632493, -79.46397299526221516, 207.6493683150922371, 178.4311686544837914, -466.2631134871182447, -172.1827799864634719, 449.9352870395410811, 60.33977866125205542, -157.6754402152596064},
+    {0.108602114403433813, -0.1783984812905714895, -7.526300685504181875, 12.36330083816194929, 70.91683363139958739, -116.4936381512825583, -197.8682514076311601, 325.0341463483171081, 216.7308429416679012, -356.0193412624425403, -82.4256705100004938, 135.3989700763708014},
+    {-0.06394391566491336191, 0.08059954173942211059, 4.5023684289293516, -5.675111202376181658, -46.55956804149142378, 58.68705112453385624, 155.2015847409644934, -195.6273161766621412, -195.3975096083345678, 246.2931706276113185, 82.4256705100004938, -103.8952838841549891},
+    {0.0345177968644245874, -0.03736179409733042651, -2.444841259718689435, 2.646277110472540478, 26.13063966192888182, -28.28360055872290008, -93.09783532115045802, 100.7683708157189963, 129.5161133197968052, -140.1872308695338979, -60.33977866125205542, 65.31130579030865437},
+    {-0.01097104146561632112, 0.01106571014994634529, 0.7787537897977534927, -0.7854736255515628456, -8.423423384614512823, 8.496108772950288064, 30.7507912521321291, -31.01613861765528237, -44.5480629552044293, 44.93246643436705004, 22.08589184874843839, -22.27647013888880496}};
 
 // e^x for the walk's nodes: the weight and the density ratios of a node enter its value as FACTORS, so 4e-14 of relative error
 // each is far inside the walk's budget (acceptance at 1e-7 of scale, results <= 1e-9; exp_fin is good to an ulp, which nothing
@@ -686,28 +692,13 @@ __device__ static const double kLongDct[kLongNT][kLongNT] = {
 // The integer n is read from the LOW WORD of x / ln 2 + 1.5 2^52 instead of v_rndne + v_cvt_i32 (round 6, last day:
 // 13 instructions; |n| < 2^31 is the caller's business -- exp_arg_clamp).  An LDS table of 2^(j/64) per lane of a
 // wave (32 KB, conflict-free) with a degree-4 polynomial was measured too: 9 fp64 + 5 integer instructions + a ds_read_b64 per
-// exponential, hydrodynamic 21.9 against 20.6 ms, constant 8.2 against 7.8 -- the reads' latency is not covered at two waves per SIMD.
-#ifndef CLOUDY_EXP_ESTRIN
-#define CLOUDY_EXP_ESTRIN 0
-#endif
+// exponential, hydrodynamic 21.9 against 20.6 ms, constant 8.2 against 7.8 -- the reads' latency is not covered at two waves per SIMD;
+// an Estrin form of the polynomial (chains of 5 instead of 9, one instruction more): 21.2 against 20.6.
 __device__ __forceinline__ double exp_node(double x) {
     constexpr double kMagic = 0x1.8p52;
     const double t = fma(x, 1.4426950408889634, kMagic);
     const double n = t - kMagic;
     const double r = fma(n, -0.6931471805599453, x);
-#if CLOUDY_EXP_ESTRIN
-    // 1 + r + r^2 (c2 + c3 r + r^2 (c4 + c5 r + r^2 (c6 + c7 r + r^2 (c8 + c9 r)))): chains of 5 instead of 10
-    const double r2 = r * r;
-    const double q4 = fma(0x1.710182df3d7acp-19, r, 0x1.a16e32bc8180fp-16);
-    const double q3 = fma(0x1.a01b7383bafc4p-13, r, 0x1.6c163be91fb17p-10);
-    const double q2 = fma(0x1.1111108e2cc07p-7, r, 0x1.5555557deef18p-5);
-    const double q1 = fma(0x1.5555555589f00p-3, r, 0x1.fffffffff13f6p-2);
-    const double q0 = r + 1.0;
-    double p = fma(q4, r2, q3);
-    p = fma(p, r2, q2);
-    p = fma(p, r2, q1);
-    p = fma(p, r2, q0);
-#else
     double p = 0x1.710182df3d7acp-19;
     p = fma(p, r, 0x1.a16e32bc8180fp-16);
     p = fma(p, r, 0x1.a01b7383bafc4p-13);
@@ -718,7 +709,6 @@ __device__ __forceinline__ double exp_node(double x) {
     p = fma(p, r, 0x1.fffffffff13f6p-2);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-#endif
     return ldexp(p, __double2loint(t));
 }
 // x limited to [-1e9, 700] by two INTEGER operations on its high word (2 cycles each on a SIMD with two waves; a v_min_f64 is 4 and
@@ -763,7 +753,7 @@ __device__ __forceinline__ double exp_small(double x) {
     p = fma(p, r, 1.0);
     return ldexp(p, __double2loint(t));
 }
-// the Chebyshev coefficients of g for shape k, left in the lane's own LDS slots sh[row0 + r][lane] (conflict-free, no barrier:
+// the coefficients of g's interpolating polynomial (in powers of 4 y - 1) for shape k, left in the lane's own LDS slots sh[row0 + r][lane] (conflict-free, no barrier:
 // a lane reads what it wrote)
 template <int NROW>
 __device__ __forceinline__ void conv_long_tab_build(double k, double (&sh)[NROW][kConvBlock], int row0) {
@@ -775,7 +765,7 @@ __device__ __forceinline__ void conv_long_tab_build(double k, double (&sh)[NROW]
         // (1 - y)^k 2F1(2k, 1; k+1; y): inc_beta_cf(k, k, y) is the hypergeometric factor (y < 1/2: its range of convergence)
         const double g = exp_fin(k * kLongL1mY[i]) * inc_beta_cf(k, k, kLongY[i]);
 #pragma unroll
-        for (int r = 0; r < kLongNT; ++r) c[r] = fma(kLongDct[i][r], g, c[r]);
+        for (int r = 0; r < kLongNT; ++r) c[r] = fma(kLongMono[i][r], g, c[r]);
     }
 #pragma unroll
     for (int r = 0; r < kLongNT; ++r) sh[row0 + r][threadIdx.x] = c[r];
@@ -787,19 +777,19 @@ __device__ __forceinline__ double conv_long_G_mid_tab(const QArgs &Q, double k, 
                                                       const double (&sh)[NROW][kConvBlock], int row0) {
     const double xt = Q.kf[0], cb = Q.kf[1], ca = Q.kf[2];
     const double x = xt * recip_cubic(s), y = 1.0 - x;   // y in (0, 1/2)
-    const double z2 = fma(8.0, y, -2.0);                // 2 z, z = 4 y - 1 in [-1, 1]
-    double b1 = 0.0, b2 = 0.0;                           // Clenshaw: b_r = c_r + 2 z b_{r+1} - b_{r+2}
+    const double z = fma(4.0, y, -1.0), w = z * z;       // z = 4 y - 1 in [-1, 1]
     // (the lane index through an opaque copy: the twelve coefficients are READ here, per node -- left alone the compiler hoists
     // the reads out of the node loop and keeps them in 24 registers the walk does not have: scratch instead of LDS)
     int tl = threadIdx.x;
     asm volatile("" : "+v"(tl));
+    static_assert(kLongNT == 12, "two Horner chains of six coefficients");
+    double pe = sh[row0 + 10][tl], po = sh[row0 + 11][tl];
 #pragma unroll
-    for (int r = kLongNT - 1; r >= 1; --r) {
-        const double b0 = fma(z2, b1, sh[row0 + r][tl]) - b2;
-        b2 = b1;
-        b1 = b0;
+    for (int r = 8; r >= 0; r -= 2) {
+        pe = fma(pe, w, sh[row0 + r][tl]);
+        po = fma(po, w, sh[row0 + r + 1][tl]);
     }
-    const double g = fma(0.5 * z2, b1, sh[row0][tl]) - b2;
+    const double g = fma(po, z, pe);
     const double yk = exp_node(k * log_pos(y)) * c0;     // y^k / (k B(k, k))   (factors of I_y and D: exp_node's 4e-14 is theirs)
     const double Dk = yk * exp_node(k * lx);             // x^k y^k / (k B(k, k)) = D(k, k) / k
     const double Ikk = fma(-yk, g, 1.0);                 // I_x(k, k) = 1 - I_y(k, k)
@@ -1262,6 +1252,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
     int j = -1, jm = -1;   // the rule in hand and its mode (the same number in the merged walk)
     double A = 1.0, lgA = 0.0, thj = 1.0, lnthj = 0.0, tlo = 0.0, thi = 0.0, kj = 1.0, lgB = 0.0, rB = 0.0, gl = 0.0, c0 = 0.0;
     double scaleS[3] = {1.0, 1.0, 1.0}, out[3] = {0.0, 0.0, 0.0};
+    double flo[3] = {kConvFloor, kConvFloor, kConvFloor};   // kConvFloor x scaleS, formed when a rule is taken
     double tmode = 0.0, lwmode = 0.0, lnup = 0.0, ltlo[NM];
     bool convex = false;
     ConvLogDensity own, oth[NM];
@@ -1270,11 +1261,8 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
     // without the cancellation of that difference); Lognormal modes keep the general form.  (Round 4: -7 of ~118 instructions
     // per node for an all-Gamma plan, where `own` and `oth` then drop out of the loop.)
     double da[NM], nb[NM], nc[NM];
-#ifndef CLOUDY_WALK_TU
-#define CLOUDY_WALK_TU 1
-#endif
-    // (CLOUDY_WALK_TU: the same line in the rule's own variables, ln rho = da t + (nb th_j) u + (nc + da ln th_j) -- a node then
-    // needs s = u th_j for its moments only and ln s not at all)
+    // (round 6, last day: the same line in the rule's own variables, ln rho = da t + (nb th_j) u + (nc + da ln th_j) -- a node of an
+    // all-Gamma plan then needs neither s nor ln s for its density ratios)
     double nbu[NM], ncu[NM];
     double upw[NM];   // 1 for the slots of the modes above the rule's own (they make up 1 - w), 0 below: one FMA instead of a select
     bool anyln = false;
@@ -1388,13 +1376,11 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
             j = jn;
             jm = kSingle ? jsingle : jn;
             mk.shift = lnthj;
-#if CLOUDY_WALK_TU
 #pragma unroll
             for (int sl = 0; sl < NM; ++sl) {
                 nbu[sl] = nb[sl] * thj;
                 ncu[sl] = fma(da[sl], lnthj, nc[sl]);
             }
-#endif
             h0 = (thi - tlo) * (1.0 / double(kConvNInit));
             gap = 1e-7 * (thi - tlo);
 #pragma unroll
@@ -1407,6 +1393,8 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
                 scaleS[1] = A * thj;
                 scaleS[2] = A * (A + 1.0) * thj * thj;
             }
+#pragma unroll
+            for (int e = 0; e < 3; ++e) flo[e] = kConvFloor * scaleS[e];
             stop = tlo;
             if (PHASE != 0) {
                 hlo = fmin(fmax(mk.extra[1], tlo), thi);
@@ -1443,11 +1431,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
         double lmax = -INFINITY;
 #pragma unroll
         for (int sl = 0; sl < NM; ++sl) {
-#if CLOUDY_WALK_TU
             const double lr = oth[sl].lognormal ? oth[sl](sb, lsb) - ow : fma(da[sl], cur, fma(nbu[sl], ub, ncu[sl]));
-#else
-            const double lr = oth[sl].lognormal ? oth[sl](sb, lsb) - ow : fma(da[sl], lsb, fma(nb[sl], sb, nc[sl]));
-#endif
             const double l = fmax(lr, ltlo[sl]);
             lmax = sl >= jm ? fmax(lmax, l) : lmax;
         }
@@ -1457,7 +1441,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
         bool stopb = true;
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
-            if (!(Bv <= kConvTermTol * fmax(fabs(out[e]), kConvFloor * scaleS[e]))) stopb = false;
+            if (!(Bv <= kConvTermTol * fmax(fabs(out[e]), flo[e]))) stopb = false;
             Bv *= sb;
         }
         // PHASE 1: an edge on the upper end of the hole jumps to its lower end
@@ -1499,10 +1483,10 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
         double K[3] = {0.0, 0.0, 0.0}, G[3] = {0.0, 0.0, 0.0};
         --budget;
         // one node: t, u = e^t, its Kronrod weight and (Gauss nodes) its Gauss weight
-#if CLOUDY_WALK_TU
         // u is handed over as a FACTOR ef of the panel's ucw (the pairs: ucw = e^c, ef = e^(+-d); PHASE 2: ucw = 1, ef = u) and never
         // formed: th_j ucw and the slots' nb th_j ucw once per panel, -ucw ef inside the weight's exponent
         double ucw = 1.0, thuc = thj, nbuc[NM];
+        constexpr bool kMomEf = PHASE == 0;
         const auto eval_node = [&](double t, double ef, double wk, double wg, bool gauss) {
             const double wt = exp_node(fma(-ucw, ef, fma(A, t, -lgA)));   // (the argument is inside the rule's range: > -1e3)
             const double s = thuc * ef, ls = t + lnthj;
@@ -1515,27 +1499,15 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
                 den += rho;
                 up = fma(upw[sl], rho, up);
             }
-#else
-        const auto eval_node = [&](double t, double u, double wk, double wg, bool gauss) {
-            const double wt = exp_node(fma(A, t, -u) - lgA);   // (the argument is inside the rule's range: > -1e3)
-            const double s = u * thj, ls = t + lnthj;
-            const double ow = anyln ? own(s, ls) : 0.0;
-            double up = 0.0, den = 1.0;
-#pragma unroll
-            for (int sl = 0; sl < NM; ++sl) {
-                const double lr = oth[sl].lognormal ? oth[sl](s, ls) - ow : fma(da[sl], ls, fma(nb[sl], s, nc[sl]));
-                const double rho = exp_node(exp_arg_clamp(lr));   // (finite: 0 x rho below is 0)
-                den += rho;
-                up = fma(upw[sl], rho, up);
-            }
-#endif
             double hh = wt * (up * recip_node(den));
             if (PHASE == 1)   // outside [x_t, 2 x_t]: both particles below x_t, or the larger one above
                 hh *= s <= Q.kf[0] ? (Q.kf[1] * gl) * (s * s) : Q.kf[2] * s;
             if (PHASE == 2)   // inside: this rule's table (rows j * kLongNT + r of the lane's LDS column); ln(x_t / s) = ex1 - t
                 hh *= LTAB ? conv_long_G_mid_tab(Q, kj, c0, rB, s, mk.extra[1] - t, gtab, j * kLongNT)
                            : conv_long_G_mid(Q, kj, lgB, rB, s);
-            const double v0 = hh, v1 = hh * s, v2 = (hh * s) * s;
+            // (the homogeneous kernels: the moments in powers of ef, th_j ucw and its square applied to the panel's six sums)
+            const double sm = kMomEf ? ef : s;
+            const double v0 = hh, v1 = hh * sm, v2 = (hh * sm) * sm;
             K[0] = fma(wk, v0, K[0]);
             K[1] = fma(wk, v1, K[1]);
             K[2] = fma(wk, v2, K[2]);
@@ -1550,10 +1522,8 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
             // of the node with the table code left 220 registers in scratch, 221 scratch accesses per trip and 20 KB of HBM
             // traffic per parcel (VALU busy 0.35; round 5 PMC); rolled: 30 accesses per trip.  Node positions go through xi;
             // the panel with the singular edge maps t = a0 + h xi^4.
-#if CLOUDY_WALK_TU
 #pragma unroll
             for (int sl = 0; sl < NM; ++sl) nbuc[sl] = nbu[sl];
-#endif
             const auto node_at = [&](double xi, double wk, double wg) {
                 const double xi2 = xi * xi;
                 const double tt = sing ? xi2 * xi2 : xi, jac = sing ? 4.0 * (xi2 * xi) : 1.0;
@@ -1572,7 +1542,6 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
             // and its reciprocal (8 exponentials + 7 reciprocals per panel for the 15 values of u instead of 15 exponentials; round
             // 4).  The pairs are taken from the outside in (g = 0 with 14, ...), the centre last.
             const double uc = exp_fin(c);
-#if CLOUDY_WALK_TU
             ucw = uc;
             thuc = thj * uc;
 #pragma unroll
@@ -1585,21 +1554,18 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
                 eval_node(c + d, e, kGKWK[14 - g], kGKWG[14 - g], (g & 1) != 0);
             }
             eval_node(c, 1.0, kGKWK[7], kGKWG[7], true);
-#else
-#pragma unroll
-            for (int g = 0; g < 7; ++g) {
-                const double d = hw * kGKX[14 - g];   // > 0
-                const double e = exp_small(d), re = recip_cubic(e);
-                eval_node(c - d, uc * re, kGKWK[g], kGKWG[g], (g & 1) != 0);
-                eval_node(c + d, uc * e, kGKWK[14 - g], kGKWG[14 - g], (g & 1) != 0);
+            if (kMomEf) {
+                const double thuc2 = thuc * thuc;
+                K[1] *= thuc;
+                G[1] *= thuc;
+                K[2] *= thuc2;
+                G[2] *= thuc2;
             }
-            eval_node(c, uc, kGKWK[7], kGKWG[7], true);
-#endif
         }
         bool ok = true;
 #pragma unroll
         for (int e = 0; e < 3; ++e)
-            if (fabs(K[e] - G[e]) * hw > kTolT * fmax(fabs(fma(K[e], hw, out[e])), kConvFloor * scaleS[e])) ok = false;
+            if (fabs(K[e] - G[e]) * hw > kTolT * fmax(fabs(fma(K[e], hw, out[e])), flo[e])) ok = false;
         const bool accept = ok || L == kConvLMax || budget <= 0;
         if (accept && hw > 0.0) {   // (hw = 0: the panel of width zero of a rule that ended before its first panel, see next_panel)
 #pragma unroll
