@@ -1017,22 +1017,24 @@ int cloudy_closure_stats(const cloudy_plan *plan, size_t n, size_t ld, const voi
     a.kmin = h.kmin;
     a.kmax = h.kmax;
     hipStream_t st = (hipStream_t)stream;
-    unsigned long long *dev = nullptr;
-    HIP_TRY(hipMallocAsync((void **)&dev, sizeof(unsigned long long) * nc, st));
-    hipError_t e = hipMemsetAsync(dev, 0, sizeof(unsigned long long) * nc, st);
-    if (e == hipSuccess) {
-        size_t blocks = (n + kBlock - 1) / kBlock;
-        if (blocks > (size_t)(4 * kSumBlocks)) blocks = 4 * kSumBlocks;
-        if (h.dtype != CLOUDY_F64)
-            hipLaunchKernelGGL(closure_stats_kernel<float>, dim3((unsigned)blocks), dim3(kBlock), 0, st, a, n, ld, (const float *)mom_dev, dev);
-        else
-            hipLaunchKernelGGL(closure_stats_kernel<double>, dim3((unsigned)blocks), dim3(kBlock), 0, st, a, n, ld, (const double *)mom_dev, dev);
-        e = hipGetLastError();
-    }
+    size_t blocks = (n + kBlock - 1) / kBlock;
+    if (blocks > (size_t)(4 * kSumBlocks)) blocks = 4 * kSumBlocks;
+    // one row of 4N counters per workgroup, every one of them stored by its workgroup (nothing to zero, no atomics)
     static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "counter width");
-    if (e == hipSuccess) e = hipMemcpyAsync(counts_host, dev, sizeof(uint64_t) * nc, hipMemcpyDeviceToHost, st);
+    std::vector<uint64_t> rows(blocks * (size_t)nc);
+    unsigned long long *dev = nullptr;
+    HIP_TRY(hipMallocAsync((void **)&dev, sizeof(unsigned long long) * rows.size(), st));
+    if (h.dtype != CLOUDY_F64)
+        hipLaunchKernelGGL(closure_stats_kernel<float>, dim3((unsigned)blocks), dim3(kBlock), 0, st, a, n, ld, (const float *)mom_dev, dev);
+    else
+        hipLaunchKernelGGL(closure_stats_kernel<double>, dim3((unsigned)blocks), dim3(kBlock), 0, st, a, n, ld, (const double *)mom_dev, dev);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(rows.data(), dev, sizeof(uint64_t) * rows.size(), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFreeAsync(dev, st);
+    if (e == hipSuccess)
+        for (size_t b = 0; b < blocks; ++b)
+            for (int q = 0; q < nc; ++q) counts_host[q] += rows[b * (size_t)nc + q];
     if (e != hipSuccess) return fail_hip(e, "cloudy_closure_stats");
     return CLOUDY_OK;
 }

@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(kBlock)
 //   [0] fallback: the parcel took the (0, 1, 1) branch;   [1] shape at its lower clamp (Gamma: k = k_min; Lognormal: sigma = eps);
 //   [2] shape at its upper clamp (Gamma: k = k_max);      [3] check_moment_consistency (:437-449) would throw for the mode's
 //   normalised moments: a negative moment, or (three moments) a negative second central moment, summed in the reference's order.
-// One pass; a lane counts its parcels in registers, a wave adds its lanes, one atomic per wave and counter.
+// One pass; a lane counts its parcels in registers, a workgroup adds its lanes and stores one row of 4N counters, the host adds the rows.
 struct ClosureStatsArgs {
     int N;
     int dist_type[CLOUDY_MAX_MODES], np[CLOUDY_MAX_MODES], off[CLOUDY_MAX_MODES];
@@ -122,13 +122,25 @@ __global__ void __launch_bounds__(kBlock)
             c[4 * m + 3] += moments_inconsistent(np, m0, m1, m2) ? 1u : 0u;
         }
     }
+    // a wave adds its lanes, the workgroup its waves, and every workgroup STORES its own row of `counts` (the host adds the rows).
+    // No counter is shared between workgroups: the first version zeroed 4N counters with hipMemsetAsync and added to them with one
+    // atomic per wave -- on one box of the pool the counters of the first two modes came back short (105 of 469), those of the
+    // last two whole: the zeros of the fill arrived in the middle of the kernel's atomics (round 6, last day).
+    __shared__ unsigned int sh_c[kBlock / 64][4 * CLOUDY_MAX_MODES];
 #pragma unroll
     for (int q = 0; q < 4 * CLOUDY_MAX_MODES; ++q) {
         if (q >= 4 * a.N) break;
         unsigned int v = c[q];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        if ((threadIdx.x & 63) == 0 && v != 0u) atomicAdd(&counts[q], (unsigned long long)v);
+        if ((threadIdx.x & 63) == 0) sh_c[threadIdx.x >> 6][q] = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < 4 * a.N) {
+        unsigned long long t = 0ull;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) t += sh_c[w][threadIdx.x];
+        counts[(size_t)blockIdx.x * (4 * a.N) + threadIdx.x] = t;
     }
 }
 
