@@ -1250,8 +1250,8 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
     bool mid_flag = false;         // PHASE 1, set by next_panel when a rule ends: its hole has to be walked
     // ---- the state of the rule in hand
     int j = -1, jm = -1;   // the rule in hand and its mode (the same number in the merged walk)
-    double A = 1.0, lgA = 0.0, thj = 1.0, lnthj = 0.0, tlo = 0.0, thi = 0.0, kj = 1.0, lgB = 0.0, rB = 0.0, gl = 0.0, c0 = 0.0;
-    double scaleS[3] = {1.0, 1.0, 1.0}, out[3] = {0.0, 0.0, 0.0};
+    double A = 1.0, lgA = 0.0, thj = 1.0, lnthj = 0.0, tlo = 0.0, kj = 1.0, lgB = 0.0, rB = 0.0, gl = 0.0, c0 = 0.0;
+    double out[3] = {0.0, 0.0, 0.0};
     double flo[3] = {kConvFloor, kConvFloor, kConvFloor};   // kConvFloor x scaleS, formed when a rule is taken
     double tmode = 0.0, lwmode = 0.0, lnup = 0.0, ltlo[NM];
     bool convex = false;
@@ -1260,10 +1260,10 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
     // differences formed once per rule -- two FMAs per node and slot instead of two log densities and their difference (and
     // without the cancellation of that difference); Lognormal modes keep the general form.  (Round 4: -7 of ~118 instructions
     // per node for an all-Gamma plan, where `own` and `oth` then drop out of the loop.)
-    double da[NM], nb[NM], nc[NM];
+    double da[NM], nb[NM];
     // (round 6, last day: the same line in the rule's own variables, ln rho = da t + (nb th_j) u + (nc + da ln th_j) -- a node of an
     // all-Gamma plan then needs neither s nor ln s for its density ratios)
-    double nbu[NM], ncu[NM];
+    double ncu[NM];
     double upw[NM];   // 1 for the slots of the modes above the rule's own (they make up 1 - w), 0 below: one FMA instead of a select
     bool anyln = false;
     ConvMarks<NM> mk;
@@ -1281,8 +1281,8 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
 #pragma unroll
     for (int sl = 0; sl < NM; ++sl) {
         ltlo[sl] = 0.0;
-        da[sl] = nb[sl] = nc[sl] = 0.0;
-        nbu[sl] = ncu[sl] = 0.0;
+        da[sl] = nb[sl] = 0.0;
+        ncu[sl] = 0.0;
         upw[sl] = 0.0;
         mk.c[sl] = 0.0;
         mk.w[sl] = 1.0;
@@ -1297,6 +1297,12 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
     const auto next_rule = [&](bool need, auto rmin_c) {
         constexpr int rmin = decltype(rmin_c)::value;
         int jn = NR;
+        // (what only the block `if (go)` below reads is local: carried through the walk's loop in a chain of selects it would stay
+        // live across it -- the compiler does not see that `go` implies one of the selects)
+        double nc[NM];   // c_j - c_m of the rule taken: every slot is set when one is
+        double thi = 0.0, scaleS[3] = {1.0, 1.0, 1.0};
+#pragma unroll
+        for (int sl = 0; sl < NM; ++sl) nc[sl] = 0.0;
 #pragma unroll
         for (int r = NR - 1; r >= rmin; --r)
             if (rb[r].valid && (PHASE != 2 || midneed[r]) && r > j) jn = r;
@@ -1378,7 +1384,6 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
             mk.shift = lnthj;
 #pragma unroll
             for (int sl = 0; sl < NM; ++sl) {
-                nbu[sl] = nb[sl] * thj;
                 ncu[sl] = fma(da[sl], lnthj, nc[sl]);
             }
             h0 = (thi - tlo) * (1.0 / double(kConvNInit));
@@ -1431,7 +1436,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
         double lmax = -INFINITY;
 #pragma unroll
         for (int sl = 0; sl < NM; ++sl) {
-            const double lr = oth[sl].lognormal ? oth[sl](sb, lsb) - ow : fma(da[sl], cur, fma(nbu[sl], ub, ncu[sl]));
+            const double lr = oth[sl].lognormal ? oth[sl](sb, lsb) - ow : fma(da[sl], cur, fma(nb[sl], sb, ncu[sl]));
             const double l = fmax(lr, ltlo[sl]);
             lmax = sl >= jm ? fmax(lmax, l) : lmax;
         }
@@ -1523,7 +1528,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
             // traffic per parcel (VALU busy 0.35; round 5 PMC); rolled: 30 accesses per trip.  Node positions go through xi;
             // the panel with the singular edge maps t = a0 + h xi^4.
 #pragma unroll
-            for (int sl = 0; sl < NM; ++sl) nbuc[sl] = nbu[sl];
+            for (int sl = 0; sl < NM; ++sl) nbuc[sl] = nb[sl] * thj;
             const auto node_at = [&](double xi, double wk, double wg) {
                 const double xi2 = xi * xi;
                 const double tt = sing ? xi2 * xi2 : xi, jac = sing ? 4.0 * (xi2 * xi) : 1.0;
@@ -1545,7 +1550,7 @@ __device__ __forceinline__ void conv_T_merged(const QArgs &Q, const ConvLogDensi
             ucw = uc;
             thuc = thj * uc;
 #pragma unroll
-            for (int sl = 0; sl < NM; ++sl) nbuc[sl] = nbu[sl] * uc;
+            for (int sl = 0; sl < NM; ++sl) nbuc[sl] = nb[sl] * thuc;
 #pragma unroll
             for (int g = 0; g < 7; ++g) {
                 const double d = hw * kGKX[14 - g];   // > 0
