@@ -1853,7 +1853,12 @@ def test_closure_stats_vs_oracle(gpu_cloudy, oracle):
     # four modes, MovingThreshold
     w4 = bench.make_workload("moving4", 200_000, seed=4)
     p4 = w4["coal_data"].plan(w4["dist_types"])
-    assert np.array_equal(cloudy.closure_stats(p4, dev(cloudy, w4["mom"])), O.closure_stats(bench.oracle_params("moving4"), w4["mom"]))
+    m4, want4 = dev(cloudy, w4["mom"]), O.closure_stats(bench.oracle_params("moving4"), w4["mom"])
+    assert np.array_equal(cloudy.closure_stats(p4, m4), want4)
+    # (round 6: the first version -- a zero-fill and one atomic per wave -- came back short on this case on one box of the pool,
+    # the first two modes' counters 105 and 302 of 469; a row of counters per workgroup now: the same integers every time)
+    for _ in range(40):
+        assert np.array_equal(cloudy.closure_stats(p4, m4), want4)
     # Exponential + Gamma + Lognormal, k_range (0.5, 5): two-moment modes have no central-moment check, a Lognormal mode clamps sigma
     dt = [0, 1, 3]
     par3, op3, _ = make_case(cloudy, O, dt, [[EPS / 1e6, 5.0], [5.0, 0.0]], (INF, INF, INF), bench.NORMS, k_range=(0.5, 5.0))
